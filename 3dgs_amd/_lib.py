@@ -1,0 +1,123 @@
+"""ctypes binding of libgsplat_hip.so (declared in include/gsplat_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library cannot be built or
+loaded, ``load()`` raises, and so does every operator.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+_lib = None
+
+
+class GsplatError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"gsplat error {code}: {text}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 with hipcc (works without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    srcs.append(os.path.join(_HERE, "..", "include", "gsplat_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-j", "5", "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class Camera(ctypes.Structure):  # gsplat_camera
+    _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("focal_x", ctypes.c_float),
+                ("focal_y", ctypes.c_float), ("campos", ctypes.c_float * 3), ("view", ctypes.c_void_p),
+                ("proj", ctypes.c_void_p)]
+
+
+class Gaussians(ctypes.Structure):  # gsplat_gaussians
+    _fields_ = [("num_gaussians", ctypes.c_int), ("xyz", ctypes.c_void_p), ("rgb", ctypes.c_void_p),
+                ("sh", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("quaternion", ctypes.c_void_p)]
+
+
+class RasterConfig(ctypes.Structure):  # gsplat_raster_config
+    _fields_ = [("near_thresh", ctypes.c_float), ("mh_dist", ctypes.c_float), ("cull_mask_padding", ctypes.c_int)]
+
+
+class ForwardView(ctypes.Structure):  # gsplat_forward_view
+    _fields_ = [("num_culled", ctypes.c_size_t), ("num_pairs", ctypes.c_size_t), ("num_splats", ctypes.c_size_t),
+                ("mask", ctypes.c_void_p), ("uv", ctypes.c_void_p), ("xyz_c", ctypes.c_void_p),
+                ("compact_to_global", ctypes.c_void_p), ("sigma", ctypes.c_void_p), ("conic", ctypes.c_void_p),
+                ("J", ctypes.c_void_p), ("precomputed_rgb", ctypes.c_void_p), ("radius", ctypes.c_void_p),
+                ("uv_selected", ctypes.c_void_p), ("xyz_c_selected", ctypes.c_void_p),
+                ("sorted_gaussians", ctypes.c_void_p), ("splat_start_end_idx_by_tile_idx", ctypes.c_void_p),
+                ("image", ctypes.c_void_p), ("weight_per_pixel", ctypes.c_void_p),
+                ("splats_per_pixel", ctypes.c_void_p)]
+
+
+class Gradients(ctypes.Structure):  # gsplat_gradients
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("grad_xyz", "grad_rgb", "grad_sh", "grad_opacity", "grad_scale", "grad_quaternion", "grad_conic",
+                 "grad_uv", "grad_J", "grad_sigma", "grad_xyz_c", "grad_precompute_rgb")]
+
+
+# every symbol include/gsplat_hip.h declares, with its argument types
+_P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+SIGNATURES = {
+    "gsplat_last_error": (ctypes.c_char_p, []),
+    "gsplat_abi_version": (_I, []),
+    "gsplat_release_scratch": (_I, []),
+    "gsplat_compute_camera_space_points": (_I, [_P, _P, _I, _P, _P]),
+    "gsplat_project_to_screen": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "gsplat_cull_gaussians": (_I, [_P, _P, _I, _F, _I, _I, _I, _P, _P]),
+    "gsplat_compute_sigma": (_I, [_P, _P, _I, _P, _P]),
+    "gsplat_compute_conic": (_I, [_P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P, _P, _P]),
+    "gsplat_get_sorted_gaussian_list": (_I, [_P, _P, _P, _I, _I, _I, ctypes.POINTER(_S), _P, _P, _P]),
+    "gsplat_precompute_spherical_harmonics": (_I, [_P, _P, _P, _F, _F, _F, _I, _I, _P, _P]),
+    "gsplat_render_image": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "gsplat_project_to_screen_backward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "gsplat_compute_camera_space_points_backward": (_I, [_P, _P, _P, _I, _P, _P]),
+    "gsplat_compute_projection_jacobian_backward": (_I, [_P, _F, _F, _F, _F, _P, _I, _P, _P]),
+    "gsplat_compute_conic_backward": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "gsplat_compute_sigma_backward": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "gsplat_precompute_spherical_harmonics_backward": (_I, [_P, _P, _P, _F, _F, _F, _P, _I, _I, _P, _P, _P, _P]),
+    "gsplat_render_image_backward": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "gsplat_compact_masked_array": (_I, [_P, _P, _I, _I, _P, ctypes.POINTER(_I), _P]),
+    "gsplat_scatter_masked_array": (_I, [_P, _P, _I, _I, _P, _P]),
+    "gsplat_context_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
+    "gsplat_context_destroy": (_I, [_P]),
+    "gsplat_context_bytes": (_S, [_P]),
+    "gsplat_rasterize_image": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera),
+                                    ctypes.POINTER(RasterConfig), _F, _I, ctypes.POINTER(ForwardView), _P]),
+    "gsplat_backward_pass": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera), _P, _F, _I,
+                                  ctypes.POINTER(Gradients), _P]),
+    "gsplat_pack_gradients_global": (_I, [_P, ctypes.POINTER(Gradients), _I, _I, _P, _P]),
+    "gsplat_packed_gradient_width": (_I, [_I]),
+}
+
+
+def load():
+    """Load the library (building it first if sources are newer).  Raises if that fails."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise GsplatError(status, load().gsplat_last_error().decode("utf-8", "replace"))
+    return status

@@ -1,0 +1,232 @@
+// gs_binning.hip -- tile binning + (tile | depth) radix sort + per-tile ranges.
+//
+// Semantics follow the reference's get_sorted_gaussian_list (cuda/culling.cu:197-343,
+// 386-475): a gaussian is listed in a tile iff the tile lies in its coarse rectangle AND
+// its oriented bounding box passes the 4-axis separating-axis test against the closed
+// tile AABB; lists are ordered by depth, ties by gaussian id.
+//
+// Structure (MI355X-first, not the reference's): no (tile, gaussian) candidate-pair buffer
+// and no second coarse pass.  One thread per gaussian counts its exact hits, a rocPRIM
+// exclusive scan turns counts into offsets, the same thread then emits packed 64-bit keys
+// (tile << 32 | order-preserving depth bits) straight to their final slots, and one
+// rocPRIM radix sort over only the significant key bits orders them.  Integer-packed keys
+// replace the reference's double keys (SURVEY.md 8a hazard 3).
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "gs_common.h"
+#include "gs_math.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// coarse candidate count (what call 1 of the reference protocol reports)
+__global__ __launch_bounds__(kBlock) void coarse_count_kernel(const float *__restrict__ uv,
+                                                              const float *__restrict__ radius, int ntx, int nty,
+                                                              int N, unsigned long long *__restrict__ total) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long mine = 0;
+  if (i < N) {
+    const gs::TileRect r = gs::coarse_rect(uv[2 * i], uv[2 * i + 1], radius[4 * i], ntx, nty);
+    mine = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
+  }
+  // wave reduction, then one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+}
+
+}  // namespace
+
+namespace gs {
+
+// counts[j] <- exact number of tiles gaussian j is listed in (j = rank ? rank[i] : i for kept i)
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(const float *__restrict__ uv,
+                                                            const float *__restrict__ radius, int ntx, int nty,
+                                                            int N, const unsigned char *__restrict__ mask,
+                                                            const int *__restrict__ rank, int *__restrict__ counts,
+                                                            unsigned long long *__restrict__ coarse_total) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long coarse = 0;
+  if (i < N && (!mask || mask[i])) {
+    const int j = rank ? rank[i] : i;
+    const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
+    const float u = uv[2 * j], v = uv[2 * j + 1];
+    const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
+    int hits = 0;
+    if (r.x1 > r.x0 && r.y1 > r.y0) {
+      coarse = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
+      const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
+      for (int tx = r.x0; tx < r.x1; ++tx)
+        for (int ty = r.y0; ty < r.y1; ++ty) hits += obb_hits_tile(o, tx, ty) ? 1 : 0;
+    }
+    counts[j] = hits;
+  }
+  if (coarse_total) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) coarse += __shfl_down(coarse, off, 64);
+    if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(coarse_total, coarse);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void tile_emit_kernel(const float *__restrict__ uv,
+                                                           const float *__restrict__ xyz_c,
+                                                           const float *__restrict__ radius, int ntx, int nty, int N,
+                                                           const unsigned char *__restrict__ mask,
+                                                           const int *__restrict__ rank,
+                                                           const int *__restrict__ offsets,
+                                                           unsigned long long *__restrict__ keys,
+                                                           int *__restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N || (mask && !mask[i])) return;
+  const int j = rank ? rank[i] : i;
+  int w = offsets[j];
+  const int end = offsets[j + 1];
+  if (w == end) return;
+  const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
+  const float u = uv[2 * j], v = uv[2 * j + 1];
+  const unsigned long long zbits = float_sort_bits(xyz_c[3 * j + 2]);
+  const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
+  const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
+  for (int tx = r.x0; tx < r.x1; ++tx)
+    for (int ty = r.y0; ty < r.y1; ++ty)
+      if (obb_hits_tile(o, tx, ty) && w < end) {
+        keys[w] = ((unsigned long long)(unsigned int)(ty * ntx + tx) << 32) | zbits;
+        vals[w] = j;
+        ++w;
+      }
+}
+
+// ranges[t] = number of instances whose tile id is < t, for t in [0, T]
+// (same outputs as find_tile_boundaries_kernel, cuda/culling.cu:302-343)
+__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const unsigned long long *__restrict__ keys, int S,
+                                                             int num_tiles, int *__restrict__ ranges) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= S) return;
+  int cur = (int)(keys[s] >> 32);
+  cur = min(max(cur, 0), num_tiles - 1);
+  int prev = -1;
+  if (s > 0) {
+    prev = (int)(keys[s - 1] >> 32);
+    prev = min(max(prev, 0), num_tiles - 1);
+  }
+  for (int t = prev + 1; t <= cur; ++t) ranges[t] = s;
+  if (s == S - 1)
+    for (int t = cur + 1; t <= num_tiles; ++t) ranges[t] = S;
+}
+
+int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
+                     const unsigned char *mask, const int *rank, const int *offsets, unsigned long long *keys,
+                     int *vals, hipStream_t st) {
+  tile_emit_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets, keys,
+                                                        vals);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+static int key_bits(int num_tiles) {
+  int b = 0;
+  while ((1LL << b) < (long long)num_tiles) ++b;
+  return 32 + (b > 0 ? b : 1);
+}
+
+size_t sort_temp_bytes(size_t S, int num_tiles) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                  (int *)nullptr, (int *)nullptr, S, 0, key_bits(num_tiles), (hipStream_t)0);
+  return bytes;
+}
+
+// keys_a/vals_a hold the S emitted instances; sorted ids go to sorted_out, sorted keys to keys_b
+int sort_and_ranges(unsigned long long *keys_a, unsigned long long *keys_b, int *vals_a, int *sorted_out, size_t S,
+                    int num_tiles, void *temp, size_t temp_bytes, int *ranges, hipStream_t st) {
+  if (S == 0) {
+    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)(num_tiles + 1) * sizeof(int), st));
+    return GSPLAT_OK;
+  }
+  GS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_a, keys_b, vals_a, sorted_out, S, 0, key_bits(num_tiles), st));
+  tile_ranges_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(keys_b, (int)S, num_tiles, ranges);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+}  // namespace gs
+
+extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz, const float *radius, int n_tiles_x,
+                                               int n_tiles_y, int N, size_t *sorted_gaussian_count,
+                                               int *sorted_gaussians, int *splat_start_end_idx_by_tile_idx,
+                                               void *stream) {
+  using namespace gs;
+  GS_REQUIRE_DEV(uv); GS_REQUIRE_DEV(xyz);
+  GS_REQUIRE_DEV(radius);  // read unconditionally by the reference (cuda/culling.cu:210)
+  GS_REQUIRE(sorted_gaussian_count != nullptr, "sorted_gaussian_count is null");
+  GS_REQUIRE(N >= 0 && n_tiles_x > 0 && n_tiles_y > 0, "bad sizes");
+  GS_REQUIRE(((uintptr_t)radius & 15) == 0, "radius must be 16-byte aligned (float4)");
+  hipStream_t st = (hipStream_t)stream;
+  const int num_tiles = n_tiles_x * n_tiles_y;
+  int rc = host_words().ensure();
+  if (rc) return rc;
+  DeviceBuffer &misc = scratch(SCR_MISC);
+  rc = misc.reserve(64);
+  if (rc) return rc;
+  unsigned long long *d_total = misc.as<unsigned long long>();
+
+  if (sorted_gaussians == nullptr) {  // call 1: candidate-pair count only
+    GS_HIP(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
+    if (N > 0) {
+      coarse_count_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, n_tiles_x, n_tiles_y, N, d_total);
+      GS_LAUNCH_CHECK();
+    }
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(host_words().p);
+    GS_HIP(hipMemcpyAsync(h, d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    *sorted_gaussian_count = (size_t)h[0];
+    return GSPLAT_OK;
+  }
+
+  GS_REQUIRE_DEV(sorted_gaussians);
+  GS_REQUIRE_DEV(splat_start_end_idx_by_tile_idx);
+  if (N == 0) {
+    GS_HIP(hipMemsetAsync(splat_start_end_idx_by_tile_idx, 0, (size_t)(num_tiles + 1) * sizeof(int), st));
+    return GSPLAT_OK;
+  }
+  DeviceBuffer &counts = scratch(SCR_COUNTS), &offsets = scratch(SCR_OFFSETS), &tmp = scratch(SCR_TEMP);
+  if ((rc = counts.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
+  if ((rc = offsets.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
+  GS_HIP(hipMemsetAsync(counts.as<int>() + N, 0, sizeof(int), st));
+  tile_count_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr,
+                                                         counts.as<int>(), nullptr);
+  GS_LAUNCH_CHECK();
+  size_t scan_bytes = 0;
+  GS_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, counts.as<int>(), offsets.as<int>(), 0, (size_t)N + 1,
+                                 rocprim::plus<int>(), st));
+  if ((rc = tmp.reserve(scan_bytes))) return rc;
+  GS_HIP(rocprim::exclusive_scan(tmp.ptr, scan_bytes, counts.as<int>(), offsets.as<int>(), 0, (size_t)N + 1,
+                                 rocprim::plus<int>(), st));
+  GS_HIP(hipMemcpyAsync(host_words().p, offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  const size_t S = (size_t)host_words().p[0];
+  if (S > *sorted_gaussian_count) {
+    set_error("%s: %zu instances do not fit the caller's buffer of %zu", __func__, S, *sorted_gaussian_count);
+    return GSPLAT_ERR_CAPACITY;
+  }
+  DeviceBuffer &ka = scratch(SCR_KEYS_A), &kb = scratch(SCR_KEYS_B), &vb = scratch(SCR_VALS_B);
+  if ((rc = ka.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = kb.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = vb.reserve((S + 1) * sizeof(int)))) return rc;
+  const size_t sort_bytes = S ? sort_temp_bytes(S, num_tiles) : 0;
+  if ((rc = tmp.reserve(sort_bytes > scan_bytes ? sort_bytes : scan_bytes))) return rc;
+  if (S) {
+    tile_emit_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr,
+                                                          offsets.as<int>(), ka.as<unsigned long long>(),
+                                                          vb.as<int>());
+    GS_LAUNCH_CHECK();
+  }
+  rc = sort_and_ranges(ka.as<unsigned long long>(), kb.as<unsigned long long>(), vb.as<int>(), sorted_gaussians, S,
+                       num_tiles, tmp.ptr, sort_bytes, splat_start_end_idx_by_tile_idx, st);
+  if (rc) return rc;
+  // the reference returns only after its blocking read-backs; keep that contract
+  GS_HIP(hipStreamSynchronize(st));
+  return GSPLAT_OK;
+}

@@ -1,0 +1,82 @@
+// gs_common.h -- host-side plumbing shared by all translation units of libgsplat_hip.so:
+// status codes, argument validation with the reference's device-pointer rule
+// (cuda/checks.cuh:17-38, but returning a status instead of exiting), launch checks and
+// the library-owned scratch arena used by the stand-alone operators.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/gsplat_hip.h"
+
+namespace gs {
+
+void set_error(const char *fmt, ...);
+
+// NULL -> GSPLAT_ERR_NULL_POINTER, host/unknown memory -> GSPLAT_ERR_NOT_DEVICE
+int check_device_ptr(const void *p, const char *name, const char *fn);
+
+#define GS_REQUIRE_DEV(p)                                                  \
+  do {                                                                     \
+    int _st = ::gs::check_device_ptr((p), #p, __func__);                   \
+    if (_st != GSPLAT_OK) return _st;                                      \
+  } while (0)
+
+#define GS_REQUIRE(cond, msg)                                              \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      ::gs::set_error("%s: invalid argument: %s", __func__, msg);          \
+      return GSPLAT_ERR_INVALID_ARG;                                       \
+    }                                                                      \
+  } while (0)
+
+#define GS_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ::gs::set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(_e));           \
+      return GSPLAT_ERR_HIP;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+#define GS_LAUNCH_CHECK()                                                                     \
+  do {                                                                                        \
+    hipError_t _e = hipGetLastError();                                                        \
+    if (_e != hipSuccess) {                                                                   \
+      ::gs::set_error("%s: kernel launch failed: %s", __func__, hipGetErrorString(_e));       \
+      return GSPLAT_ERR_HIP;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+static inline unsigned int div_up(long long a, long long b) { return (unsigned int)((a + b - 1) / b); }
+
+// A growable device buffer (never shrinks).  Growing synchronises the device: it only
+// happens while sizes are still settling, never in the steady state of a training loop.
+struct DeviceBuffer {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t want);
+  void release();
+  template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+// Scratch slots of the stand-alone operators (the reference allocates thrust::device_vector
+// temporaries inside the same operators: cuda/culling.cu:400-463, cuda/spherical_harmonics.cu:76-79).
+enum ScratchSlot {
+  SCR_COUNTS = 0, SCR_OFFSETS, SCR_KEYS_A, SCR_KEYS_B, SCR_VALS_B, SCR_TEMP, SCR_SPLATS, SCR_MISC, SCR_GRADROWS,
+  SCR_NUM
+};
+DeviceBuffer &scratch(ScratchSlot slot);
+
+// pinned host words for count read-backs
+struct HostWords {
+  int *p = nullptr;
+  int ensure();
+};
+HostWords &host_words();
+
+}  // namespace gs

@@ -1,0 +1,82 @@
+// gs_common.hip -- status/error text, device-pointer validation, scratch arena.
+#include "gs_common.h"
+
+namespace gs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_device_ptr(const void *p, const char *name, const char *fn) {
+  if (p == nullptr) {
+    set_error("%s: pointer '%s' is null", fn, name);
+    return GSPLAT_ERR_NULL_POINTER;
+  }
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // clear the sticky error
+    set_error("%s: pointer '%s' is not known to the HIP runtime (%s)", fn, name, hipGetErrorString(e));
+    return GSPLAT_ERR_NOT_DEVICE;
+  }
+  if (attr.type != hipMemoryTypeDevice) {
+    set_error("%s: pointer '%s' is not a device pointer", fn, name);
+    return GSPLAT_ERR_NOT_DEVICE;
+  }
+  return GSPLAT_OK;
+}
+
+int DeviceBuffer::reserve(size_t want) {
+  if (want <= bytes) return GSPLAT_OK;
+  size_t grow = want + want / 4 + 256;
+  if (ptr) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { set_error("scratch: hipDeviceSynchronize: %s", hipGetErrorString(e)); return GSPLAT_ERR_HIP; }
+    (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  hipError_t e = hipMalloc(&ptr, grow);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    set_error("scratch: hipMalloc(%zu) failed: %s", grow, hipGetErrorString(e));
+    return GSPLAT_ERR_HIP;
+  }
+  bytes = grow;
+  return GSPLAT_OK;
+}
+
+void DeviceBuffer::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+static DeviceBuffer g_scratch[SCR_NUM];
+DeviceBuffer &scratch(ScratchSlot slot) { return g_scratch[slot]; }
+
+static HostWords g_words;
+int HostWords::ensure() {
+  if (p) return GSPLAT_OK;
+  hipError_t e = hipHostMalloc((void **)&p, 64 * sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) { p = nullptr; set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return GSPLAT_ERR_HIP; }
+  return GSPLAT_OK;
+}
+HostWords &host_words() { return g_words; }
+
+}  // namespace gs
+
+extern "C" {
+const char *gsplat_last_error(void) { return gs::g_err; }
+int gsplat_abi_version(void) { return 1; }
+int gsplat_release_scratch(void) {
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < gs::SCR_NUM; ++i) gs::g_scratch[i].release();
+  return GSPLAT_OK;
+}
+}

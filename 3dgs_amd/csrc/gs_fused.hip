@@ -1,0 +1,491 @@
+// gs_fused.hip -- the device-resident per-view pass: gsplat_rasterize_image (the work of
+// rasterize_image, cuda/raster.cu:12-136) and gsplat_backward_pass (the operator chain of
+// TrainerImpl::backward_pass, cuda/trainer.cu:941-1012) on a persistent workspace.
+//
+// Forward:   project+cull (N)  ->  scan(mask)  ->  preprocess (fused SH / Sigma / J / conic /
+//            radius / splat record / exact tile count, written in compacted order)
+//            ->  scan(counts)  ->  ONE host read-back {M, S}  ->  emit keys  ->  radix sort
+//            ->  tile ranges  ->  compositing.
+// Backward:  zero gradient rows -> compositing backward (64-byte row atomics) -> one fused
+//            per-gaussian kernel for the whole SH / conic / Jacobian / Sigma / projection chain.
+// The reference runs ~20 thrust compactions, ~15 kernels and 5 blocking read-backs for the
+// same work; results are laid out exactly like its ForwardPassData / GaussianGradients.
+#include <cstring>
+#include <cmath>
+#include <new>
+#include <rocprim/rocprim.hpp>
+
+#include "gs_common.h"
+#include "gs_math.h"
+#include "gs_render.h"
+
+namespace gs {
+// from gs_binning.hip / gs_render.hip
+int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
+                     const unsigned char *mask, const int *rank, const int *offsets, unsigned long long *keys,
+                     int *vals, hipStream_t st);
+size_t sort_temp_bytes(size_t S, int num_tiles);
+int sort_and_ranges(unsigned long long *keys_a, unsigned long long *keys_b, int *vals_a, int *sorted_out, size_t S,
+                    int num_tiles, void *temp, size_t temp_bytes, int *ranges, hipStream_t st);
+struct RawSplats;
+int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
+                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st);
+int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
+                      const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
+                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st);
+}  // namespace gs
+
+struct gsplat_context {
+  int max_gaussians = 0, max_width = 0, max_height = 0;
+  // per-gaussian, global order
+  gs::DeviceBuffer mask, flags, rank, xyz_c_all, uv_all;
+  // per-gaussian, compacted order
+  gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows;
+  // instances
+  gs::DeviceBuffer keys_a, keys_b, vals_a, sorted, temp;
+  // per tile / pixel
+  gs::DeviceBuffer ranges, image, T_px, n_px;
+  int *h_words = nullptr;  // pinned
+  // state of the last forward
+  int N = 0, M = 0, l_max = 0, width = 0, height = 0;
+  size_t S = 0;
+  bool have_forward = false;
+  size_t bytes() const {
+    const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
+                                     &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &vals_a,
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px};
+    size_t b = 0;
+    for (auto *p : all) b += p->bytes;
+    return b;
+  }
+  void release() {
+    gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
+                               &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &vals_a,
+                               &sorted, &temp, &ranges, &image, &T_px, &n_px};
+    for (auto *p : all) p->release();
+    if (h_words) (void)hipHostFree(h_words);
+    h_words = nullptr;
+  }
+};
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- A: world -> camera -> pixel -> keep-mask, for all N
+__global__ __launch_bounds__(kBlock) void project_cull_kernel(const float *__restrict__ xyz,
+                                                              const float *__restrict__ view,
+                                                              const float *__restrict__ proj, int N, int width,
+                                                              int height, float near_thresh, int padding,
+                                                              float *__restrict__ xyz_c, float *__restrict__ uv,
+                                                              unsigned char *__restrict__ mask,
+                                                              int *__restrict__ flags) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) {
+    if (i == N) flags[N] = 0;
+    return;
+  }
+  const gs::Mat34 v = gs::load_view(view);
+  const gs::Mat44 p = gs::load_proj(proj);
+  float x, y, z, u, w;
+  gs::camera_space(v, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], x, y, z);
+  gs::to_screen(p, x, y, z, width, height, u, w);
+  const bool k = gs::keep(u, w, z, near_thresh, padding, width, height);
+  xyz_c[3 * i] = x; xyz_c[3 * i + 1] = y; xyz_c[3 * i + 2] = z;
+  uv[2 * i] = u; uv[2 * i + 1] = w;
+  mask[i] = k ? 1 : 0;
+  flags[i] = k ? 1 : 0;
+}
+
+struct PreOut {
+  int *c2g;
+  float *xyz_c, *uv, *sigma, *conic, *J, *rgb, *radius;
+  float4 *recs;
+  int *counts;
+};
+
+// ---- B: everything per kept gaussian, written at its compacted slot
+template <int L>
+__global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, const float *__restrict__ view,
+                                                            const unsigned char *__restrict__ mask,
+                                                            const int *__restrict__ rank,
+                                                            const float *__restrict__ xyz_c_all,
+                                                            const float *__restrict__ uv_all, float fx, float fy,
+                                                            float tan_fovx, float tan_fovy, float mh_dist, float cx,
+                                                            float cy, float cz, int ntx, int nty, PreOut o) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int N = g.num_gaussians;
+  if (i >= N || !mask[i]) return;
+  const int j = rank[i];
+  constexpr int n = (L + 1) * (L + 1);
+  const gs::Mat34 vw = gs::load_view(view);
+  // colour
+  float dx, dy, dz, len, rgb[3];
+  gs::view_dir(g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, dx, dy, dz, len);
+  gs::sh_to_rgb<L>(g.sh + (size_t)i * (n - 1) * 3, g.rgb + 3 * i, dx, dy, dz, rgb);
+  // covariance -> conic
+  const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i];
+  const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
+  float sg[6], J[6], con[3], rad[4];
+  gs::sigma_from(rs, sg);
+  const float x = xyz_c_all[3 * i], y = xyz_c_all[3 * i + 1], z = xyz_c_all[3 * i + 2];
+  const float u = uv_all[2 * i], v = uv_all[2 * i + 1];
+  gs::jacobian(x, y, z, fx, fy, tan_fovx, tan_fovy, J);
+  gs::conic_radius(J, sg, vw, mh_dist, con, rad);
+  // exact tile count
+  int hits = 0;
+  const gs::TileRect r = gs::coarse_rect(u, v, rad[0], ntx, nty);
+  if (r.x1 > r.x0 && r.y1 > r.y0) {
+    const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
+    for (int tx = r.x0; tx < r.x1; ++tx)
+      for (int ty = r.y0; ty < r.y1; ++ty) hits += gs::obb_hits_tile(ob, tx, ty) ? 1 : 0;
+  }
+  // stores (compacted order)
+  o.c2g[j] = i;
+  o.counts[j] = hits;
+  o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
+  o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { o.sigma[6 * j + k] = sg[k]; o.J[6 * j + k] = J[k]; }
+  o.conic[3 * j] = con[0]; o.conic[3 * j + 1] = con[1]; o.conic[3 * j + 2] = con[2];
+  o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
+  reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
+  const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
+  o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
+}
+
+// coarse candidate count, reported for parity with call 1 of get_sorted_gaussian_list
+__global__ __launch_bounds__(kBlock) void coarse_pairs_kernel(const float *__restrict__ uv,
+                                                              const float *__restrict__ radius, int ntx, int nty,
+                                                              const int *__restrict__ pM,
+                                                              unsigned long long *__restrict__ total) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long mine = 0;
+  if (j < *pM) {
+    const gs::TileRect r = gs::coarse_rect(uv[2 * j], uv[2 * j + 1], radius[4 * j], ntx, nty);
+    mine = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+}
+
+struct BwdOut {
+  float *xyz, *rgb, *sh, *opacity, *scale, *quaternion;
+  float *conic, *uv, *J, *sigma, *xyz_c, *pre_rgb;
+};
+
+// ---- backward of everything per gaussian, one thread per compacted slot
+template <int L>
+__global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
+                                                                const float *__restrict__ proj, int M,
+                                                                const int *__restrict__ c2g,
+                                                                const float *__restrict__ xyz_c_sel,
+                                                                const float *__restrict__ sigma,
+                                                                const float *__restrict__ Jm,
+                                                                const float *__restrict__ conic,
+                                                                const float4 *__restrict__ rows, float fx, float fy,
+                                                                float tan_fovx, float tan_fovy, float cx, float cy,
+                                                                float cz, int width, int height, BwdOut o) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= M) return;
+  constexpr int n = (L + 1) * (L + 1);
+  const int i = c2g[j];
+  const gs::Mat34 vw = gs::load_view(view);
+  const gs::Mat44 pr = gs::load_proj(proj);
+  const float4 a = rows[4 * j], b = rows[4 * j + 1], c = rows[4 * j + 2];
+  const float g_rgb[3] = {a.x, a.y, a.z};
+  const float g_op = a.w;
+  const float g_con[3] = {b.x, b.y, b.z};
+  const float g_u = b.w, g_v = c.x;
+  // SH chain: sh_grad (=), band0_grad (=), xyz_grad starts with the view-direction term
+  float gx, gy, gz, b0g[3];
+  float *shg = o.sh + (size_t)j * (n - 1) * 3;
+  gs::sh_bwd<L>(g.sh + (size_t)i * (n - 1) * 3, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy,
+                cz, g_rgb, shg, b0g, gx, gy, gz);
+  gx = 0.0f + gx; gy = 0.0f + gy; gz = 0.0f + gz;
+  // conic -> (J, Sigma)
+  float Jv[6], sg[6], con[3], dJ[6], dS[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Jv[k] = Jm[6 * j + k]; sg[k] = sigma[6 * j + k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) con[k] = conic[3 * j + k];
+  gs::conic_bwd(Jv, sg, vw, con, g_con, dJ, dS);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { dJ[k] = 0.0f + dJ[k]; dS[k] = 0.0f + dS[k]; }
+  // J -> xyz_c
+  const float x = xyz_c_sel[3 * j], y = xyz_c_sel[3 * j + 1], z = xyz_c_sel[3 * j + 2];
+  float cxg, cyg, czg;
+  gs::jacobian_bwd(x, y, z, fx, fy, tan_fovx, tan_fovy, dJ, cxg, cyg, czg);
+  cxg = 0.0f + cxg; cyg = 0.0f + cyg; czg = 0.0f + czg;
+  // Sigma -> quaternion, scale
+  const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i];
+  const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
+  float dQ[4], dSc[3];
+  gs::sigma_bwd(rs, dS, dQ, dSc);
+  // uv -> xyz_c
+  float px_, py_, pz_;
+  gs::to_screen_bwd(pr, x, y, z, g_u, g_v, width, height, px_, py_, pz_);
+  cxg += px_; cyg += py_; czg += pz_;
+  // xyz_c -> xyz
+  float wx, wy, wz;
+  gs::camera_space_bwd(vw, cxg, cyg, czg, wx, wy, wz);
+  gx += wx; gy += wy; gz += wz;
+  // stores
+  o.xyz[3 * j] = gx; o.xyz[3 * j + 1] = gy; o.xyz[3 * j + 2] = gz;
+  o.rgb[3 * j] = b0g[0]; o.rgb[3 * j + 1] = b0g[1]; o.rgb[3 * j + 2] = b0g[2];
+  o.opacity[j] = g_op;
+  o.scale[3 * j] = dSc[0]; o.scale[3 * j + 1] = dSc[1]; o.scale[3 * j + 2] = dSc[2];
+  reinterpret_cast<float4 *>(o.quaternion)[j] = make_float4(dQ[0], dQ[1], dQ[2], dQ[3]);
+  if (o.conic) { o.conic[3 * j] = g_con[0]; o.conic[3 * j + 1] = g_con[1]; o.conic[3 * j + 2] = g_con[2]; }
+  if (o.uv) { o.uv[2 * j] = g_u; o.uv[2 * j + 1] = g_v; }
+  if (o.pre_rgb) { o.pre_rgb[3 * j] = g_rgb[0]; o.pre_rgb[3 * j + 1] = g_rgb[1]; o.pre_rgb[3 * j + 2] = g_rgb[2]; }
+  if (o.J) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.J[6 * j + k] = dJ[k];
+  }
+  if (o.sigma) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.sigma[6 * j + k] = dS[k];
+  }
+  if (o.xyz_c) { o.xyz_c[3 * j] = cxg; o.xyz_c[3 * j + 1] = cyg; o.xyz_c[3 * j + 2] = czg; }
+}
+
+// ---- global-order gradient rows for the view-sharded all-reduce
+__global__ __launch_bounds__(kBlock) void pack_global_kernel(const unsigned char *__restrict__ mask,
+                                                             const int *__restrict__ rank, int N, int n_coeffs,
+                                                             gsplat_gradients gr, float *__restrict__ packed) {
+  const int width = 12 + 3 * n_coeffs;
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (long long)N * width) return;
+  const int i = (int)(e / width), k = (int)(e % width);
+  float val = 0.0f;
+  if (mask[i]) {
+    const size_t j = (size_t)rank[i];
+    const int n_rest3 = 3 * (n_coeffs - 1);
+    if (k < 3) val = gr.grad_xyz[3 * j + k];
+    else if (k < 6) val = gr.grad_rgb[3 * j + (k - 3)];
+    else if (k < 6 + n_rest3) val = gr.grad_sh[j * n_rest3 + (k - 6)];
+    else if (k == 6 + n_rest3) val = gr.grad_opacity[j];
+    else if (k < 10 + n_rest3) val = gr.grad_scale[3 * j + (k - 7 - n_rest3)];
+    else if (k < 14 + n_rest3) val = gr.grad_quaternion[4 * j + (k - 10 - n_rest3)];
+    else val = 1.0f;
+  }
+  packed[e] = val;
+}
+
+int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
+  int rc;
+  if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = c->keys_b.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = c->vals_a.reserve((S + 1) * sizeof(int)))) return rc;
+  if ((rc = c->sorted.reserve((S + 1) * sizeof(int)))) return rc;
+  const size_t sb = gs::sort_temp_bytes(S ? S : 1, num_tiles);
+  if ((rc = c->temp.reserve(sb))) return rc;
+  return GSPLAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsplat_packed_gradient_width(int l_max) { return 12 + 3 * (l_max + 1) * (l_max + 1); }
+
+int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width, int max_height) {
+  GS_REQUIRE(out != nullptr, "out is null");
+  GS_REQUIRE(max_gaussians > 0 && max_width > 0 && max_height > 0, "capacities must be positive");
+  gsplat_context *c = new (std::nothrow) gsplat_context();
+  GS_REQUIRE(c != nullptr, "out of host memory");
+  c->max_gaussians = max_gaussians; c->max_width = max_width; c->max_height = max_height;
+  const size_t N = (size_t)max_gaussians, P = (size_t)max_width * max_height;
+  const size_t T = (size_t)((max_width + 15) / 16) * ((max_height + 15) / 16);
+  int rc = GSPLAT_OK;
+  auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
+  R(c->mask, N + 16); R(c->flags, (N + 1) * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
+  R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
+  R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
+  R(c->grad_rows, N * 64);
+  R(c->ranges, (T + 1) * 4); R(c->image, P * 12); R(c->T_px, P * 4); R(c->n_px, P * 4);
+  if (!rc) {
+    size_t sb1 = 0, sb2 = 0;
+    (void)rocprim::exclusive_scan(nullptr, sb1, (int *)nullptr, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
+    sb2 = sb1;
+    rc = c->temp.reserve(sb1 > sb2 ? sb1 : sb2);
+  }
+  if (!rc) rc = reserve_instances(c, 4 * N, (int)T);
+  if (!rc && hipHostMalloc((void **)&c->h_words, 64, hipHostMallocDefault) != hipSuccess) {
+    gs::set_error("gsplat_context_create: hipHostMalloc failed");
+    rc = GSPLAT_ERR_HIP;
+  }
+  if (rc) { c->release(); delete c; return rc; }
+  *out = c;
+  return GSPLAT_OK;
+}
+
+int gsplat_context_destroy(gsplat_context *ctx) {
+  if (!ctx) return GSPLAT_OK;
+  (void)hipDeviceSynchronize();
+  ctx->release();
+  delete ctx;
+  return GSPLAT_OK;
+}
+
+size_t gsplat_context_bytes(const gsplat_context *ctx) { return ctx ? ctx->bytes() : 0; }
+
+int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam,
+                           const gsplat_raster_config *cfg, float bg_color, int l_max, gsplat_forward_view *out,
+                           void *stream) {
+  GS_REQUIRE(c && g && cam && cfg, "null argument struct");
+  GS_REQUIRE(l_max >= 0 && l_max <= 3, "l_max must be 0..3");  // cuda/raster.cu:58-60
+  const int N = g->num_gaussians, W = cam->width, H = cam->height;
+  GS_REQUIRE(N > 0, "num_gaussians must be positive");
+  if (N > c->max_gaussians || W > c->max_width || H > c->max_height || W <= 0 || H <= 0) {
+    gs::set_error("gsplat_rasterize_image: %d gaussians / %dx%d exceed the context capacity %d / %dx%d", N, W, H,
+                  c->max_gaussians, c->max_width, c->max_height);
+    return GSPLAT_ERR_CAPACITY;
+  }
+  GS_REQUIRE_DEV(g->xyz); GS_REQUIRE_DEV(g->rgb); GS_REQUIRE_DEV(g->opacity); GS_REQUIRE_DEV(g->scale);
+  GS_REQUIRE_DEV(g->quaternion); GS_REQUIRE_DEV(cam->view); GS_REQUIRE_DEV(cam->proj);
+  if (l_max > 0) GS_REQUIRE_DEV(g->sh);
+  GS_REQUIRE(((uintptr_t)g->quaternion & 15) == 0, "quaternion must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  c->have_forward = false;
+  const int ntx = (W + 15) / 16, nty = (H + 15) / 16, num_tiles = ntx * nty;
+  const float fx = cam->focal_x, fy = cam->focal_y;
+  const float tan_fovx = (float)W / (2.0f * fx), tan_fovy = (float)H / (2.0f * fy);  // cuda/raster.cu:92-93
+
+  const dim3 gridN(gs::div_up((long long)N + 1, kBlock)), block(kBlock);
+  project_cull_kernel<<<gridN, block, 0, st>>>(g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh,
+                                               cfg->cull_mask_padding, c->xyz_c_all.as<float>(), c->uv_all.as<float>(),
+                                               c->mask.as<unsigned char>(), c->flags.as<int>());
+  GS_LAUNCH_CHECK();
+  size_t scan_bytes = c->temp.bytes;
+  GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->flags.as<int>(), c->rank.as<int>(), 0, (size_t)N + 1,
+                                 rocprim::plus<int>(), st));
+  PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
+               c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>()};
+  GS_HIP(hipMemsetAsync(c->counts.ptr, 0, (size_t)(N + 1) * sizeof(int), st));
+#define GS_PRE(LL)                                                                                                     \
+  preprocess_kernel<LL><<<gridN, block, 0, st>>>(*g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(),        \
+                                                 c->xyz_c_all.as<float>(), c->uv_all.as<float>(), fx, fy, tan_fovx,    \
+                                                 tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1],               \
+                                                 cam->campos[2], ntx, nty, po)
+  switch (l_max) {
+    case 0: GS_PRE(0); break;
+    case 1: GS_PRE(1); break;
+    case 2: GS_PRE(2); break;
+    default: GS_PRE(3); break;
+  }
+#undef GS_PRE
+  GS_LAUNCH_CHECK();
+  scan_bytes = c->temp.bytes;
+  GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->counts.as<int>(), c->offsets.as<int>(), 0, (size_t)N + 1,
+                                 rocprim::plus<int>(), st));
+  // coarse candidate count (reporting only)
+  unsigned long long *d_pairs = reinterpret_cast<unsigned long long *>(c->flags.ptr);  // flags are dead after the scan
+  GS_HIP(hipMemsetAsync(d_pairs, 0, sizeof(unsigned long long), st));
+  coarse_pairs_kernel<<<gs::div_up(N, kBlock), block, 0, st>>>(c->uv.as<float>(), c->radius.as<float>(), ntx, nty,
+                                                              c->rank.as<int>() + N, d_pairs);
+  GS_LAUNCH_CHECK();
+  // the one host read-back of the forward: M, S (and the candidate count)
+  GS_HIP(hipMemcpyAsync(&c->h_words[0], c->rank.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&c->h_words[1], c->offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&c->h_words[2], d_pairs, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  const int M = c->h_words[0];
+  const size_t S = (size_t)c->h_words[1];
+  unsigned long long pairs;
+  memcpy(&pairs, &c->h_words[2], sizeof(pairs));
+  if (M == 0) {
+    gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
+    return GSPLAT_ERR_NO_VISIBLE;
+  }
+  int rc = reserve_instances(c, S, num_tiles);
+  if (rc) return rc;
+  if (S) {
+    rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
+                              c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
+                              c->keys_a.as<unsigned long long>(), c->vals_a.as<int>(), st);
+    if (rc) return rc;
+  }
+  rc = gs::sort_and_ranges(c->keys_a.as<unsigned long long>(), c->keys_b.as<unsigned long long>(), c->vals_a.as<int>(),
+                           c->sorted.as<int>(), S, num_tiles, c->temp.ptr, c->temp.bytes, c->ranges.as<int>(), st);
+  if (rc) return rc;
+  rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
+                             c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st);
+  if (rc) return rc;
+  c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
+  c->have_forward = true;
+  if (out) {
+    out->num_culled = (size_t)M; out->num_pairs = (size_t)pairs; out->num_splats = S;
+    out->mask = c->mask.as<unsigned char>(); out->uv = c->uv_all.as<float>(); out->xyz_c = c->xyz_c_all.as<float>();
+    out->compact_to_global = c->c2g.as<int>();
+    out->sigma = c->sigma.as<float>(); out->conic = c->conic.as<float>(); out->J = c->J.as<float>();
+    out->precomputed_rgb = c->rgb.as<float>(); out->radius = c->radius.as<float>();
+    out->uv_selected = c->uv.as<float>(); out->xyz_c_selected = c->xyz_c.as<float>();
+    out->sorted_gaussians = c->sorted.as<int>();
+    out->splat_start_end_idx_by_tile_idx = c->ranges.as<int>();
+    out->image = c->image.as<float>(); out->weight_per_pixel = c->T_px.as<float>();
+    out->splats_per_pixel = c->n_px.as<int>();
+  }
+  return GSPLAT_OK;
+}
+
+int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam,
+                         const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
+                         void *stream) {
+  GS_REQUIRE(c && g && cam && out, "null argument struct");
+  GS_REQUIRE(c->have_forward, "no forward pass recorded in this context");
+  GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N && cam->width == c->width && cam->height == c->height,
+             "backward arguments do not match the recorded forward pass");
+  GS_REQUIRE_DEV(grad_image);
+  GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
+  GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
+  if (l_max > 0) GS_REQUIRE_DEV(out->grad_sh);
+  GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = c->M, W = c->width, H = c->height;
+  GS_HIP(hipMemsetAsync(c->grad_rows.ptr, 0, (size_t)M * 64, st));
+  int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
+                                 c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
+                                 c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st);
+  if (rc) return rc;
+  // cuda/trainer.cu:992-995
+  const float fx = cam->focal_x, fy = cam->focal_y;
+  const float fov_x = (float)(2.0 * atan((double)W / (2.0 * (double)fx)));
+  const float fov_y = (float)(2.0 * atan((double)H / (2.0 * (double)fy)));
+  const float tan_fovx = tanf(fov_x * 0.5f), tan_fovy = tanf(fov_y * 0.5f);
+  BwdOut bo = {out->grad_xyz, out->grad_rgb, out->grad_sh, out->grad_opacity, out->grad_scale, out->grad_quaternion,
+               out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb};
+  const dim3 grid(gs::div_up(M, kBlock)), block(kBlock);
+#define GS_BWD(LL)                                                                                                     \
+  preprocess_bwd_kernel<LL><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),                     \
+                                                    c->xyz_c.as<float>(), c->sigma.as<float>(), c->J.as<float>(),      \
+                                                    c->conic.as<float>(), c->grad_rows.as<float4>(), fx, fy,           \
+                                                    tan_fovx, tan_fovy, cam->campos[0], cam->campos[1],                \
+                                                    cam->campos[2], W, H, bo)
+  switch (l_max) {
+    case 0: GS_BWD(0); break;
+    case 1: GS_BWD(1); break;
+    case 2: GS_BWD(2); break;
+    default: GS_BWD(3); break;
+  }
+#undef GS_BWD
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_pack_gradients_global(gsplat_context *c, const gsplat_gradients *grads, int l_max, int num_gaussians,
+                                 float *packed, void *stream) {
+  GS_REQUIRE(c && grads, "null argument struct");
+  GS_REQUIRE(c->have_forward && num_gaussians == c->N && l_max == c->l_max, "does not match the recorded forward");
+  GS_REQUIRE_DEV(packed);
+  const int n_coeffs = (l_max + 1) * (l_max + 1);
+  const long long total = (long long)num_gaussians * (12 + 3 * n_coeffs);
+  pack_global_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+      c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, n_coeffs, *grads, packed);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+}  // extern "C"

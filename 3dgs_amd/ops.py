@@ -1,0 +1,139 @@
+"""Host-side mirror of the reference operator surface on torch device tensors.
+
+Same names, argument order and output semantics ("=" vs "+=") as
+/root/reference/include/gsplat_cuda/cuda_forward.cuh:26-131 and cuda_backward.cuh:21-123.
+Each function only forwards raw device pointers to the C ABI (include/gsplat_hip.h) on
+torch's current HIP stream; torch is used for device memory, nothing else.  Errors come back
+as GsplatError (the C++ shim headers in include/gsplat_cuda/ reproduce the reference's
+print-and-exit instead).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch tensor or None")
+    if t.numel() == 0:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32")
+    return t
+
+
+def compute_camera_space_points(xyz_w, view, N, xyz_c):
+    check(_lib.load().gsplat_compute_camera_space_points(_p(_f32(xyz_w, "xyz_w")), _p(view), N, _p(xyz_c), _stream()))
+
+
+def project_to_screen(xyz, proj, N, width, height, uv):
+    check(_lib.load().gsplat_project_to_screen(_p(_f32(xyz, "xyz")), _p(proj), N, width, height, _p(uv), _stream()))
+
+
+def cull_gaussians(uv, xyz, N, near_thresh, padding, width, height, mask):
+    """mask: torch.bool or uint8 tensor [N]; true = keep."""
+    check(_lib.load().gsplat_cull_gaussians(_p(uv), _p(xyz), N, near_thresh, padding, width, height, _p(mask), _stream()))
+
+
+def compute_sigma(quaternion, scale, N, sigma):
+    check(_lib.load().gsplat_compute_sigma(_p(quaternion), _p(scale), N, _p(sigma), _stream()))
+
+
+def compute_conic(xyz, view, sigma, focal_x, focal_y, tan_fovx, tan_fovy, mh_dist, N, J, conic, radius):
+    check(_lib.load().gsplat_compute_conic(_p(xyz), _p(view), _p(sigma), focal_x, focal_y, tan_fovx, tan_fovy, mh_dist,
+                                           N, _p(J), _p(conic), _p(radius), _stream()))
+
+
+def get_sorted_gaussian_list(uv, xyz, radius, n_tiles_x, n_tiles_y, N, count, sorted_gaussians, ranges):
+    """Two-call protocol.  ``count`` is the in/out size_t of the reference, passed as an int; returns the count
+    (call 1: number of candidate pairs; call 2: unchanged)."""
+    c = ctypes.c_size_t(int(count))
+    check(_lib.load().gsplat_get_sorted_gaussian_list(_p(uv), _p(xyz), _p(radius), n_tiles_x, n_tiles_y, N,
+                                                      ctypes.byref(c), _p(sorted_gaussians), _p(ranges), _stream()))
+    return int(c.value)
+
+
+def precompute_spherical_harmonics(xyz, sh_coefficients, sh_coeffs_band_0, campos, l_max, N, rgb):
+    check(_lib.load().gsplat_precompute_spherical_harmonics(_p(xyz), _p(sh_coefficients), _p(sh_coeffs_band_0),
+                                                            float(campos[0]), float(campos[1]), float(campos[2]),
+                                                            l_max, N, _p(rgb), _stream()))
+
+
+def render_image(uv, opacity, conic, rgb, background_opacity, sorted_splats, splat_range_by_tile, image_width,
+                 image_height, splats_per_pixel, weight_per_pixel, image):
+    check(_lib.load().gsplat_render_image(_p(uv), _p(opacity), _p(conic), _p(rgb), background_opacity,
+                                          _p(sorted_splats), _p(splat_range_by_tile), image_width, image_height,
+                                          _p(splats_per_pixel), _p(weight_per_pixel), _p(image), _stream()))
+
+
+def project_to_screen_backward(xyz_c, proj, uv_grad_out, N, width, height, xyz_c_grad_in):
+    check(_lib.load().gsplat_project_to_screen_backward(_p(xyz_c), _p(proj), _p(uv_grad_out), N, width, height,
+                                                        _p(xyz_c_grad_in), _stream()))
+
+
+def compute_camera_space_points_backward(xyz_w, view, xyz_c_grad_out, N, xyz_w_grad_in):
+    check(_lib.load().gsplat_compute_camera_space_points_backward(_p(xyz_w), _p(view), _p(xyz_c_grad_out), N,
+                                                                  _p(xyz_w_grad_in), _stream()))
+
+
+def compute_projection_jacobian_backward(xyz_c, focal_x, focal_y, tan_fovx, tan_fovy, J_grad_out, N, xyz_c_grad_in):
+    check(_lib.load().gsplat_compute_projection_jacobian_backward(_p(xyz_c), focal_x, focal_y, tan_fovx, tan_fovy,
+                                                                  _p(J_grad_out), N, _p(xyz_c_grad_in), _stream()))
+
+
+def compute_conic_backward(J, sigma, view, conic, conic_grad_out, N, J_grad_in, sigma_grad_in):
+    check(_lib.load().gsplat_compute_conic_backward(_p(J), _p(sigma), _p(view), _p(conic), _p(conic_grad_out), N,
+                                                    _p(J_grad_in), _p(sigma_grad_in), _stream()))
+
+
+def compute_sigma_backward(quaternion, scale, sigma_grad_out, N, quaternion_grad_in, scale_grad_in):
+    check(_lib.load().gsplat_compute_sigma_backward(_p(quaternion), _p(scale), _p(sigma_grad_out), N,
+                                                    _p(quaternion_grad_in), _p(scale_grad_in), _stream()))
+
+
+def precompute_spherical_harmonics_backward(xyz_c, rgb_vals, sh_coeffs, campos, rgb_grad_out, l_max, N, sh_grad_in,
+                                            sh_grad_band_0_in, xyz_c_grad_in):
+    check(_lib.load().gsplat_precompute_spherical_harmonics_backward(
+        _p(xyz_c), _p(rgb_vals), _p(sh_coeffs), float(campos[0]), float(campos[1]), float(campos[2]),
+        _p(rgb_grad_out), l_max, N, _p(sh_grad_in), _p(sh_grad_band_0_in), _p(xyz_c_grad_in), _stream()))
+
+
+def render_image_backward(uvs, opacity, conic, rgb, background_opacity, sorted_splats, splat_range_by_tile,
+                          num_splats_per_pixel, final_weight_per_pixel, grad_image, image_width, image_height,
+                          grad_rgb, grad_opacity, grad_uv, grad_conic):
+    check(_lib.load().gsplat_render_image_backward(
+        _p(uvs), _p(opacity), _p(conic), _p(rgb), background_opacity, _p(sorted_splats), _p(splat_range_by_tile),
+        _p(num_splats_per_pixel), _p(final_weight_per_pixel), _p(grad_image), image_width, image_height, _p(grad_rgb),
+        _p(grad_opacity), _p(grad_uv), _p(grad_conic), _stream()))
+
+
+def compact_masked_array(stride, d_source, d_mask, num_culled=None):
+    """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride]."""
+    N = int(d_mask.numel())
+    out = torch.empty(max(N * stride, 1), dtype=torch.float32, device=d_mask.device if N else "cuda")
+    n = ctypes.c_int(0)
+    check(_lib.load().gsplat_compact_masked_array(_p(d_source), _p(d_mask), N, stride, _p(out), ctypes.byref(n),
+                                                  _stream()))
+    if num_culled is not None and int(num_culled) != n.value:
+        raise ValueError(f"num_culled={num_culled} but the mask selects {n.value}")
+    return out[: n.value * stride]
+
+
+def scatter_masked_array(stride, d_compacted, d_mask, d_destination):
+    check(_lib.load().gsplat_scatter_masked_array(_p(d_compacted), _p(d_mask), int(d_mask.numel()), stride,
+                                                  _p(d_destination), _stream()))

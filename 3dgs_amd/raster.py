@@ -1,0 +1,159 @@
+"""Per-view forward/backward on the device-resident context (binding of gsplat_rasterize_image /
+gsplat_backward_pass, include/gsplat_hip.h).
+
+Mirrors the two call sites of the reference trainer: ``rasterize_image(...)``
+(/root/reference/cuda/raster.cu:12-136, called at cuda/trainer.cu:1350) and the operator
+chain of ``TrainerImpl::backward_pass`` (cuda/trainer.cu:941-1012).  All tensors are torch
+device tensors; results are zero-copy views into the context's workspace (valid until the
+next forward on the same context).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class _DevView:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+def _view(ptr, shape, typestr, owner):
+    if ptr is None or int(np.prod(shape)) == 0:
+        dt = {"<f4": torch.float32, "<i4": torch.int32, "|u1": torch.uint8}[typestr]
+        return torch.empty(tuple(shape), dtype=dt, device="cuda")
+    return torch.as_tensor(_DevView(ptr, shape, typestr, owner), device="cuda")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+
+
+def device_params(params, device="cuda"):
+    """numpy parameter dict (scene.make_gaussians) -> dict of contiguous float32 device tensors."""
+    return {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(device).contiguous()
+            for k, v in params.items()}
+
+
+def device_camera(cam, device="cuda"):
+    out = dict(cam)
+    out["view"] = torch.as_tensor(np.asarray(cam["view"], np.float32)).to(device)
+    out["proj"] = torch.as_tensor(np.asarray(cam["proj"], np.float32)).to(device)
+    return out
+
+
+class RasterContext:
+    """Owns a gsplat_context (persistent HBM workspace sized for max_gaussians / max image)."""
+
+    def __init__(self, max_gaussians, max_width, max_height):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self._lib.gsplat_context_create(ctypes.byref(h), int(max_gaussians), int(max_width), int(max_height)))
+        self._h = h
+        self._last = None
+
+    def close(self):
+        if self._h:
+            self._lib.gsplat_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self._lib.gsplat_context_bytes(self._h))
+
+    @staticmethod
+    def _structs(params, cam, l_max):
+        g = _lib.Gaussians()
+        g.num_gaussians = int(params["xyz"].shape[0])
+        g.xyz, g.rgb, g.opacity = _ptr(params["xyz"]), _ptr(params["rgb"]), _ptr(params["opacity"])
+        g.scale, g.quaternion = _ptr(params["scale"]), _ptr(params["quaternion"])
+        g.sh = _ptr(params["sh"]) if l_max > 0 else None
+        c = _lib.Camera()
+        c.width, c.height = int(cam["width"]), int(cam["height"])
+        c.focal_x, c.focal_y = float(cam["fx"]), float(cam["fy"])
+        for k in range(3):
+            c.campos[k] = float(cam["campos"][k])
+        c.view, c.proj = _ptr(cam["view"]), _ptr(cam["proj"])
+        return g, c
+
+    def rasterize_image(self, params, cam, config, bg_color, l_max):
+        """params: dict of device tensors (xyz rgb sh opacity scale quaternion); sh must be stored with the
+        current band's stride, [N,(l_max+1)^2-1,3] (cuda_data.cuh layout).  Returns a dict of views."""
+        g, c = self._structs(params, cam, l_max)
+        if l_max > 0:
+            want = ((l_max + 1) ** 2 - 1) * 3
+            if params["sh"].numel() != g.num_gaussians * want:
+                raise ValueError("sh must be packed at the current band's stride")
+        cfg = _lib.RasterConfig(float(config["near_thresh"]), float(config["mh_dist"]), int(config["cull_mask_padding"]))
+        fv = _lib.ForwardView()
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_rasterize_image(self._h, ctypes.byref(g), ctypes.byref(c), ctypes.byref(cfg),
+                                               float(bg_color), int(l_max), ctypes.byref(fv), st))
+        N, M, S = g.num_gaussians, int(fv.num_culled), int(fv.num_splats)
+        W, H = c.width, c.height
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        o = self
+        out = dict(
+            num_culled=M, num_pairs=int(fv.num_pairs), num_splats=S,
+            mask=_view(fv.mask, (N,), "|u1", o), uv_all=_view(fv.uv, (N, 2), "<f4", o),
+            xyz_c_all=_view(fv.xyz_c, (N, 3), "<f4", o), compact_to_global=_view(fv.compact_to_global, (M,), "<i4", o),
+            sigma=_view(fv.sigma, (M, 6), "<f4", o), conic=_view(fv.conic, (M, 3), "<f4", o),
+            J=_view(fv.J, (M, 6), "<f4", o), rgb=_view(fv.precomputed_rgb, (M, 3), "<f4", o),
+            radius=_view(fv.radius, (M, 4), "<f4", o), uv=_view(fv.uv_selected, (M, 2), "<f4", o),
+            xyz_c=_view(fv.xyz_c_selected, (M, 3), "<f4", o), sorted=_view(fv.sorted_gaussians, (S,), "<i4", o),
+            ranges=_view(fv.splat_start_end_idx_by_tile_idx, (T + 1,), "<i4", o),
+            image=_view(fv.image, (H, W, 3), "<f4", o), T=_view(fv.weight_per_pixel, (H, W), "<f4", o),
+            n=_view(fv.splats_per_pixel, (H, W), "<i4", o))
+        self._last = (g.num_gaussians, M, l_max)
+        return out
+
+    def alloc_gradients(self, M, l_max, intermediates=False, device="cuda"):
+        n_rest = (l_max + 1) ** 2 - 1
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        g = dict(xyz=z(M, 3), rgb=z(M, 3), sh=z(M, n_rest, 3), opacity=z(M), scale=z(M, 3), quaternion=z(M, 4))
+        if intermediates:
+            g.update(conic=z(M, 3), uv=z(M, 2), J=z(M, 6), sigma=z(M, 6), xyz_c=z(M, 3), precompute_rgb=z(M, 3))
+        return g
+
+    @staticmethod
+    def _grad_struct(grads):
+        gs = _lib.Gradients()
+        gs.grad_xyz, gs.grad_rgb, gs.grad_sh = _ptr(grads["xyz"]), _ptr(grads["rgb"]), _ptr(grads["sh"])
+        gs.grad_opacity, gs.grad_scale = _ptr(grads["opacity"]), _ptr(grads["scale"])
+        gs.grad_quaternion = _ptr(grads["quaternion"])
+        for k in ("conic", "uv", "J", "sigma", "xyz_c", "precompute_rgb"):
+            setattr(gs, "grad_" + k, _ptr(grads.get(k)))
+        return gs
+
+    def backward_pass(self, params, cam, grad_image, bg_color, l_max, grads):
+        """grads: dict from alloc_gradients (compacted order); every leaf gradient is overwritten."""
+        g, c = self._structs(params, cam, l_max)
+        gs = self._grad_struct(grads)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_backward_pass(self._h, ctypes.byref(g), ctypes.byref(c), _ptr(grad_image),
+                                             float(bg_color), int(l_max), ctypes.byref(gs), st))
+        return grads
+
+    def pack_gradients_global(self, grads, l_max, num_gaussians, packed):
+        gs = self._grad_struct(grads)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_pack_gradients_global(self._h, ctypes.byref(gs), int(l_max), int(num_gaussians),
+                                                     _ptr(packed), st))
+        return packed
+
+
+def packed_gradient_width(l_max):
+    return int(_lib.load().gsplat_packed_gradient_width(int(l_max)))

@@ -1,0 +1,115 @@
+"""Deterministic synthetic scenes for parity tests and the benchmark.
+
+Counter-based RNG: splitmix64 of (seed, stream, index) -> 24-bit uniform floats, so every
+array element is a pure function of its index and the same scene can be regenerated at any
+size, on any host, without shipping data.  Seed 0x3D65.
+
+Camera model and matrices follow the reference trainer
+(/root/reference/cuda/trainer.cu:1299-1331): PINHOLE, proj built from znear=0.01 /
+zfar=100, view = [R|t] row-major.
+"""
+import math
+
+import numpy as np
+
+SEED = 0x3D65
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _splitmix64(state):
+    z = state.copy()
+    z ^= z >> np.uint64(30)
+    z *= _M1
+    z ^= z >> np.uint64(27)
+    z *= _M2
+    z ^= z >> np.uint64(31)
+    return z
+
+
+def _stream_base(seed, stream):
+    s = np.array([np.uint64(seed) ^ (np.uint64(stream + 1) * np.uint64(0xD1B54A32D192ED03))], dtype=np.uint64)
+    return _splitmix64(s)[0]
+
+
+def uniform24(seed, stream, count, offset=0):
+    """count floats in [0,1) with 24 random bits each (exact in float32)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(offset + 1, offset + count + 1, dtype=np.uint64)
+        z = _splitmix64(_stream_base(seed, stream) + idx * _GOLDEN)
+    return (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def normal(seed, stream, count):
+    u1 = uniform24(seed, stream, count)
+    u2 = uniform24(seed, stream + 1000, count)
+    return np.sqrt(-2.0 * np.log(u1 + 0.5 / (1 << 24))) * np.cos(2.0 * math.pi * u2)
+
+
+def make_camera(width, height, view_index=0):
+    """60-degree horizontal FOV pinhole; view 0 is the identity pose, view k>0 a small deterministic
+    rotation + translation (used to give each rank of a view-sharded run its own training view)."""
+    fx = fy = width / (2.0 * math.tan(math.radians(30.0)))
+    znear, zfar = 0.01, 100.0
+    fov_x = 2.0 * math.atan(width / (2.0 * fx))
+    fov_y = 2.0 * math.atan(height / (2.0 * fy))
+    top = math.tan(fov_y / 2.0) * znear
+    right = math.tan(fov_x / 2.0) * znear
+    proj = np.zeros(16, np.float32)
+    proj[0] = 2.0 * znear / (2.0 * right)
+    proj[5] = 2.0 * znear / (2.0 * top)
+    proj[14] = 1.0
+    proj[10] = zfar / (zfar - znear)
+    proj[11] = -(zfar * znear) / (zfar - znear)
+    if view_index == 0:
+        R = np.eye(3)
+        t = np.zeros(3)
+    else:
+        u = uniform24(SEED, 900 + view_index, 6)
+        ay, ax = (u[0] - 0.5) * 0.12, (u[1] - 0.5) * 0.08
+        Ry = np.array([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+        R = Rx @ Ry
+        t = (u[2:5] - 0.5) * np.array([0.6, 0.4, 0.6])
+    view = np.zeros(16, np.float32)
+    view[[0, 1, 2, 4, 5, 6, 8, 9, 10]] = R.astype(np.float32).reshape(-1)
+    view[[3, 7, 11]] = t.astype(np.float32)
+    view[15] = 1.0
+    campos = (-R.T @ t).astype(np.float32)  # Image::CamPos(), src/colmap.cpp
+    return dict(width=int(width), height=int(height), fx=float(np.float32(fx)), fy=float(np.float32(fy)),
+                view=view, proj=proj, campos=campos)
+
+
+def make_gaussians(num, width, height, l_max, seed=SEED):
+    """Gaussian parameters in the reference's device layout (cuda_data.cuh:11-16)."""
+    fx = width / (2.0 * math.tan(math.radians(30.0)))
+    u = (uniform24(seed, 1, num) * 1.10 - 0.05) * width
+    v = (uniform24(seed, 2, num) * 1.10 - 0.05) * height
+    z = 2.0 + 10.0 * uniform24(seed, 3, num)
+    xyz = np.stack([(u - width / 2.0) * z / fx, (v - height / 2.0) * z / fx, z], 1).astype(np.float32)
+    s0 = 1.5 * 7.0 / fx
+    scale = np.log(s0 * np.exp(0.35 * normal(seed, 10, 3 * num))).reshape(num, 3).astype(np.float32)
+    quaternion = normal(seed, 20, 4 * num).reshape(num, 4).astype(np.float32)
+    opacity = (-2.0 + 5.0 * uniform24(seed, 30, num)).astype(np.float32)
+    rgb = (-1.5 + 3.0 * uniform24(seed, 40, 3 * num)).reshape(num, 3).astype(np.float32)
+    n_rest = (l_max + 1) ** 2 - 1
+    sh = (0.1 * normal(seed, 50, 3 * n_rest * num)).reshape(num, n_rest, 3).astype(np.float32) if n_rest else \
+        np.zeros((num, 0, 3), np.float32)
+    return dict(xyz=xyz, rgb=rgb, sh=sh, opacity=opacity, scale=scale, quaternion=quaternion)
+
+
+def make_grad_image(width, height, seed=SEED):
+    g = (uniform24(seed, 60, 3 * width * height) * 2.0 - 1.0) / (3.0 * width * height)
+    return g.reshape(height, width, 3).astype(np.float32)
+
+
+CONFIG = dict(near_thresh=0.3, mh_dist=3.0, cull_mask_padding=100, bg=0.5)  # config/base.yaml:9-11
+
+WORKLOADS = {
+    # name: (N, W, H, l_max, backward)
+    "tiny": (200, 64, 48, 3, True),
+    "small": (5000, 256, 144, 3, True),
+    "config2": (100_000, 800, 800, 0, False),
+    "config3": (1_000_000, 1920, 1080, 3, True),
+}

@@ -1,0 +1,237 @@
+/*
+ * gsplat_hip.h -- C ABI of libgsplat_hip.so, the MI355X (gfx950) differentiable
+ * gaussian-splat rasterizer.
+ *
+ * Drop-in boundary.  Every gsplat_<op> below replaces the free function <op> that the
+ * reference declares in include/gsplat_cuda/cuda_forward.cuh:26-131 and
+ * include/gsplat_cuda/cuda_backward.cuh:21-123 (AndrewBoessen/3DGS) and takes the same
+ * raw device pointers and scalars in the same order.  ABI adaptations, all mechanical:
+ *   float3 campos        -> three floats
+ *   float4* radius       -> float* (4 floats per gaussian, 16-byte aligned)
+ *   bool* mask           -> unsigned char* (one byte per gaussian, 0/1)
+ *   size_t& count        -> size_t*
+ *   cudaStream_t stream  -> void* (a hipStream_t; NULL = the null stream)
+ *   void / exit(1)       -> int status (0 = GSPLAT_OK, negative = error; nothing exits)
+ * include/gsplat_cuda/cuda_forward.cuh and cuda_backward.cuh in this repository are C++
+ * shims with the reference's exact signatures (and its print-and-exit error behaviour)
+ * that forward to these symbols, so a host written against the reference's headers
+ * compiles unchanged.
+ *
+ * Ownership: the caller owns every buffer it passes.  Outputs documented "+=" are
+ * accumulated into and must be pre-zeroed by the caller, exactly as in the reference
+ * (cuda/trainer.cu:247-261).  Operators may use library-owned scratch memory that is
+ * grown on demand and released by gsplat_release_scratch().
+ *
+ * Threading: one host thread per device at a time (the reference's trainer thread).
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSPLAT_OK 0
+#define GSPLAT_ERR_NULL_POINTER (-1)   /* a required pointer is NULL            (checks.cuh:17-21)  */
+#define GSPLAT_ERR_NOT_DEVICE (-2)     /* pointer is not device memory          (checks.cuh:23-38)  */
+#define GSPLAT_ERR_INVALID_ARG (-3)    /* negative size, l_max outside 0..3 ... (raster.cu:58-60)   */
+#define GSPLAT_ERR_HIP (-4)            /* a HIP runtime call or kernel launch failed                 */
+#define GSPLAT_ERR_NO_VISIBLE (-5)     /* nothing survives culling              (raster.cu:38-41)   */
+#define GSPLAT_ERR_CAPACITY (-6)       /* context capacity exceeded                                   */
+
+#define GSPLAT_TILE_SIZE 16 /* TILE_SIZE_FWD / TILE_SIZE_BWD, cuda_forward.cuh:8, cuda_backward.cuh:8 */
+
+/* Human-readable text for the last error raised on the calling thread. */
+const char *gsplat_last_error(void);
+/* Library ABI version (bumped when a signature changes). */
+int gsplat_abi_version(void);
+/* Frees library-owned scratch memory of the current device. */
+int gsplat_release_scratch(void);
+
+/* ---------------------------------------------------------------- forward operators --- */
+
+/* replaces compute_camera_space_points  (cuda_forward.cuh:50-51, cuda/projection.cu:100-114)
+ * xyz_c[N,3] = view[0:3,0:4] * [xyz_w;1], view row-major 4x4 */
+int gsplat_compute_camera_space_points(const float *xyz_w, const float *view, int N, float *xyz_c, void *stream);
+
+/* replaces project_to_screen  (cuda_forward.cuh:63-64, cuda/projection.cu:116-130) -> uv[N,2] */
+int gsplat_project_to_screen(const float *xyz, const float *proj, int N, int width, int height, float *uv,
+                             void *stream);
+
+/* replaces cull_gaussians  (cuda_forward.cuh:78-79, cuda/culling.cu:361-375); mask: 1 = keep */
+int gsplat_cull_gaussians(const float *uv, const float *xyz, int N, float near_thresh, int padding, int width,
+                          int height, unsigned char *mask, void *stream);
+
+/* replaces compute_sigma  (cuda_forward.cuh:39, cuda/gaussian.cu:220-235)
+ * quaternion[N,4] in (w,x,y,z) order, scale[N,3] log-scales -> sigma[N,6] = [xx,xy,xz,yy,yz,zz] */
+int gsplat_compute_sigma(const float *quaternion, const float *scale, int N, float *sigma, void *stream);
+
+/* replaces compute_conic  (cuda_forward.cuh:26-28, cuda/gaussian.cu:237-262)
+ * -> J[N,6], conic[N,3] = [c00,c01,c11], radius[N,4] = {r_major, r_minor, sin(theta), cos(theta)} */
+int gsplat_compute_conic(const float *xyz, const float *view, const float *sigma, float focal_x, float focal_y,
+                         float tan_fovx, float tan_fovy, float mh_dist, int N, float *J, float *conic,
+                         float *radius, void *stream);
+
+/* replaces get_sorted_gaussian_list  (cuda_forward.cuh:95-97, cuda/culling.cu:386-475)
+ * Two-call protocol, as in the reference:
+ *   sorted_gaussians == NULL : *sorted_gaussian_count <- number of coarse (tile, gaussian)
+ *                              candidate pairs; the caller sizes sorted_gaussians with it.
+ *   sorted_gaussians != NULL : sorted_gaussians[0..S) <- gaussian ids ordered by (tile, depth),
+ *                              ties by gaussian id; splat_start_end_idx_by_tile_idx[0..T] <-
+ *                              start offsets (entry T = S).  Blocks the host, as the reference does. */
+int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz, const float *radius, int n_tiles_x,
+                                    int n_tiles_y, int N, size_t *sorted_gaussian_count, int *sorted_gaussians,
+                                    int *splat_start_end_idx_by_tile_idx, void *stream);
+
+/* replaces precompute_spherical_harmonics  (cuda_forward.cuh:111-113, cuda/spherical_harmonics.cu:62-94)
+ * sh_coefficients[N,(l_max+1)^2-1,3] (may be NULL when l_max == 0), band 0 in sh_coeffs_band_0[N,3];
+ * rgb = 0.5 + sum coeff * Y(dir), dir = normalize(xyz - campos); no clamp */
+int gsplat_precompute_spherical_harmonics(const float *xyz, const float *sh_coefficients,
+                                          const float *sh_coeffs_band_0, float campos_x, float campos_y,
+                                          float campos_z, int l_max, int N, float *rgb, void *stream);
+
+/* replaces render_image  (cuda_forward.cuh:131-134, cuda/render.cu:110-135)
+ * -> splats_per_pixel[H,W], weight_per_pixel[H,W] (final transmittance), image[H,W,3] */
+int gsplat_render_image(const float *uv, const float *opacity, const float *conic, const float *rgb,
+                        float background_opacity, const int *sorted_splats, const int *splat_range_by_tile,
+                        int image_width, int image_height, int *splats_per_pixel, float *weight_per_pixel,
+                        float *image, void *stream);
+
+/* --------------------------------------------------------------- backward operators --- */
+
+/* replaces project_to_screen_backward  (cuda_backward.cuh:21-23); xyz_c_grad_in += */
+int gsplat_project_to_screen_backward(const float *xyz_c, const float *proj, const float *uv_grad_out, int N,
+                                      int width, int height, float *xyz_c_grad_in, void *stream);
+
+/* replaces compute_camera_space_points_backward  (cuda_backward.cuh:34-36); xyz_w_grad_in += */
+int gsplat_compute_camera_space_points_backward(const float *xyz_w, const float *view, const float *xyz_c_grad_out,
+                                                int N, float *xyz_w_grad_in, void *stream);
+
+/* replaces compute_projection_jacobian_backward  (cuda_backward.cuh:47-49); xyz_c_grad_in += */
+int gsplat_compute_projection_jacobian_backward(const float *xyz_c, float focal_x, float focal_y, float tan_fovx,
+                                                float tan_fovy, const float *J_grad_out, int N,
+                                                float *xyz_c_grad_in, void *stream);
+
+/* replaces compute_conic_backward  (cuda_backward.cuh:61-63); J_grad_in +=, sigma_grad_in +=
+ * (off-diagonal sigma entries receive the sum of both symmetric positions) */
+int gsplat_compute_conic_backward(const float *J, const float *sigma, const float *view, const float *conic,
+                                  const float *conic_grad_out, int N, float *J_grad_in, float *sigma_grad_in,
+                                  void *stream);
+
+/* replaces compute_sigma_backward  (cuda_backward.cuh:75-76); quaternion_grad_in =, scale_grad_in = */
+int gsplat_compute_sigma_backward(const float *quaternion, const float *scale, const float *sigma_grad_out, int N,
+                                  float *quaternion_grad_in, float *scale_grad_in, void *stream);
+
+/* replaces precompute_spherical_harmonics_backward  (cuda_backward.cuh:90-94)
+ * sh_grad_in =, sh_grad_band_0_in =, xyz_c_grad_in += */
+int gsplat_precompute_spherical_harmonics_backward(const float *xyz_c, const float *rgb_vals,
+                                                   const float *sh_coeffs, float campos_x, float campos_y,
+                                                   float campos_z, const float *rgb_grad_out, int l_max, int N,
+                                                   float *sh_grad_in, float *sh_grad_band_0_in,
+                                                   float *xyz_c_grad_in, void *stream);
+
+/* replaces render_image_backward  (cuda_backward.cuh:116-122); all four outputs += (pre-zeroed by the caller);
+ * grad_uv carries the reference's extra 0.5*W / 0.5*H factor (cuda/render_backward.cu:186-187) */
+int gsplat_render_image_backward(const float *uvs, const float *opacity, const float *conic, const float *rgb,
+                                 float background_opacity, const int *sorted_splats,
+                                 const int *splat_range_by_tile, const int *num_splats_per_pixel,
+                                 const float *final_weight_per_pixel, const float *grad_image, int image_width,
+                                 int image_height, float *grad_rgb, float *grad_opacity, float *grad_uv,
+                                 float *grad_conic, void *stream);
+
+/* ------------------------------------------------------------- compaction templates --- */
+
+/* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]
+ * into dst (room for N*stride floats); *num_selected <- rows kept (host value; blocks the host). */
+int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int N, int stride, float *dst,
+                                int *num_selected, void *stream);
+
+/* replaces scatter_masked_array<STRIDE>  (cuda_data.cuh:150-167): dst[i] <- src[rank(i)] where mask[i] */
+int gsplat_scatter_masked_array(const float *src, const unsigned char *mask, int N, int stride, float *dst,
+                                void *stream);
+
+/* --------------------------------------------------- fused per-view pass (additive API) --- */
+/*
+ * gsplat_rasterize_image / gsplat_backward_pass are the device-resident equivalents of
+ * rasterize_image (raster.cuh:22-24, cuda/raster.cu:12-136) and of the operator chain in
+ * TrainerImpl::backward_pass (cuda/trainer.cu:941-1012).  They run on a context that owns
+ * a persistent workspace (no per-call allocation), fuse the per-gaussian operators into
+ * one preprocess kernel each way, and need one host read-back per forward (M and S).
+ * Results are identical in layout to ForwardPassData / GaussianGradients: per-gaussian
+ * buffers are in compacted (post-cull) order.
+ */
+typedef struct gsplat_context gsplat_context;
+
+typedef struct gsplat_camera {
+  int width, height;
+  float focal_x, focal_y;  /* camera.params[0], params[1]                         */
+  float campos[3];         /* Image::CamPos()                                     */
+  const float *view;       /* device, 16 floats row-major [R|t]  (trainer.cu:1321-1331) */
+  const float *proj;       /* device, 16 floats row-major        (trainer.cu:1310-1318) */
+} gsplat_camera;
+
+typedef struct gsplat_gaussians {      /* GaussianParameters, cuda_data.cuh:11-16; all device pointers */
+  int num_gaussians;
+  const float *xyz;        /* [N,3] */
+  const float *rgb;        /* [N,3]  SH band 0 */
+  const float *sh;         /* [N,(l_max+1)^2-1,3], may be NULL when l_max == 0 */
+  const float *opacity;    /* [N]   logits */
+  const float *scale;      /* [N,3] log-scales */
+  const float *quaternion; /* [N,4] (w,x,y,z) */
+} gsplat_gaussians;
+
+typedef struct gsplat_raster_config {  /* the ConfigParameters fields the path reads, raster.cu:33,100 */
+  float near_thresh, mh_dist;
+  int cull_mask_padding;
+} gsplat_raster_config;
+
+typedef struct gsplat_forward_view {   /* ForwardPassData, cuda_data.cuh:70-86: pointers INTO the context */
+  size_t num_culled;                   /* M */
+  size_t num_pairs;                    /* coarse candidates (what call 1 of get_sorted_gaussian_list reports) */
+  size_t num_splats;                   /* S */
+  const unsigned char *mask;           /* [N] */
+  const float *uv, *xyz_c;             /* [N,2], [N,3] uncompacted */
+  const int *compact_to_global;        /* [M] */
+  const float *sigma, *conic, *J, *precomputed_rgb, *radius; /* [M,6] [M,3] [M,6] [M,3] [M,4] */
+  const float *uv_selected, *xyz_c_selected;                 /* [M,2] [M,3] */
+  const int *sorted_gaussians;         /* [S] compacted ids */
+  const int *splat_start_end_idx_by_tile_idx; /* [T+1] */
+  const float *image, *weight_per_pixel;      /* [H,W,3] [H,W] */
+  const int *splats_per_pixel;                /* [H,W] */
+} gsplat_forward_view;
+
+typedef struct gsplat_gradients {      /* GaussianGradients (leaf part), compacted order [M,...], caller-owned */
+  float *grad_xyz, *grad_rgb, *grad_sh, *grad_opacity, *grad_scale, *grad_quaternion;
+  /* optional intermediates (may be NULL): */
+  float *grad_conic, *grad_uv, *grad_J, *grad_sigma, *grad_xyz_c, *grad_precompute_rgb;
+} gsplat_gradients;
+
+int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width, int max_height);
+int gsplat_context_destroy(gsplat_context *ctx);
+/* bytes of device memory currently held by the context */
+size_t gsplat_context_bytes(const gsplat_context *ctx);
+
+int gsplat_rasterize_image(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
+                           const gsplat_raster_config *config, float bg_color, int l_max,
+                           gsplat_forward_view *out, void *stream);
+
+/* Consumes the state left in ctx by the last gsplat_rasterize_image.  All leaf gradients are
+ * overwritten ("=" on a zeroed buffer, i.e. the state after zero_grads + backward_pass). */
+int gsplat_backward_pass(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
+                         const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
+                         void *stream);
+
+/* View-sharded training support: scatter compacted per-view gradients into one global-order
+ * row-major buffer packed[N, 12 + 3*n_coeffs] = [xyz3 | band0 3 | sh 3(n_coeffs-1) | opacity1 | scale3 | quat4 |
+ * visible1], zero where culled, ready for one RCCL all-reduce. */
+int gsplat_pack_gradients_global(gsplat_context *ctx, const gsplat_gradients *grads, int l_max, int num_gaussians,
+                                 float *packed, void *stream);
+int gsplat_packed_gradient_width(int l_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

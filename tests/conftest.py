@@ -1,0 +1,75 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(name=""):
+    """The package directory starts with a digit, so it is imported through importlib."""
+    return importlib.import_module("3dgs_amd" + ("." + name if name else ""))
+
+
+@pytest.fixture(scope="session")
+def scene():
+    return pkg("scene")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle  # test infrastructure: the CPU parity oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """torch + the HIP library; fails loudly (no CPU fallback) when either is missing."""
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    lib = pkg("_lib").load()
+    assert lib.gsplat_abi_version() >= 1
+    return torch
+
+
+# ---------------------------------------------------------------- comparison helpers (tolerances live here)
+PIXEL_L1_TOL = 1e-4      # north_star: rendered pixels within 1e-4 per-pixel L1
+GRAD_REL_TOL = 1e-3      # north_star: gradients within 1e-3 relative
+# The alpha > 1/255 test is a step function of a float expression: two correct implementations that round the
+# exponent differently may flip it on a few (pixel, gaussian) pairs, each worth at most alpha*colour ~ 4e-3.
+FLIP_FRACTION = 2e-4
+
+
+def assert_image_close(got, ref, what="image"):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    per_pixel_l1 = err.reshape(-1, got.shape[-1]).sum(1) if got.ndim == 3 else err.reshape(-1)
+    assert per_pixel_l1.mean() < PIXEL_L1_TOL, f"{what}: mean per-pixel L1 {per_pixel_l1.mean():.3e}"
+    bad = (per_pixel_l1 > PIXEL_L1_TOL).mean()
+    assert bad <= FLIP_FRACTION, f"{what}: {bad:.2e} of pixels differ by more than {PIXEL_L1_TOL}"
+    assert err.max() < 2e-2, f"{what}: max abs error {err.max():.3e}"
+
+
+def assert_grad_close(got, ref, what="grad", rel=GRAD_REL_TOL):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if ref.size == 0:
+        return
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    scale = np.abs(ref).mean() + 1e-30
+    denom = np.sqrt((ref ** 2).sum()) + 1e-30
+    l2 = np.sqrt(((got - ref) ** 2).sum()) / denom
+    assert l2 < rel, f"{what}: relative L2 error {l2:.3e}"
+    tol = rel * np.abs(ref) + rel * scale
+    bad = (np.abs(got - ref) > tol).mean()
+    assert bad <= 5e-4, f"{what}: {bad:.2e} of elements outside {rel} relative (+{rel}*mean|ref|)"

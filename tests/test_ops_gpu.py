@@ -1,0 +1,266 @@
+"""GPU parity of every stand-alone operator (through the C ABI) against the CPU oracle.
+
+Inputs come from the deterministic scene generator; the oracle (test infrastructure) is the
+checker.  Per-gaussian operators share their arithmetic order with the oracle, so they must
+agree to a few ulps; the compositing operators are compared with the north-star tolerances
+(1e-4 per-pixel L1, 1e-3 relative on gradients).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_grad_close, assert_image_close, pkg
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(near_thresh=0.3, mh_dist=3.0, cull_mask_padding=100)
+
+
+def _dev(torch, a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module")
+def case(scene, orc):
+    N, W, H, L, _ = scene.WORKLOADS["small"]
+    params = scene.make_gaussians(N, W, H, L)
+    cam = scene.make_camera(W, H, view_index=1)  # non-trivial pose
+    fwd = orc.rasterize(params, cam, 0.3, 3.0, 100, 0.5, L, threads=8)
+    gi = scene.make_grad_image(W, H)
+    bwd = orc.backward_pass(fwd, cam, gi, 0.5, L, threads=8)
+    return dict(N=N, W=W, H=H, L=L, params=params, cam=cam, fwd=fwd, gi=gi, bwd=bwd)
+
+
+def test_projection_and_cull(gpu, case):
+    torch, ops = gpu, pkg("ops")
+    N, W, H, f, cam = case["N"], case["W"], case["H"], case["fwd"], case["cam"]
+    xyz = _dev(torch, case["params"]["xyz"])
+    view, proj = _dev(torch, cam["view"]), _dev(torch, cam["proj"])
+    xyz_c = torch.empty(N, 3, device="cuda")
+    uv = torch.empty(N, 2, device="cuda")
+    mask = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    ops.compute_camera_space_points(xyz, view, N, xyz_c)
+    ops.project_to_screen(xyz_c, proj, N, W, H, uv)
+    ops.cull_gaussians(uv, xyz_c, N, 0.3, 100, W, H, mask)
+    np.testing.assert_allclose(xyz_c.cpu().numpy(), f["xyz_c_all"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(uv.cpu().numpy(), f["uv_all"], rtol=1e-6, atol=1e-4)
+    assert (mask.cpu().numpy().astype(bool) == f["mask"]).all()
+
+
+def test_known_answer_cull(gpu):  # reference tests/cuda_forward_test.cpp:159-230
+    torch, ops = gpu, pkg("ops")
+    xyz = _dev(torch, np.array([[0, 0, 5], [0, 0, .5], [0, 0, 12], [0, 0, 5], [0, 0, 5], [0, 0, 12], [0, 0, .5]], np.float32))
+    uv = _dev(torch, np.array([[960, 540], [960, 540], [960, 540], [-5, 540], [1925, 540], [-11, 540], [960, 1091]], np.float32))
+    mask = torch.zeros(7, dtype=torch.uint8, device="cuda")
+    ops.cull_gaussians(uv, xyz, 7, 1.0, 10, 1920, 1080, mask)
+    assert mask.cpu().tolist() == [1, 0, 1, 1, 1, 0, 0]
+
+
+def test_sigma_conic_radius(gpu, case):
+    torch, ops = gpu, pkg("ops")
+    f, cam = case["fwd"], case["cam"]
+    M = f["num_culled"]
+    q, s = _dev(torch, f["quaternion"]), _dev(torch, f["scale"])
+    sigma = torch.empty(M, 6, device="cuda")
+    ops.compute_sigma(q, s, M, sigma)
+    np.testing.assert_allclose(sigma.cpu().numpy(), f["sigma"], rtol=2e-5, atol=1e-9)
+    J, conic, radius = torch.empty(M, 6, device="cuda"), torch.empty(M, 3, device="cuda"), torch.empty(M, 4, device="cuda")
+    # feed the oracle's sigma so that only compute_conic is under test
+    ops.compute_conic(_dev(torch, f["xyz_c"]), _dev(torch, cam["view"]), _dev(torch, f["sigma"]), cam["fx"], cam["fy"],
+                      f["tan_fovx"], f["tan_fovy"], 3.0, M, J, conic, radius)
+    np.testing.assert_allclose(J.cpu().numpy(), f["J"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(conic.cpu().numpy(), f["conic"], rtol=1e-5, atol=1e-7)
+    r = radius.cpu().numpy()
+    assert (r[:, :2] == f["radius"][:, :2]).mean() > 0.999  # ceil() of values that agree to ~1 ulp
+    np.testing.assert_allclose(r[:, 2:], f["radius"][:, 2:], atol=2e-6)
+
+
+def test_known_answer_conic(gpu):  # reference tests/cuda_forward_test.cpp:306-414
+    torch, ops = gpu, pkg("ops")
+    J, conic, radius = torch.empty(1, 6, device="cuda"), torch.empty(1, 3, device="cuda"), torch.empty(1, 4, device="cuda")
+    ops.compute_conic(_dev(torch, np.array([1, 2, 5], np.float32)), _dev(torch, np.eye(4, dtype=np.float32).ravel()),
+                      _dev(torch, np.array([1, 0, 0, 1, 0, 1], np.float32)), 1.0, 1.0, 1.0, 1.0, 3.0, 1, J, conic, radius)
+    np.testing.assert_allclose(radius.cpu().numpy()[0], [3, 1, np.sqrt(.8), np.sqrt(.2)], atol=1e-5)
+    c00, c01, c11 = .04 + .0016 + .3, .04 * .08, .04 + .0064 + .3
+    det = c00 * c11 - c01 * c01
+    np.testing.assert_allclose(conic.cpu().numpy()[0], [c11 / det, -c01 / det, c00 / det], atol=1e-5)
+
+
+@pytest.mark.parametrize("l_max", [0, 1, 2, 3])
+def test_spherical_harmonics_forward_backward(gpu, orc, scene, l_max):
+    torch, ops = gpu, pkg("ops")
+    M = 3000
+    p = scene.make_gaussians(M, 256, 144, l_max)
+    campos = np.array([0.3, -0.2, 0.1], np.float32)
+    rgb_ref = orc.precompute_spherical_harmonics(p["xyz"], p["sh"], p["rgb"], campos, l_max)
+    xyz, sh, band0 = _dev(torch, p["xyz"]), _dev(torch, p["sh"]), _dev(torch, p["rgb"])
+    rgb = torch.empty(M, 3, device="cuda")
+    ops.precompute_spherical_harmonics(xyz, sh if l_max else None, band0, campos, l_max, M, rgb)
+    np.testing.assert_allclose(rgb.cpu().numpy(), rgb_ref, rtol=1e-5, atol=2e-6)
+    g = scene.normal(77, 5, 3 * M).reshape(M, 3).astype(np.float32)
+    pre = np.full((M, 3), 0.25, np.float32)
+    shg_ref, b0g_ref, xg_ref = orc.precompute_spherical_harmonics_backward(p["xyz"], p["rgb"], p["sh"], campos, g, l_max,
+                                                                           xyz_grad=pre)
+    n_rest = (l_max + 1) ** 2 - 1
+    shg = torch.empty(M, max(n_rest, 1), 3, device="cuda")
+    b0g = torch.empty(M, 3, device="cuda")
+    xg = _dev(torch, pre)  # "+=" output
+    ops.precompute_spherical_harmonics_backward(xyz, band0, sh if l_max else None, campos, _dev(torch, g), l_max, M,
+                                                shg if l_max else None, b0g, xg)
+    np.testing.assert_allclose(b0g.cpu().numpy(), b0g_ref, rtol=1e-6, atol=1e-8)
+    if l_max:
+        np.testing.assert_allclose(shg.cpu().numpy()[:, :n_rest], shg_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xg.cpu().numpy(), xg_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_binning_is_bit_exact(gpu, case):
+    """Same uv / depth / radius in -> identical lists out (integer work: bit-exact bar)."""
+    torch, ops = gpu, pkg("ops")
+    f, W, H = case["fwd"], case["W"], case["H"]
+    M = f["num_culled"]
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    uv, xyz_c, radius = _dev(torch, f["uv"]), _dev(torch, f["xyz_c"]), _dev(torch, f["radius"])
+    count = ops.get_sorted_gaussian_list(uv, xyz_c, radius, ntx, nty, M, 0, None, None)
+    assert count == f["num_pairs"]
+    srt = torch.full((count,), -1, dtype=torch.int32, device="cuda")
+    ranges = torch.full((ntx * nty + 1,), -1, dtype=torch.int32, device="cuda")
+    ops.get_sorted_gaussian_list(uv, xyz_c, radius, ntx, nty, M, count, srt, ranges)
+    S = len(f["sorted"])
+    assert (ranges.cpu().numpy() == f["ranges"]).all()
+    assert (srt.cpu().numpy()[:S] == f["sorted"]).all()
+
+
+def test_known_answer_binning(gpu):  # reference tests/cuda_forward_test.cpp:422-538
+    torch, ops = gpu, pkg("ops")
+    uv = _dev(torch, np.array([24, 24, 32, 24, 40, 40], np.float32))
+    xyz = _dev(torch, np.array([0, 0, 10, 0, 0, 20, 0, 0, 5], np.float32))
+    radius = _dev(torch, np.array([4, 4, 0, 1, 4, 4, 0, 1, 6, 6, 0, 1], np.float32))
+    assert ops.get_sorted_gaussian_list(uv, xyz, radius, 4, 4, 3, 0, None, None) == 48
+    srt = torch.zeros(48, dtype=torch.int32, device="cuda")
+    rng = torch.zeros(17, dtype=torch.int32, device="cuda")
+    ops.get_sorted_gaussian_list(uv, xyz, radius, 4, 4, 3, 48, srt, rng)
+    assert srt.cpu().tolist()[:4] == [0, 1, 1, 2]
+    r = rng.cpu().tolist()
+    assert [r[5], r[6], r[7], r[10], r[11], r[16]] == [0, 2, 3, 3, 4, 4]
+
+
+def _render_inputs(torch, f):
+    return (_dev(torch, f["uv"]), _dev(torch, f["opacity"]), _dev(torch, f["conic"]), _dev(torch, f["rgb"]),
+            _dev(torch, f["sorted"]), _dev(torch, f["ranges"]))
+
+
+def test_render_image(gpu, case):
+    torch, ops = gpu, pkg("ops")
+    f, W, H = case["fwd"], case["W"], case["H"]
+    uv, op, conic, rgb, srt, rng = _render_inputs(torch, f)
+    n = torch.zeros(H, W, dtype=torch.int32, device="cuda")
+    T = torch.zeros(H, W, device="cuda")
+    img = torch.zeros(H, W, 3, device="cuda")
+    ops.render_image(uv, op, conic, rgb, 0.5, srt, rng, W, H, n, T, img)
+    assert_image_close(img.cpu().numpy(), f["image"], "image")
+    assert_image_close(T.cpu().numpy(), f["T"], "final transmittance")
+    assert (n.cpu().numpy() != f["n"]).mean() < 2e-4
+
+
+def test_known_answer_render(gpu):  # reference tests/cuda_forward_test.cpp:631-767
+    torch, ops = gpu, pkg("ops")
+    from test_oracle_known_answers import _expected_color
+    uv = [7.5, 7.5, 3.5, 3.5, 11.5, 11.5]
+    opacity, rgb = [0.5, 0.6, 0.4], [1.0, 0.8, 0.4, 0.4, 0.8, 1.0, 0.8, 1.0, 0.4]
+    conic = [1.0, 0.0, 1.0, 2.0, 0.5, 2.0, 1.5, -0.5, 1.5]
+    f32 = lambda a: _dev(torch, np.array(a, np.float32))
+    n = torch.zeros(16, 16, dtype=torch.int32, device="cuda")
+    T, img = torch.zeros(16, 16, device="cuda"), torch.zeros(16, 16, 3, device="cuda")
+    ops.render_image(f32(uv), f32(opacity), f32(conic), f32(rgb), 1.0, _dev(torch, np.array([0, 1, 2], np.int32)),
+                     _dev(torch, np.array([0, 3], np.int32)), 16, 16, n, T, img)
+    img = img.cpu().numpy()
+    np.testing.assert_allclose(img[7, 7], _expected_color(7.0, 7.0, uv, opacity, conic, rgb, 1.0), atol=1e-3)
+    np.testing.assert_allclose(img[0, 0], [1, 1, 1], atol=1e-3)
+    assert (n.cpu().numpy() == 3).all()
+
+
+def test_render_image_backward(gpu, case):
+    torch, ops = gpu, pkg("ops")
+    f, b, W, H = case["fwd"], case["bwd"], case["W"], case["H"]
+    M = f["num_culled"]
+    uv, op, conic, rgb, srt, rng = _render_inputs(torch, f)
+    g_rgb, g_op = torch.zeros(M, 3, device="cuda"), torch.zeros(M, device="cuda")
+    g_uv, g_conic = torch.zeros(M, 2, device="cuda"), torch.zeros(M, 3, device="cuda")
+    ops.render_image_backward(uv, op, conic, rgb, 0.5, srt, rng, _dev(torch, f["n"]), _dev(torch, f["T"]),
+                              _dev(torch, case["gi"]), W, H, g_rgb, g_op, g_uv, g_conic)
+    assert_grad_close(g_rgb.cpu().numpy(), b["rgb_pre"], "grad_rgb")
+    assert_grad_close(g_op.cpu().numpy(), b["opacity"], "grad_opacity")
+    assert_grad_close(g_uv.cpu().numpy(), b["uv"], "grad_uv")
+    assert_grad_close(g_conic.cpu().numpy(), b["conic"], "grad_conic")
+    # "+=": a second call doubles the result
+    ops.render_image_backward(uv, op, conic, rgb, 0.5, srt, rng, _dev(torch, f["n"]), _dev(torch, f["T"]),
+                              _dev(torch, case["gi"]), W, H, g_rgb, g_op, g_uv, g_conic)
+    assert_grad_close(g_op.cpu().numpy(), 2 * b["opacity"], "grad_opacity accumulated")
+
+
+def test_per_gaussian_backward_chain(gpu, case):
+    """conic -> (J, Sigma) -> (xyz_c, quaternion, scale), uv -> xyz_c -> xyz, with the reference's += chaining."""
+    torch, ops = gpu, pkg("ops")
+    f, b, cam, W, H = case["fwd"], case["bwd"], case["cam"], case["W"], case["H"]
+    M = f["num_culled"]
+    view, proj = _dev(torch, cam["view"]), _dev(torch, cam["proj"])
+    gJ, gS = torch.zeros(M, 6, device="cuda"), torch.zeros(M, 6, device="cuda")
+    ops.compute_conic_backward(_dev(torch, f["J"]), _dev(torch, f["sigma"]), view, _dev(torch, f["conic"]),
+                               _dev(torch, b["conic"]), M, gJ, gS)
+    assert_grad_close(gJ.cpu().numpy(), b["J"], "grad_J", rel=1e-4)
+    assert_grad_close(gS.cpu().numpy(), b["sigma"], "grad_sigma", rel=1e-4)
+    tfx = float(np.tan(np.float32(2) * np.arctan(np.float32(W) / (np.float32(2) * np.float32(cam["fx"]))) * np.float32(.5)))
+    tfy = float(np.tan(np.float32(2) * np.arctan(np.float32(H) / (np.float32(2) * np.float32(cam["fy"]))) * np.float32(.5)))
+    g_xyz_c = torch.zeros(M, 3, device="cuda")
+    ops.compute_projection_jacobian_backward(_dev(torch, f["xyz_c"]), cam["fx"], cam["fy"], tfx, tfy,
+                                             _dev(torch, b["J"]), M, g_xyz_c)
+    gq, gs = torch.empty(M, 4, device="cuda"), torch.empty(M, 3, device="cuda")
+    ops.compute_sigma_backward(_dev(torch, f["quaternion"]), _dev(torch, f["scale"]), _dev(torch, b["sigma"]), M, gq, gs)
+    assert_grad_close(gq.cpu().numpy(), b["quaternion"], "grad_quaternion", rel=1e-4)
+    assert_grad_close(gs.cpu().numpy(), b["scale"], "grad_scale", rel=1e-4)
+    ops.project_to_screen_backward(_dev(torch, f["xyz_c"]), proj, _dev(torch, b["uv"]), M, W, H, g_xyz_c)
+    assert_grad_close(g_xyz_c.cpu().numpy(), b["xyz_c"], "grad_xyz_c", rel=1e-4)
+    sh_part = b["xyz"] - 0  # oracle's final grad_xyz = SH term + R^T grad_xyz_c
+    g_xyz = torch.zeros(M, 3, device="cuda")
+    ops.compute_camera_space_points_backward(_dev(torch, f["xyz"]), view, _dev(torch, b["xyz_c"]), M, g_xyz)
+    R = np.asarray(cam["view"]).reshape(4, 4)[:3, :3]
+    np.testing.assert_allclose(g_xyz.cpu().numpy(), b["xyz_c"] @ R, rtol=1e-4, atol=1e-7)
+    assert np.isfinite(sh_part).all()
+
+
+def test_compact_and_scatter(gpu, orc):  # reference tests/cuda_data_test.cpp:38-125
+    torch, ops = gpu, pkg("ops")
+    rng = np.random.default_rng(3)
+    for N, stride in [(5, 1), (4, 3), (1000, 45), (2, 3)]:
+        src = rng.normal(size=N * stride).astype(np.float32)
+        for mask in [rng.random(N) < 0.5, np.ones(N, bool), np.zeros(N, bool)]:
+            out = ops.compact_masked_array(stride, _dev(torch, src), _dev(torch, mask.astype(np.uint8)))
+            ref = orc.compact_masked_array(src, mask, stride)
+            assert out.shape[0] == ref.shape[0]
+            if ref.size:
+                assert (out.cpu().numpy() == ref).all()
+            dst = torch.zeros(N * stride, device="cuda")
+            ops.scatter_masked_array(stride, out if ref.size else None, _dev(torch, mask.astype(np.uint8)), dst)
+            assert (dst.cpu().numpy() == orc.scatter_masked_array(ref, mask, stride, np.zeros(N * stride))).all()
+    empty = ops.compact_masked_array(3, torch.empty(0, device="cuda"), torch.empty(0, dtype=torch.uint8, device="cuda"))
+    assert empty.numel() == 0
+
+
+def test_error_codes_instead_of_exit(gpu):
+    """Null / host pointers are reported as status codes (the reference exits: cuda/checks.cuh:17-38)."""
+    torch, ops, lib_mod = gpu, pkg("ops"), pkg("_lib")
+    good = torch.zeros(16, device="cuda")
+    with pytest.raises(lib_mod.GsplatError) as e:
+        ops.compute_camera_space_points(None, good, 1, good)
+    assert e.value.code == -1
+    import ctypes
+    host = (ctypes.c_float * 16)()
+    lib = lib_mod.load()
+    rc = lib.gsplat_compute_camera_space_points(ctypes.cast(host, ctypes.c_void_p), ctypes.c_void_p(good.data_ptr()), 1,
+                                                ctypes.c_void_p(good.data_ptr()), None)
+    assert rc == -2 and b"device" in lib.gsplat_last_error()
+    with pytest.raises(lib_mod.GsplatError) as e:
+        ops.precompute_spherical_harmonics(good, good, good, [0, 0, 0], 7, 1, good)
+    assert e.value.code == -3
