@@ -32,7 +32,7 @@ def _p(t):
 
 
 def _f32(t, name):
-    if t.dtype != torch.float32:
+    if t is not None and t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32")
     return t
 
