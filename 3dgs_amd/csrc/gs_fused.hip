@@ -46,6 +46,28 @@ struct gsplat_context {
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
+  // optional per-stage HIP-event timing (gsplat_context_set_timing)
+  static constexpr int kStages = 8, kSlots = 32;
+  bool timing = false;
+  hipEvent_t ev[kSlots][2 * kStages] = {};
+  unsigned char pending[kSlots][kStages] = {};
+  double stage_ms[kStages] = {};
+  long long stage_n[kStages] = {};
+  long long fwd_calls = 0;
+  int slot = 0;
+  void mark(int stage, bool stop, hipStream_t st) {
+    if (!timing) return;
+    (void)hipEventRecord(ev[slot][2 * stage + (stop ? 1 : 0)], st);
+    if (stop) pending[slot][stage] = 1;
+  }
+  void harvest(int sl) {
+    for (int k = 0; k < kStages; ++k)
+      if (pending[sl][k]) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[sl][2 * k], ev[sl][2 * k + 1]) == hipSuccess) { stage_ms[k] += ms; stage_n[k] += 1; }
+        pending[sl][k] = 0;
+      }
+  }
   // state of the last forward
   int N = 0, M = 0, l_max = 0, width = 0, height = 0;
   size_t S = 0;
@@ -65,6 +87,9 @@ struct gsplat_context {
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
+    for (int a = 0; a < kSlots; ++a)
+      for (int b = 0; b < 2 * kStages; ++b)
+        if (ev[a][b]) { (void)hipEventDestroy(ev[a][b]); ev[a][b] = nullptr; }
   }
 };
 
@@ -354,7 +379,13 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   const float fx = cam->focal_x, fy = cam->focal_y;
   const float tan_fovx = (float)W / (2.0f * fx), tan_fovy = (float)H / (2.0f * fy);  // cuda/raster.cu:92-93
 
+  if (c->timing) {  // next timing slot; its events are >= kSlots forwards old, hence complete
+    c->slot = (int)(c->fwd_calls % gsplat_context::kSlots);
+    c->harvest(c->slot);
+  }
+  c->fwd_calls++;
   const dim3 gridN(gs::div_up((long long)N + 1, kBlock)), block(kBlock);
+  c->mark(0, false, st);
   project_cull_kernel<<<gridN, block, 0, st>>>(g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh,
                                                cfg->cull_mask_padding, c->xyz_c_all.as<float>(), c->uv_all.as<float>(),
                                                c->mask.as<unsigned char>(), c->flags.as<int>());
@@ -362,6 +393,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   size_t scan_bytes = c->temp.bytes;
   GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->flags.as<int>(), c->rank.as<int>(), 0, (size_t)N + 1,
                                  rocprim::plus<int>(), st));
+  c->mark(0, true, st);
+  c->mark(1, false, st);
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
                c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>()};
   GS_HIP(hipMemsetAsync(c->counts.ptr, 0, (size_t)(N + 1) * sizeof(int), st));
@@ -387,6 +420,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   coarse_pairs_kernel<<<gs::div_up(N, kBlock), block, 0, st>>>(c->uv.as<float>(), c->radius.as<float>(), ntx, nty,
                                                               c->rank.as<int>() + N, d_pairs);
   GS_LAUNCH_CHECK();
+  c->mark(1, true, st);
   // the one host read-back of the forward: M, S (and the candidate count)
   GS_HIP(hipMemcpyAsync(&c->h_words[0], c->rank.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(&c->h_words[1], c->offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -402,18 +436,24 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   }
   int rc = reserve_instances(c, S, num_tiles);
   if (rc) return rc;
+  c->mark(2, false, st);
   if (S) {
     rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                               c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
                               c->keys_a.as<unsigned long long>(), c->vals_a.as<int>(), st);
     if (rc) return rc;
   }
+  c->mark(2, true, st);
+  c->mark(3, false, st);
   rc = gs::sort_and_ranges(c->keys_a.as<unsigned long long>(), c->keys_b.as<unsigned long long>(), c->vals_a.as<int>(),
                            c->sorted.as<int>(), S, num_tiles, c->temp.ptr, c->temp.bytes, c->ranges.as<int>(), st);
   if (rc) return rc;
+  c->mark(3, true, st);
+  c->mark(4, false, st);
   rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                              c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st);
   if (rc) return rc;
+  c->mark(4, true, st);
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
   c->have_forward = true;
   if (out) {
@@ -445,11 +485,15 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
   GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int M = c->M, W = c->width, H = c->height;
+  c->mark(5, false, st);
   GS_HIP(hipMemsetAsync(c->grad_rows.ptr, 0, (size_t)M * 64, st));
+  c->mark(5, true, st);
+  c->mark(6, false, st);
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st);
   if (rc) return rc;
+  c->mark(6, true, st);
   // cuda/trainer.cu:992-995
   const float fx = cam->focal_x, fy = cam->focal_y;
   const float fov_x = (float)(2.0 * atan((double)W / (2.0 * (double)fx)));
@@ -458,6 +502,7 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
   BwdOut bo = {out->grad_xyz, out->grad_rgb, out->grad_sh, out->grad_opacity, out->grad_scale, out->grad_quaternion,
                out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb};
   const dim3 grid(gs::div_up(M, kBlock)), block(kBlock);
+  c->mark(7, false, st);
 #define GS_BWD(LL)                                                                                                     \
   preprocess_bwd_kernel<LL><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),                     \
                                                     c->xyz_c.as<float>(), c->sigma.as<float>(), c->J.as<float>(),      \
@@ -472,7 +517,32 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
   }
 #undef GS_BWD
   GS_LAUNCH_CHECK();
+  c->mark(7, true, st);
   return GSPLAT_OK;
+}
+
+int gsplat_context_set_timing(gsplat_context *c, int enabled) {
+  GS_REQUIRE(c != nullptr, "null context");
+  if (enabled && !c->ev[0][0]) {
+    for (int a = 0; a < gsplat_context::kSlots; ++a)
+      for (int b = 0; b < 2 * gsplat_context::kStages; ++b) GS_HIP(hipEventCreate(&c->ev[a][b]));
+  }
+  GS_HIP(hipDeviceSynchronize());
+  for (int a = 0; a < gsplat_context::kSlots; ++a) c->harvest(a);
+  for (int k = 0; k < gsplat_context::kStages; ++k) { c->stage_ms[k] = 0; c->stage_n[k] = 0; }
+  c->timing = enabled != 0;
+  return GSPLAT_OK;
+}
+
+int gsplat_context_get_timing(gsplat_context *c, double *stage_ms_sum, long long *stage_count, int max_stages) {
+  GS_REQUIRE(c && stage_ms_sum && stage_count, "null argument");
+  GS_HIP(hipDeviceSynchronize());
+  for (int a = 0; a < gsplat_context::kSlots; ++a) c->harvest(a);
+  for (int k = 0; k < max_stages && k < gsplat_context::kStages; ++k) {
+    stage_ms_sum[k] = c->stage_ms[k];
+    stage_count[k] = c->stage_n[k];
+  }
+  return gsplat_context::kStages;
 }
 
 int gsplat_pack_gradients_global(gsplat_context *c, const gsplat_gradients *grads, int l_max, int num_gaussians,

@@ -74,6 +74,19 @@ class RasterContext:
     def workspace_bytes(self):
         return int(self._lib.gsplat_context_bytes(self._h))
 
+    STAGES = ("project_cull", "preprocess", "emit_keys", "sort_ranges", "render_forward", "zero_grad_rows",
+              "render_backward", "preprocess_backward")
+
+    def set_timing(self, enabled):
+        check(self._lib.gsplat_context_set_timing(self._h, int(bool(enabled))))
+
+    def get_timing(self):
+        """{stage: (mean ms per launch, launches)} since timing was enabled (HIP events on the launch stream)."""
+        ms = (ctypes.c_double * 8)()
+        cnt = (ctypes.c_longlong * 8)()
+        self._lib.gsplat_context_get_timing(self._h, ms, cnt, 8)
+        return {s: ((ms[i] / cnt[i]) if cnt[i] else 0.0, int(cnt[i])) for i, s in enumerate(self.STAGES)}
+
     @staticmethod
     def _structs(params, cam, l_max):
         g = _lib.Gaussians()

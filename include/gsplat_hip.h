@@ -224,6 +224,14 @@ int gsplat_backward_pass(gsplat_context *ctx, const gsplat_gaussians *gaussians,
                          const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
                          void *stream);
 
+/* Measurement hook: when enabled, every stage of the two fused passes is bracketed by HIP events on the
+ * caller's stream.  Stage ids: 0 project+cull+scan, 1 preprocess+scan, 2 key emit, 3 radix sort+ranges,
+ * 4 compositing forward, 5 gradient-row memset, 6 compositing backward, 7 per-gaussian backward.
+ * gsplat_context_get_timing synchronises the device, writes the per-stage sum of milliseconds and the number
+ * of samples since timing was (re)enabled, and returns the number of stages. */
+int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
+int gsplat_context_get_timing(gsplat_context *ctx, double *stage_ms_sum, long long *stage_count, int max_stages);
+
 /* View-sharded training support: scatter compacted per-view gradients into one global-order
  * row-major buffer packed[N, 12 + 3*n_coeffs] = [xyz3 | band0 3 | sh 3(n_coeffs-1) | opacity1 | scale3 | quat4 |
  * visible1], zero where culled, ready for one RCCL all-reduce. */
