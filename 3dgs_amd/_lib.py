@@ -110,6 +110,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
+    # torch owns device memory and ships its own HIP runtime: import it first so that this library binds to the
+    # same runtime instance (two runtimes in one process do not see each other's allocations)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync

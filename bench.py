@@ -122,7 +122,7 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
         reps_cpu = 2
         t2 = time.perf_counter()
         for _ in range(reps_cpu):
