@@ -127,6 +127,7 @@ struct PreOut {
   float *xyz_c, *uv, *sigma, *conic, *J, *rgb, *radius;
   float4 *recs;
   int *counts;
+  unsigned long long *pairs;  // 64 spread counters of coarse candidate pairs (reporting only)
 };
 
 // ---- B: everything per kept gaussian, written at its compacted slot
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
                                                             float cy, float cz, int ntx, int nty, PreOut o) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int N = g.num_gaussians;
-  if (i >= N || !mask[i]) return;
+  unsigned long long coarse = 0;
+  if (i < N && mask[i]) {
   const int j = rank[i];
   constexpr int n = (L + 1) * (L + 1);
   const gs::Mat34 vw = gs::load_view(view);
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
   int hits = 0;
   const gs::TileRect r = gs::coarse_rect(u, v, rad[0], ntx, nty);
   if (r.x1 > r.x0 && r.y1 > r.y0) {
+    coarse = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
     const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
     for (int tx = r.x0; tx < r.x1; ++tx)
       for (int ty = r.y0; ty < r.y1; ++ty) hits += gs::obb_hits_tile(ob, tx, ty) ? 1 : 0;
@@ -177,22 +180,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
   reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
   const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
   o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
-}
-
-// coarse candidate count, reported for parity with call 1 of get_sorted_gaussian_list
-__global__ __launch_bounds__(kBlock) void coarse_pairs_kernel(const float *__restrict__ uv,
-                                                              const float *__restrict__ radius, int ntx, int nty,
-                                                              const int *__restrict__ pM,
-                                                              unsigned long long *__restrict__ total) {
-  const int j = blockIdx.x * kBlock + threadIdx.x;
-  unsigned long long mine = 0;
-  if (j < *pM) {
-    const gs::TileRect r = gs::coarse_rect(uv[2 * j], uv[2 * j + 1], radius[4 * j], ntx, nty);
-    mine = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
   }
+  // candidate-pair count (what call 1 of get_sorted_gaussian_list reports): one atomic per wave, spread over 64
+  // counters so that no single address serialises the chip
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+  for (int off = 32; off > 0; off >>= 1) coarse += __shfl_down(coarse, off, 64);
+  if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(&o.pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], coarse);
 }
 
 struct BwdOut {
@@ -326,7 +319,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   const size_t T = (size_t)((max_width + 15) / 16) * ((max_height + 15) / 16);
   int rc = GSPLAT_OK;
   auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
-  R(c->mask, N + 16); R(c->flags, (N + 1) * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
+  R(c->mask, N + 16); R(c->flags, (N + 1) * 4 + 512); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64);
@@ -338,7 +331,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
     rc = c->temp.reserve(sb1 > sb2 ? sb1 : sb2);
   }
   if (!rc) rc = reserve_instances(c, 4 * N, (int)T);
-  if (!rc && hipHostMalloc((void **)&c->h_words, 64, hipHostMallocDefault) != hipSuccess) {
+  if (!rc && hipHostMalloc((void **)&c->h_words, 1024, hipHostMallocDefault) != hipSuccess) {
     gs::set_error("gsplat_context_create: hipHostMalloc failed");
     rc = GSPLAT_ERR_HIP;
   }
@@ -396,8 +389,10 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->mark(0, true, st);
   c->mark(1, false, st);
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
-               c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>()};
+               c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
+               reinterpret_cast<unsigned long long *>(c->flags.ptr)};  // flags are dead after the scan
   GS_HIP(hipMemsetAsync(c->counts.ptr, 0, (size_t)(N + 1) * sizeof(int), st));
+  GS_HIP(hipMemsetAsync(c->flags.ptr, 0, 64 * sizeof(unsigned long long), st));
 #define GS_PRE(LL)                                                                                                     \
   preprocess_kernel<LL><<<gridN, block, 0, st>>>(*g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(),        \
                                                  c->xyz_c_all.as<float>(), c->uv_all.as<float>(), fx, fy, tan_fovx,    \
@@ -414,22 +409,20 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   scan_bytes = c->temp.bytes;
   GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->counts.as<int>(), c->offsets.as<int>(), 0, (size_t)N + 1,
                                  rocprim::plus<int>(), st));
-  // coarse candidate count (reporting only)
-  unsigned long long *d_pairs = reinterpret_cast<unsigned long long *>(c->flags.ptr);  // flags are dead after the scan
-  GS_HIP(hipMemsetAsync(d_pairs, 0, sizeof(unsigned long long), st));
-  coarse_pairs_kernel<<<gs::div_up(N, kBlock), block, 0, st>>>(c->uv.as<float>(), c->radius.as<float>(), ntx, nty,
-                                                              c->rank.as<int>() + N, d_pairs);
-  GS_LAUNCH_CHECK();
   c->mark(1, true, st);
   // the one host read-back of the forward: M, S (and the candidate count)
   GS_HIP(hipMemcpyAsync(&c->h_words[0], c->rank.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(&c->h_words[1], c->offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(&c->h_words[2], d_pairs, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&c->h_words[2], c->flags.ptr, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   const int M = c->h_words[0];
   const size_t S = (size_t)c->h_words[1];
-  unsigned long long pairs;
-  memcpy(&pairs, &c->h_words[2], sizeof(pairs));
+  unsigned long long pairs = 0;
+  for (int k = 0; k < 64; ++k) {
+    unsigned long long part;
+    memcpy(&part, &c->h_words[2 + 2 * k], sizeof(part));
+    pairs += part;
+  }
   if (M == 0) {
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;

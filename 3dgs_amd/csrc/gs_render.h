@@ -72,21 +72,48 @@ __device__ __forceinline__ float gauss_power(float a, float b, float c, float dx
   return __builtin_fmaf(-bx, dy, -0.5f * t);
 }
 
-// ---- wave64 sum on DPP: 6 dependent v_add_f32 with DPP operands, result valid in lane 63
-template <int kCtrl, int kRowMask>
+// ---- wave64 reduction of NINE values at once.
+// A plain butterfly costs 6 DPP adds per value (54).  Here the values are folded pairwise while the lane groups
+// halve: v_permlane32_swap exchanges the upper half of one register with the lower half of another, so ONE swap +
+// ONE add turns two registers into one that holds the half-wave sums of both values (gfx950 only); the same with
+// v_permlane16_swap across 16-lane rows; the last four steps stay inside a row on DPP.  28 VALU instead of 54.
+// Result: in a lane of row r (= lane >> 4), q0 holds the total of value {0,2,1,3}[r], q1 of value {4,6,5,7}[r],
+// and q2 (row 0 only) of value 8.
+typedef unsigned int gs_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fold32(float a, float b) {
+  const gs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+  const gs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int kCtrl>
 __device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xF, false);
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false);
   return v + __int_as_float(moved);
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);  // row_mirror        -> every lane holds its 16-lane row sum
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> lanes 48..63 hold the total
+__device__ __forceinline__ float row_sum(float v) {  // every lane of a 16-lane row ends with the row total
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
   return v;
 }
+struct Sum9 { float q0, q1, q2; };
+__device__ __forceinline__ Sum9 wave_sum9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                          float v7, float v8) {
+  const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7);
+  const float r4 = fold32(v8, 0.0f);
+  Sum9 s;
+  s.q0 = row_sum(fold16(r0, r1));
+  s.q1 = row_sum(fold16(r2, r3));
+  s.q2 = row_sum(fold16(r4, 0.0f));
+  return s;
+}
+// which of the nine values a lane's q0 / q1 holds
+__device__ __forceinline__ int sum9_index_q0(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }
+__device__ __forceinline__ int sum9_index_q1(int lane) { return 4 + ((lane >> 4) & 1) * 2 + (lane >> 5); }
 __device__ __forceinline__ int wave_max_int(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));

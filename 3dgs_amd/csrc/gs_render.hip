@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
     g0 = grad_image[3 * pid]; g1 = grad_image[3 * pid + 1]; g2 = grad_image[3 * pid + 2];
   }
   float T = Tf, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;  // running transmittance, colour behind the current splat
-  const float bgdot = bg * g0 + bg * g1 + bg * g2;
+  const float tfb = Tf * (bg * g0 + bg * g1 + bg * g2);  // T_final * (background . grad)
   const int wave_top = wave_max_int(n);
   if (tid == 0) s_top = 0;
   __syncthreads();
@@ -162,6 +162,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
   __syncthreads();
   const int top = s_top;  // cuda/render_backward.cu:64,74: start at (max n over the tile) - 1
   if (top <= 0) return;
+  // where this lane's share of the nine wave totals goes (see wave_sum9)
+  const bool row_leader = (lane & 15) == 0;
+  const int acc_q0 = sum9_index_q0(lane) * kBatch, acc_q1 = sum9_index_q1(lane) * kBatch;
 
   for (int base = ((top - 1) / kBatch) * kBatch; base >= 0; base -= kBatch) {
     const int count = min(kBatch, top - base);
@@ -197,48 +200,55 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         alpha = valid ? alpha : 0.0f;
         gg = valid ? gg : 0.0f;
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
-        T *= inv;
+        T *= inv;                                           // transmittance in front of this splat
         const float aT = alpha * T;
-        float v0 = aT * g0, v1 = aT * g1, v2 = aT * g2;  // d/d rgb
-        float ga = (c.x - c0) * g0 + (c.y - c1) * g1 + (c.z - c2) * g2;
-        ga = ga * T - Tf * inv * bgdot;                  // d/d alpha
-        float v3 = gg * ga * opa * (1.0f - opa);          // d/d logit (cuda/render_backward.cu:154)
-        const float om = 1.0f - alpha;
-        c0 = __builtin_fmaf(alpha, c.x, om * c0);
-        c1 = __builtin_fmaf(alpha, c.y, om * c1);
-        c2 = __builtin_fmaf(alpha, c.z, om * c2);
-        const float gp = gg * (ga * opa);                 // d/d power
-        float v4 = gp * (-0.5f * dx * dx);                // conic00
-        float v5 = gp * (-dx * dy);                       // conic01
-        float v6 = gp * (-0.5f * dy * dy);                // conic11
-        float v7 = gp * (-(a.z * dx + a.w * dy));         // u
-        float v8 = gp * (-(b.x * dy + a.w * dx));         // v
-        if (!__any(v3 != 0.0f)) continue;                 // cuda/render_backward.cu:170
-        v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
-        v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
-        v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
-        if (lane == 63) {
-          atomicAdd(&s_acc[0 * kBatch + slot], v0);
-          atomicAdd(&s_acc[1 * kBatch + slot], v1);
-          atomicAdd(&s_acc[2 * kBatch + slot], v2);
-          atomicAdd(&s_acc[3 * kBatch + slot], v3);
-          atomicAdd(&s_acc[4 * kBatch + slot], v4);
-          atomicAdd(&s_acc[5 * kBatch + slot], v5);
-          atomicAdd(&s_acc[6 * kBatch + slot], v6);
-          atomicAdd(&s_acc[7 * kBatch + slot], v7 * (0.5f * (float)width));   // cuda/render_backward.cu:186
-          atomicAdd(&s_acc[8 * kBatch + slot], v8 * (0.5f * (float)height));  // :187
+        const float v0 = aT * g0, v1 = aT * g1, v2 = aT * g2;  // d/d rgb
+        const float d0 = c.x - c0, d1 = c.y - c1, d2 = c.z - c2;
+        float ga = __builtin_fmaf(d0, g0, __builtin_fmaf(d1, g1, d2 * g2));
+        ga = __builtin_fmaf(ga, T, -(tfb * inv));           // d/d alpha (cuda/render_backward.cu:139-151)
+        c0 = __builtin_fmaf(alpha, d0, c0);                 // colour behind the next (nearer) splat
+        c1 = __builtin_fmaf(alpha, d1, c1);
+        c2 = __builtin_fmaf(alpha, d2, c2);
+        const float gp = gg * (ga * opa);                   // d/d power
+        // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa)
+        if (opa == 1.0f || !__any(gp != 0.0f)) continue;
+        const float gpx = gp * dx, gpy = gp * dy;
+        // nine raw sums; signs, the -1/2 factors, (1 - opa) and the 0.5*W / 0.5*H are applied once per gaussian
+        // at flush time:  S0 = sum gp, Sx, Sy, Sxx, Sxy, Syy
+        const Sum9 r = wave_sum9(v0, v1, v2, gp, gpx, gpy, gpx * dx, gpx * dy, gpy * dy);
+        if (row_leader) {
+          atomicAdd(&s_acc[acc_q0 + slot], r.q0);
+          atomicAdd(&s_acc[acc_q1 + slot], r.q1);
+          if (lane == 0) atomicAdd(&s_acc[8 * kBatch + slot], r.q2);
         }
       }
     }
     __syncthreads();
-    // flush: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows
+    // flush: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows.
+    // s_acc rows: 0..2 rgb, 3 S0, 4 Sx, 5 Sy, 6 Sxx, 7 Sxy, 8 Syy
     const int k = tid & 15;
     if (k < 9) {
 #pragma unroll 4
       for (int r = 0; r < 16; ++r) {
         const int slot = r * 16 + (tid >> 4);
         if (slot >= count) continue;
-        const float val = s_acc[k * kBatch + slot];
+        float val;
+        if (k < 3) {
+          val = s_acc[k * kBatch + slot];
+        } else if (k == 3) {
+          val = s_acc[3 * kBatch + slot] * (1.0f - s_r1[slot].y);              // d/d logit (render_backward.cu:154)
+        } else if (k == 4) {
+          val = -0.5f * s_acc[6 * kBatch + slot];                               // conic00
+        } else if (k == 5) {
+          val = -s_acc[7 * kBatch + slot];                                      // conic01
+        } else if (k == 6) {
+          val = -0.5f * s_acc[8 * kBatch + slot];                               // conic11
+        } else {
+          const float sx = s_acc[4 * kBatch + slot], sy = s_acc[5 * kBatch + slot];
+          const float4 a = s_r0[slot];
+          val = (k == 7) ? -(a.z * sx + a.w * sy) * (0.5f * (float)width)       // u (render_backward.cu:180-186)
+                         : -(s_r1[slot].x * sy + a.w * sx) * (0.5f * (float)height);  // v (:181-187)
+        }
         if (val == 0.0f) continue;
         const int g = s_id[slot];
         if constexpr (kRows) {
