@@ -125,6 +125,130 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
   return GSPLAT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-level ordering (used by the fused path and by gsplat_get_sorted_gaussian_list):
+//   1. sort the GAUSSIANS once by depth (32-bit keys, N entries, culled ones pushed to the end);
+//   2. emit every gaussian's (tile, id) instances in that depth order;
+//   3. one STABLE radix sort of the instances over the tile bits only (ceil(log2 T) bits).
+// Same final order as sorting (tile << 32 | depth) keys of all S instances -- ties still fall back to the
+// gaussian id because both sorts are stable -- but the wide sort runs over N 32-bit keys instead of S 64-bit
+// keys and the S-sized sort needs 2 digit passes instead of 6.
+struct DepthOrderFn {  // counts in depth order, as a scan input
+  const int *perm, *rank, *counts;
+  const unsigned char *mask;
+  int N;
+  __device__ int operator()(int k) const {
+    if (k >= N) return 0;
+    const int i = perm[k];
+    if (mask && !mask[i]) return 0;
+    return counts[rank ? rank[i] : i];
+  }
+};
+
+__global__ __launch_bounds__(kBlock) void depth_keys_kernel(const float *__restrict__ xyz_c, int N,
+                                                            const unsigned char *__restrict__ mask,
+                                                            unsigned int *__restrict__ keys, int *__restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  keys[i] = (!mask || mask[i]) ? float_sort_bits(xyz_c[3 * i + 2]) : 0xFFFFFFFFu;
+  vals[i] = i;
+}
+
+__global__ __launch_bounds__(kBlock) void tile_emit_ordered_kernel(const float *__restrict__ uv,
+                                                                   const float *__restrict__ radius, int ntx, int nty,
+                                                                   int N, const int *__restrict__ perm,
+                                                                   const unsigned char *__restrict__ mask,
+                                                                   const int *__restrict__ rank,
+                                                                   const int *__restrict__ offsets,
+                                                                   unsigned int *__restrict__ keys,
+                                                                   int *__restrict__ vals) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= N) return;
+  int w = offsets[k];
+  const int end = offsets[k + 1];
+  if (w == end) return;
+  const int i = perm[k];
+  const int j = rank ? rank[i] : i;
+  const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
+  const float u = uv[2 * j], v = uv[2 * j + 1];
+  const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
+  const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
+  for (int tx = r.x0; tx < r.x1; ++tx)
+    for (int ty = r.y0; ty < r.y1; ++ty)
+      if (obb_hits_tile(o, tx, ty) && w < end) {
+        keys[w] = (unsigned int)(ty * ntx + tx);
+        vals[w] = j;
+        ++w;
+      }
+}
+
+__global__ __launch_bounds__(kBlock) void tile_ranges32_kernel(const unsigned int *__restrict__ keys, int S,
+                                                               int num_tiles, int *__restrict__ ranges) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= S) return;
+  const int cur = min((int)keys[s], num_tiles - 1);
+  const int prev = s > 0 ? min((int)keys[s - 1], num_tiles - 1) : -1;
+  for (int t = prev + 1; t <= cur; ++t) ranges[t] = s;
+  if (s == S - 1)
+    for (int t = cur + 1; t <= num_tiles; ++t) ranges[t] = S;
+}
+
+static int tile_bits(int num_tiles) {
+  int b = 1;
+  while ((1LL << b) < (long long)num_tiles) ++b;
+  return b;
+}
+
+size_t binning_temp_bytes(size_t N, size_t S, int num_tiles) {
+  size_t a = 0, b = 0, c = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr,
+                                  (int *)nullptr, N ? N : 1, 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, b, (unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr,
+                                  (int *)nullptr, S ? S : 1, 0, tile_bits(num_tiles), (hipStream_t)0);
+  DepthOrderFn fn{nullptr, nullptr, nullptr, nullptr, 0};
+  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
+  (void)rocprim::exclusive_scan(nullptr, c, in, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
+  size_t m = a > b ? a : b;
+  return (m > c ? m : c) + 256;
+}
+
+// perm[0..N) <- gaussian indices by ascending depth (culled last).  xyz_c/mask are indexed by the gaussian's own
+// index i (not by its compacted slot).
+int depth_order(const float *xyz_c, int N, const unsigned char *mask, unsigned int *dkeys_a, unsigned int *dkeys_b,
+                int *dvals_a, int *perm, void *temp, size_t temp_bytes, hipStream_t st) {
+  depth_keys_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(xyz_c, N, mask, dkeys_a, dvals_a);
+  GS_LAUNCH_CHECK();
+  GS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, dkeys_a, dkeys_b, dvals_a, perm, (size_t)N, 0, 32, st));
+  return GSPLAT_OK;
+}
+
+// offsets[0..N] <- exclusive scan of the per-gaussian tile counts taken in depth order
+int scan_counts_in_depth_order(int N, const int *perm, const unsigned char *mask, const int *rank, const int *counts,
+                               int *offsets, void *temp, size_t temp_bytes, hipStream_t st) {
+  DepthOrderFn fn{perm, rank, counts, mask, N};
+  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
+  GS_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0, (size_t)N + 1, rocprim::plus<int>(), st));
+  return GSPLAT_OK;
+}
+
+int emit_sort_ranges(const float *uv, const float *radius, int ntx, int nty, int N, const int *perm,
+                     const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
+                     unsigned int *tkeys_b, int *tvals_a, int *sorted_out, int *ranges, void *temp, size_t temp_bytes,
+                     hipStream_t st) {
+  const int num_tiles = ntx * nty;
+  if (S == 0) {
+    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)(num_tiles + 1) * sizeof(int), st));
+    return GSPLAT_OK;
+  }
+  tile_emit_ordered_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, ntx, nty, N, perm, mask, rank, offsets,
+                                                                tkeys_a, tvals_a);
+  GS_LAUNCH_CHECK();
+  GS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, tkeys_a, tkeys_b, tvals_a, sorted_out, S, 0, tile_bits(num_tiles), st));
+  tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_b, (int)S, num_tiles, ranges);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
 static int key_bits(int num_tiles) {
   int b = 0;
   while ((1LL << b) < (long long)num_tiles) ++b;
@@ -192,18 +316,21 @@ extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz
     return GSPLAT_OK;
   }
   DeviceBuffer &counts = scratch(SCR_COUNTS), &offsets = scratch(SCR_OFFSETS), &tmp = scratch(SCR_TEMP);
+  DeviceBuffer &ka = scratch(SCR_KEYS_A), &kb = scratch(SCR_KEYS_B), &vb = scratch(SCR_VALS_B), &pm = scratch(SCR_SPLATS);
   if ((rc = counts.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
   if ((rc = offsets.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
-  GS_HIP(hipMemsetAsync(counts.as<int>() + N, 0, sizeof(int), st));
+  if ((rc = pm.reserve((size_t)N * sizeof(int)))) return rc;
+  if ((rc = ka.reserve((size_t)(N + 1) * sizeof(unsigned int)))) return rc;
+  if ((rc = kb.reserve((size_t)(N + 1) * sizeof(unsigned int)))) return rc;
+  if ((rc = vb.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
+  if ((rc = tmp.reserve(binning_temp_bytes((size_t)N, 1, num_tiles)))) return rc;
   tile_count_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr,
                                                          counts.as<int>(), nullptr);
   GS_LAUNCH_CHECK();
-  size_t scan_bytes = 0;
-  GS_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, counts.as<int>(), offsets.as<int>(), 0, (size_t)N + 1,
-                                 rocprim::plus<int>(), st));
-  if ((rc = tmp.reserve(scan_bytes))) return rc;
-  GS_HIP(rocprim::exclusive_scan(tmp.ptr, scan_bytes, counts.as<int>(), offsets.as<int>(), 0, (size_t)N + 1,
-                                 rocprim::plus<int>(), st));
+  if ((rc = depth_order(xyz, N, nullptr, ka.as<unsigned int>(), kb.as<unsigned int>(), vb.as<int>(), pm.as<int>(),
+                        tmp.ptr, tmp.bytes, st))) return rc;
+  if ((rc = scan_counts_in_depth_order(N, pm.as<int>(), nullptr, nullptr, counts.as<int>(), offsets.as<int>(), tmp.ptr,
+                                       tmp.bytes, st))) return rc;
   GS_HIP(hipMemcpyAsync(host_words().p, offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   const size_t S = (size_t)host_words().p[0];
@@ -211,20 +338,13 @@ extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz
     set_error("%s: %zu instances do not fit the caller's buffer of %zu", __func__, S, *sorted_gaussian_count);
     return GSPLAT_ERR_CAPACITY;
   }
-  DeviceBuffer &ka = scratch(SCR_KEYS_A), &kb = scratch(SCR_KEYS_B), &vb = scratch(SCR_VALS_B);
-  if ((rc = ka.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
-  if ((rc = kb.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = ka.reserve((S + 1) * sizeof(unsigned int)))) return rc;
+  if ((rc = kb.reserve((S + 1) * sizeof(unsigned int)))) return rc;
   if ((rc = vb.reserve((S + 1) * sizeof(int)))) return rc;
-  const size_t sort_bytes = S ? sort_temp_bytes(S, num_tiles) : 0;
-  if ((rc = tmp.reserve(sort_bytes > scan_bytes ? sort_bytes : scan_bytes))) return rc;
-  if (S) {
-    tile_emit_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr,
-                                                          offsets.as<int>(), ka.as<unsigned long long>(),
-                                                          vb.as<int>());
-    GS_LAUNCH_CHECK();
-  }
-  rc = sort_and_ranges(ka.as<unsigned long long>(), kb.as<unsigned long long>(), vb.as<int>(), sorted_gaussians, S,
-                       num_tiles, tmp.ptr, sort_bytes, splat_start_end_idx_by_tile_idx, st);
+  if ((rc = tmp.reserve(binning_temp_bytes((size_t)N, S, num_tiles)))) return rc;
+  rc = emit_sort_ranges(uv, radius, n_tiles_x, n_tiles_y, N, pm.as<int>(), nullptr, nullptr, offsets.as<int>(), S,
+                        ka.as<unsigned int>(), kb.as<unsigned int>(), vb.as<int>(), sorted_gaussians,
+                        splat_start_end_idx_by_tile_idx, tmp.ptr, tmp.bytes, st);
   if (rc) return rc;
   // the reference returns only after its blocking read-backs; keep that contract
   GS_HIP(hipStreamSynchronize(st));

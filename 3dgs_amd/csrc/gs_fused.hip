@@ -21,12 +21,15 @@
 
 namespace gs {
 // from gs_binning.hip / gs_render.hip
-int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
-                     const unsigned char *mask, const int *rank, const int *offsets, unsigned long long *keys,
-                     int *vals, hipStream_t st);
-size_t sort_temp_bytes(size_t S, int num_tiles);
-int sort_and_ranges(unsigned long long *keys_a, unsigned long long *keys_b, int *vals_a, int *sorted_out, size_t S,
-                    int num_tiles, void *temp, size_t temp_bytes, int *ranges, hipStream_t st);
+size_t binning_temp_bytes(size_t N, size_t S, int num_tiles);
+int depth_order(const float *xyz_c, int N, const unsigned char *mask, unsigned int *dkeys_a, unsigned int *dkeys_b,
+                int *dvals_a, int *perm, void *temp, size_t temp_bytes, hipStream_t st);
+int scan_counts_in_depth_order(int N, const int *perm, const unsigned char *mask, const int *rank, const int *counts,
+                               int *offsets, void *temp, size_t temp_bytes, hipStream_t st);
+int emit_sort_ranges(const float *uv, const float *radius, int ntx, int nty, int N, const int *perm,
+                     const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
+                     unsigned int *tkeys_b, int *tvals_a, int *sorted_out, int *ranges, void *temp, size_t temp_bytes,
+                     hipStream_t st);
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st);
@@ -42,7 +45,7 @@ struct gsplat_context {
   // per-gaussian, compacted order
   gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows;
   // instances
-  gs::DeviceBuffer keys_a, keys_b, vals_a, sorted, temp;
+  gs::DeviceBuffer keys_a, keys_b, vals_a, sorted, temp, perm, dkeys_a, dkeys_b, dvals_a;
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
@@ -75,7 +78,7 @@ struct gsplat_context {
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &vals_a,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px};
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &perm, &dkeys_a, &dkeys_b, &dvals_a};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -83,7 +86,7 @@ struct gsplat_context {
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &vals_a,
-                               &sorted, &temp, &ranges, &image, &T_px, &n_px};
+                               &sorted, &temp, &ranges, &image, &T_px, &n_px, &perm, &dkeys_a, &dkeys_b, &dvals_a};
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
@@ -294,12 +297,11 @@ __global__ __launch_bounds__(kBlock) void pack_global_kernel(const unsigned char
 
 int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   int rc;
-  if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
-  if ((rc = c->keys_b.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned int)))) return rc;
+  if ((rc = c->keys_b.reserve((S + 1) * sizeof(unsigned int)))) return rc;
   if ((rc = c->vals_a.reserve((S + 1) * sizeof(int)))) return rc;
   if ((rc = c->sorted.reserve((S + 1) * sizeof(int)))) return rc;
-  const size_t sb = gs::sort_temp_bytes(S ? S : 1, num_tiles);
-  if ((rc = c->temp.reserve(sb))) return rc;
+  if ((rc = c->temp.reserve(gs::binning_temp_bytes((size_t)c->max_gaussians, S ? S : 1, num_tiles)))) return rc;
   return GSPLAT_OK;
 }
 
@@ -323,11 +325,12 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64);
+  R(c->perm, N * 4); R(c->dkeys_a, N * 4); R(c->dkeys_b, N * 4); R(c->dvals_a, N * 4);
   R(c->ranges, (T + 1) * 4); R(c->image, P * 12); R(c->T_px, P * 4); R(c->n_px, P * 4);
   if (!rc) {
-    size_t sb1 = 0, sb2 = 0;
+    size_t sb1 = 0;
     (void)rocprim::exclusive_scan(nullptr, sb1, (int *)nullptr, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
-    sb2 = sb1;
+    const size_t sb2 = gs::binning_temp_bytes(N, 4 * N, (int)T);
     rc = c->temp.reserve(sb1 > sb2 ? sb1 : sb2);
   }
   if (!rc) rc = reserve_instances(c, 4 * N, (int)T);
@@ -386,6 +389,10 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   size_t scan_bytes = c->temp.bytes;
   GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->flags.as<int>(), c->rank.as<int>(), 0, (size_t)N + 1,
                                  rocprim::plus<int>(), st));
+  int rc = gs::depth_order(c->xyz_c_all.as<float>(), N, c->mask.as<unsigned char>(), c->dkeys_a.as<unsigned int>(),
+                           c->dkeys_b.as<unsigned int>(), c->dvals_a.as<int>(), c->perm.as<int>(), c->temp.ptr,
+                           c->temp.bytes, st);
+  if (rc) return rc;
   c->mark(0, true, st);
   c->mark(1, false, st);
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
@@ -406,9 +413,9 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   }
 #undef GS_PRE
   GS_LAUNCH_CHECK();
-  scan_bytes = c->temp.bytes;
-  GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->counts.as<int>(), c->offsets.as<int>(), 0, (size_t)N + 1,
-                                 rocprim::plus<int>(), st));
+  rc = gs::scan_counts_in_depth_order(N, c->perm.as<int>(), c->mask.as<unsigned char>(), c->rank.as<int>(),
+                                      c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
+  if (rc) return rc;
   c->mark(1, true, st);
   // the one host read-back of the forward: M, S (and the candidate count)
   GS_HIP(hipMemcpyAsync(&c->h_words[0], c->rank.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -427,21 +434,15 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;
   }
-  int rc = reserve_instances(c, S, num_tiles);
+  rc = reserve_instances(c, S, num_tiles);
   if (rc) return rc;
   c->mark(2, false, st);
-  if (S) {
-    rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
-                              c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
-                              c->keys_a.as<unsigned long long>(), c->vals_a.as<int>(), st);
-    if (rc) return rc;
-  }
-  c->mark(2, true, st);
-  c->mark(3, false, st);
-  rc = gs::sort_and_ranges(c->keys_a.as<unsigned long long>(), c->keys_b.as<unsigned long long>(), c->vals_a.as<int>(),
-                           c->sorted.as<int>(), S, num_tiles, c->temp.ptr, c->temp.bytes, c->ranges.as<int>(), st);
+  rc = gs::emit_sort_ranges(c->uv.as<float>(), c->radius.as<float>(), ntx, nty, N, c->perm.as<int>(),
+                            c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
+                            c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(), c->vals_a.as<int>(),
+                            c->sorted.as<int>(), c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st);
   if (rc) return rc;
-  c->mark(3, true, st);
+  c->mark(2, true, st);
   c->mark(4, false, st);
   rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                              c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st);
