@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kBlock) void tile_ranges32_kernel(const unsigned in
     for (int t = cur + 1; t <= num_tiles; ++t) ranges[t] = S;
 }
 
+// rocPRIM switches to a merge sort below 2^20 items (~0.14 ms for 1e6 depth keys); Onesweep needs 4 digit passes
+using OnesweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 8192>;
+
 static int tile_bits(int num_tiles) {
   int b = 1;
   while ((1LL << b) < (long long)num_tiles) ++b;
@@ -201,10 +205,11 @@ static int tile_bits(int num_tiles) {
 
 size_t binning_temp_bytes(size_t N, size_t S, int num_tiles) {
   size_t a = 0, b = 0, c = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, a, (unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr,
-                                  (int *)nullptr, N ? N : 1, 0, 32, (hipStream_t)0);
-  (void)rocprim::radix_sort_pairs(nullptr, b, (unsigned int *)nullptr, (unsigned int *)nullptr, (int *)nullptr,
-                                  (int *)nullptr, S ? S : 1, 0, tile_bits(num_tiles), (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, a, (unsigned int *)nullptr, (unsigned int *)nullptr,
+                                                  (int *)nullptr, (int *)nullptr, N ? N : 1, 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, b, (unsigned int *)nullptr, (unsigned int *)nullptr,
+                                                  (int *)nullptr, (int *)nullptr, S ? S : 1, 0, tile_bits(num_tiles),
+                                                  (hipStream_t)0);
   DepthOrderFn fn{nullptr, nullptr, nullptr, nullptr, 0};
   auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
   (void)rocprim::exclusive_scan(nullptr, c, in, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
@@ -218,7 +223,7 @@ int depth_order(const float *xyz_c, int N, const unsigned char *mask, unsigned i
                 int *dvals_a, int *perm, void *temp, size_t temp_bytes, hipStream_t st) {
   depth_keys_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(xyz_c, N, mask, dkeys_a, dvals_a);
   GS_LAUNCH_CHECK();
-  GS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, dkeys_a, dkeys_b, dvals_a, perm, (size_t)N, 0, 32, st));
+  GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, dkeys_a, dkeys_b, dvals_a, perm, (size_t)N, 0, 32, st));
   return GSPLAT_OK;
 }
 
@@ -243,7 +248,8 @@ int emit_sort_ranges(const float *uv, const float *radius, int ntx, int nty, int
   tile_emit_ordered_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, ntx, nty, N, perm, mask, rank, offsets,
                                                                 tkeys_a, tvals_a);
   GS_LAUNCH_CHECK();
-  GS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, tkeys_a, tkeys_b, tvals_a, sorted_out, S, 0, tile_bits(num_tiles), st));
+  GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, tkeys_a, tkeys_b, tvals_a, sorted_out, S, 0,
+                                                   tile_bits(num_tiles), st));
   tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_b, (int)S, num_tiles, ranges);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
