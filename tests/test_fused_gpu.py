@@ -182,3 +182,33 @@ def test_full_size_properties_and_parity(gpu, scene, orc):
     _check_forward(fwd, ref, exact_lists=False)
     bref = orc.backward_pass(ref, r["cam"], r["gi"], c["bg"], r["L"], threads=16)
     _check_backward(r["grads"], bref)
+
+
+def test_pack_gradients_global_layout(gpu, scene):
+    """Compacted per-view gradients -> global-order packed rows (the buffer the ranks all-reduce)."""
+    torch = gpu
+    raster, gdist = pkg("raster"), pkg("dist")
+    N, W, H, L = 2000, 128, 96, 2
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::3, 2] *= -1  # a third of the gaussians are culled
+    cam = scene.make_camera(W, H, 1)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    grads = ctx.alloc_gradients(fwd["num_culled"], L)
+    ctx.backward_pass(dp, dc, torch.as_tensor(scene.make_grad_image(W, H)).cuda(), c["bg"], L, grads)
+    width = raster.packed_gradient_width(L)
+    packed = torch.full((N, width), float("nan"), device="cuda")
+    ctx.pack_gradients_global(grads, L, N, packed)
+    p = _np(packed)
+    mask = _np(fwd["mask"]).astype(bool)
+    cols, w2 = gdist.packed_layout(L)
+    assert w2 == width
+    assert (p[~mask] == 0).all()
+    assert (p[mask, cols["visible"][0]] == 1).all()
+    for k in ("xyz", "rgb", "sh", "opacity", "scale", "quaternion"):
+        a, b = cols[k]
+        assert (p[mask, a:b] == _np(grads[k]).reshape(mask.sum(), b - a)).all(), k
+    un = gdist.unpack(packed, L)
+    assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3)
