@@ -127,57 +127,35 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
 
 // ------------------------------------------------------------------------------------------------
 // Two-level ordering (used by the fused path and by gsplat_get_sorted_gaussian_list):
-//   1. sort the GAUSSIANS once by depth (32-bit keys, N entries, culled ones pushed to the end);
-//   2. emit every gaussian's (tile, id) instances in that depth order;
-//   3. one STABLE radix sort of the instances over the tile bits only (ceil(log2 T) bits).
-// Same final order as sorting (tile << 32 | depth) keys of all S instances -- ties still fall back to the
-// gaussian id because both sorts are stable -- but the wide sort runs over N 32-bit keys instead of S 64-bit
-// keys and the S-sized sort needs 2 digit passes instead of 6.
-struct DepthOrderFn {  // counts in depth order, as a scan input
-  const int *perm, *rank, *counts;
-  const unsigned char *mask;
-  int N;
-  __device__ int operator()(int k) const {
-    if (k >= N) return 0;
-    const int i = perm[k];
-    if (mask && !mask[i]) return 0;
-    return counts[rank ? rank[i] : i];
-  }
-};
-
-__global__ __launch_bounds__(kBlock) void depth_keys_kernel(const float *__restrict__ xyz_c, int N,
-                                                            const unsigned char *__restrict__ mask,
-                                                            unsigned int *__restrict__ keys, int *__restrict__ vals) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  keys[i] = (!mask || mask[i]) ? float_sort_bits(xyz_c[3 * i + 2]) : 0xFFFFFFFFu;
-  vals[i] = i;
-}
-
-__global__ __launch_bounds__(kBlock) void tile_emit_ordered_kernel(const float *__restrict__ uv,
+//   1. every gaussian emits (tile id, payload = depth bits << 32 | gaussian id) for the tiles it is listed in;
+//   2. ONE rocPRIM radix sort over only the tile bits (ceil(log2 T) bits, 2 digit passes) groups them by tile;
+//   3. one workgroup per tile orders its group by payload with a bitonic sort in LDS and writes the ids.
+// Same final order as a global sort on (tile << 32 | depth) with ties broken by gaussian id (payloads are unique
+// inside a tile), but the wide 45-bit / 6-pass sort of all S instances is gone.
+__global__ __launch_bounds__(kBlock) void tile_emit_payload_kernel(const float *__restrict__ uv,
+                                                                   const float *__restrict__ xyz_c,
                                                                    const float *__restrict__ radius, int ntx, int nty,
-                                                                   int N, const int *__restrict__ perm,
-                                                                   const unsigned char *__restrict__ mask,
+                                                                   int N, const unsigned char *__restrict__ mask,
                                                                    const int *__restrict__ rank,
                                                                    const int *__restrict__ offsets,
                                                                    unsigned int *__restrict__ keys,
-                                                                   int *__restrict__ vals) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= N) return;
-  int w = offsets[k];
-  const int end = offsets[k + 1];
-  if (w == end) return;
-  const int i = perm[k];
+                                                                   unsigned long long *__restrict__ payload) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N || (mask && !mask[i])) return;
   const int j = rank ? rank[i] : i;
+  int w = offsets[j];
+  const int end = offsets[j + 1];
+  if (w == end) return;
   const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
   const float u = uv[2 * j], v = uv[2 * j + 1];
+  const unsigned long long pay = ((unsigned long long)float_sort_bits(xyz_c[3 * j + 2]) << 32) | (unsigned int)j;
   const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
   const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
   for (int tx = r.x0; tx < r.x1; ++tx)
     for (int ty = r.y0; ty < r.y1; ++ty)
       if (obb_hits_tile(o, tx, ty) && w < end) {
         keys[w] = (unsigned int)(ty * ntx + tx);
-        vals[w] = j;
+        payload[w] = pay;
         ++w;
       }
 }
@@ -193,9 +171,64 @@ __global__ __launch_bounds__(kBlock) void tile_ranges32_kernel(const unsigned in
     for (int t = cur + 1; t <= num_tiles; ++t) ranges[t] = S;
 }
 
-// rocPRIM switches to a merge sort below 2^20 items (~0.14 ms for 1e6 depth keys); Onesweep needs 4 digit passes
-using OnesweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                  rocprim::default_config, 8192>;
+// Depth order inside every tile: a NORMALISED bitonic network (every comparator puts the minimum at the lower
+// index, the first step of each merge pairs i with its mirror image), so virtual +infinity padding above `len`
+// never moves and comparators that touch it can simply be skipped: any list length works without padding stores.
+// Lists up to kLdsSort entries are sorted in LDS, longer ones in place in global memory by the same workgroup.
+constexpr int kLdsSort = 2048;
+
+template <typename Buf>
+__device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int tid) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    {  // mirror step
+      const int half = k >> 1;
+      for (int t = tid; t < (n2 >> 1); t += kBlock) {
+        const int base = (t / half) * k, il = t % half;
+        const int lo = base + il, hi = base + k - 1 - il;
+        if (hi < len) {
+          const unsigned long long a = p[lo], b = p[hi];
+          if (a > b) { p[lo] = b; p[hi] = a; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      for (int t = tid; t < (n2 >> 1); t += kBlock) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        if (hi < len) {
+          const unsigned long long a = p[lo], b = p[hi];
+          if (a > b) { p[lo] = b; p[hi] = a; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void tile_depth_sort_kernel(unsigned long long *__restrict__ payload,
+                                                                 const int *__restrict__ ranges, int num_tiles,
+                                                                 int *__restrict__ sorted) {
+  __shared__ unsigned long long buf[kLdsSort];
+  const int tile = blockIdx.x;
+  if (tile >= num_tiles) return;
+  const int start = ranges[tile], len = ranges[tile + 1] - start;
+  if (len <= 0) return;
+  const int tid = threadIdx.x;
+  int n2 = 1;
+  while (n2 < len) n2 <<= 1;
+  if (len <= kLdsSort) {
+    for (int i = tid; i < len; i += kBlock) buf[i] = payload[start + i];
+    __syncthreads();
+    bitonic_sort_block(buf, len, n2, tid);
+    for (int i = tid; i < len; i += kBlock) sorted[start + i] = (int)(unsigned int)(buf[i] & 0xFFFFFFFFull);
+  } else {
+    unsigned long long *p = payload + start;
+    bitonic_sort_block(p, len, n2, tid);
+    for (int i = tid; i < len; i += kBlock) sorted[start + i] = (int)(unsigned int)(p[i] & 0xFFFFFFFFull);
+  }
+}
 
 static int tile_bits(int num_tiles) {
   int b = 1;
@@ -203,54 +236,44 @@ static int tile_bits(int num_tiles) {
   return b;
 }
 
+// rocPRIM falls back to a merge sort below 2^20 items; Onesweep is faster for these key widths
+using OnesweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 8192>;
+
 size_t binning_temp_bytes(size_t N, size_t S, int num_tiles) {
-  size_t a = 0, b = 0, c = 0;
-  (void)rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, a, (unsigned int *)nullptr, (unsigned int *)nullptr,
-                                                  (int *)nullptr, (int *)nullptr, N ? N : 1, 0, 32, (hipStream_t)0);
+  size_t b = 0, c = 0;
   (void)rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, b, (unsigned int *)nullptr, (unsigned int *)nullptr,
-                                                  (int *)nullptr, (int *)nullptr, S ? S : 1, 0, tile_bits(num_tiles),
-                                                  (hipStream_t)0);
-  DepthOrderFn fn{nullptr, nullptr, nullptr, nullptr, 0};
-  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
-  (void)rocprim::exclusive_scan(nullptr, c, in, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
-  size_t m = a > b ? a : b;
-  return (m > c ? m : c) + 256;
+                                                  (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                                  S ? S : 1, 0, tile_bits(num_tiles), (hipStream_t)0);
+  (void)rocprim::exclusive_scan(nullptr, c, (int *)nullptr, (int *)nullptr, 0, N + 1, rocprim::plus<int>(),
+                                (hipStream_t)0);
+  return (b > c ? b : c) + 256;
 }
 
-// perm[0..N) <- gaussian indices by ascending depth (culled last).  xyz_c/mask are indexed by the gaussian's own
-// index i (not by its compacted slot).
-int depth_order(const float *xyz_c, int N, const unsigned char *mask, unsigned int *dkeys_a, unsigned int *dkeys_b,
-                int *dvals_a, int *perm, void *temp, size_t temp_bytes, hipStream_t st) {
-  depth_keys_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(xyz_c, N, mask, dkeys_a, dvals_a);
-  GS_LAUNCH_CHECK();
-  GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, dkeys_a, dkeys_b, dvals_a, perm, (size_t)N, 0, 32, st));
+// offsets[0..N] = exclusive scan of counts[0..N] (counts[N] must be 0)
+int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_bytes, hipStream_t st) {
+  GS_HIP(rocprim::exclusive_scan(temp, temp_bytes, counts, offsets, 0, (size_t)N + 1, rocprim::plus<int>(), st));
   return GSPLAT_OK;
 }
 
-// offsets[0..N] <- exclusive scan of the per-gaussian tile counts taken in depth order
-int scan_counts_in_depth_order(int N, const int *perm, const unsigned char *mask, const int *rank, const int *counts,
-                               int *offsets, void *temp, size_t temp_bytes, hipStream_t st) {
-  DepthOrderFn fn{perm, rank, counts, mask, N};
-  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
-  GS_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0, (size_t)N + 1, rocprim::plus<int>(), st));
-  return GSPLAT_OK;
-}
-
-int emit_sort_ranges(const float *uv, const float *radius, int ntx, int nty, int N, const int *perm,
+// emit -> sort by tile -> ranges -> per-tile depth sort.  pay_a/pay_b: S 64-bit payloads each.
+int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
-                     unsigned int *tkeys_b, int *tvals_a, int *sorted_out, int *ranges, void *temp, size_t temp_bytes,
-                     hipStream_t st) {
+                     unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
+                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st) {
   const int num_tiles = ntx * nty;
   if (S == 0) {
     GS_HIP(hipMemsetAsync(ranges, 0, (size_t)(num_tiles + 1) * sizeof(int), st));
     return GSPLAT_OK;
   }
-  tile_emit_ordered_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, ntx, nty, N, perm, mask, rank, offsets,
-                                                                tkeys_a, tvals_a);
+  tile_emit_payload_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets,
+                                                                tkeys_a, pay_a);
   GS_LAUNCH_CHECK();
-  GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, tkeys_a, tkeys_b, tvals_a, sorted_out, S, 0,
+  GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, tkeys_a, tkeys_b, pay_a, pay_b, S, 0,
                                                    tile_bits(num_tiles), st));
   tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_b, (int)S, num_tiles, ranges);
+  GS_LAUNCH_CHECK();
+  tile_depth_sort_kernel<<<num_tiles, kBlock, 0, st>>>(pay_b, ranges, num_tiles, sorted_out);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
@@ -322,21 +345,15 @@ extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz
     return GSPLAT_OK;
   }
   DeviceBuffer &counts = scratch(SCR_COUNTS), &offsets = scratch(SCR_OFFSETS), &tmp = scratch(SCR_TEMP);
-  DeviceBuffer &ka = scratch(SCR_KEYS_A), &kb = scratch(SCR_KEYS_B), &vb = scratch(SCR_VALS_B), &pm = scratch(SCR_SPLATS);
+  DeviceBuffer &ka = scratch(SCR_KEYS_A), &kb = scratch(SCR_KEYS_B), &pa = scratch(SCR_VALS_B), &pb = scratch(SCR_SPLATS);
   if ((rc = counts.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
   if ((rc = offsets.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
-  if ((rc = pm.reserve((size_t)N * sizeof(int)))) return rc;
-  if ((rc = ka.reserve((size_t)(N + 1) * sizeof(unsigned int)))) return rc;
-  if ((rc = kb.reserve((size_t)(N + 1) * sizeof(unsigned int)))) return rc;
-  if ((rc = vb.reserve((size_t)(N + 1) * sizeof(int)))) return rc;
   if ((rc = tmp.reserve(binning_temp_bytes((size_t)N, 1, num_tiles)))) return rc;
+  GS_HIP(hipMemsetAsync(counts.as<int>() + N, 0, sizeof(int), st));
   tile_count_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr,
                                                          counts.as<int>(), nullptr);
   GS_LAUNCH_CHECK();
-  if ((rc = depth_order(xyz, N, nullptr, ka.as<unsigned int>(), kb.as<unsigned int>(), vb.as<int>(), pm.as<int>(),
-                        tmp.ptr, tmp.bytes, st))) return rc;
-  if ((rc = scan_counts_in_depth_order(N, pm.as<int>(), nullptr, nullptr, counts.as<int>(), offsets.as<int>(), tmp.ptr,
-                                       tmp.bytes, st))) return rc;
+  if ((rc = scan_counts(N, counts.as<int>(), offsets.as<int>(), tmp.ptr, tmp.bytes, st))) return rc;
   GS_HIP(hipMemcpyAsync(host_words().p, offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   const size_t S = (size_t)host_words().p[0];
@@ -346,11 +363,13 @@ extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz
   }
   if ((rc = ka.reserve((S + 1) * sizeof(unsigned int)))) return rc;
   if ((rc = kb.reserve((S + 1) * sizeof(unsigned int)))) return rc;
-  if ((rc = vb.reserve((S + 1) * sizeof(int)))) return rc;
+  if ((rc = pa.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = pb.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
   if ((rc = tmp.reserve(binning_temp_bytes((size_t)N, S, num_tiles)))) return rc;
-  rc = emit_sort_ranges(uv, radius, n_tiles_x, n_tiles_y, N, pm.as<int>(), nullptr, nullptr, offsets.as<int>(), S,
-                        ka.as<unsigned int>(), kb.as<unsigned int>(), vb.as<int>(), sorted_gaussians,
-                        splat_start_end_idx_by_tile_idx, tmp.ptr, tmp.bytes, st);
+  rc = emit_sort_ranges(uv, xyz, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr, offsets.as<int>(), S,
+                        ka.as<unsigned int>(), kb.as<unsigned int>(), pa.as<unsigned long long>(),
+                        pb.as<unsigned long long>(), sorted_gaussians, splat_start_end_idx_by_tile_idx, tmp.ptr,
+                        tmp.bytes, st);
   if (rc) return rc;
   // the reference returns only after its blocking read-backs; keep that contract
   GS_HIP(hipStreamSynchronize(st));

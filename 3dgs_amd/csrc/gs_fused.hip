@@ -22,14 +22,11 @@
 namespace gs {
 // from gs_binning.hip / gs_render.hip
 size_t binning_temp_bytes(size_t N, size_t S, int num_tiles);
-int depth_order(const float *xyz_c, int N, const unsigned char *mask, unsigned int *dkeys_a, unsigned int *dkeys_b,
-                int *dvals_a, int *perm, void *temp, size_t temp_bytes, hipStream_t st);
-int scan_counts_in_depth_order(int N, const int *perm, const unsigned char *mask, const int *rank, const int *counts,
-                               int *offsets, void *temp, size_t temp_bytes, hipStream_t st);
-int emit_sort_ranges(const float *uv, const float *radius, int ntx, int nty, int N, const int *perm,
+int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_bytes, hipStream_t st);
+int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
-                     unsigned int *tkeys_b, int *tvals_a, int *sorted_out, int *ranges, void *temp, size_t temp_bytes,
-                     hipStream_t st);
+                     unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
+                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st);
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st);
@@ -45,7 +42,7 @@ struct gsplat_context {
   // per-gaussian, compacted order
   gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows;
   // instances
-  gs::DeviceBuffer keys_a, keys_b, vals_a, sorted, temp, perm, dkeys_a, dkeys_b, dvals_a;
+  gs::DeviceBuffer keys_a, keys_b, pay_a, pay_b, sorted, temp;
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
@@ -77,16 +74,16 @@ struct gsplat_context {
   bool have_forward = false;
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
-                                     &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &vals_a,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &perm, &dkeys_a, &dkeys_b, &dvals_a};
+                                     &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &pay_a, &pay_b,
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
   }
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
-                               &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &vals_a,
-                               &sorted, &temp, &ranges, &image, &T_px, &n_px, &perm, &dkeys_a, &dkeys_b, &dvals_a};
+                               &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &pay_a, &pay_b,
+                               &sorted, &temp, &ranges, &image, &T_px, &n_px};
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
@@ -299,7 +296,8 @@ int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   int rc;
   if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned int)))) return rc;
   if ((rc = c->keys_b.reserve((S + 1) * sizeof(unsigned int)))) return rc;
-  if ((rc = c->vals_a.reserve((S + 1) * sizeof(int)))) return rc;
+  if ((rc = c->pay_a.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = c->pay_b.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
   if ((rc = c->sorted.reserve((S + 1) * sizeof(int)))) return rc;
   if ((rc = c->temp.reserve(gs::binning_temp_bytes((size_t)c->max_gaussians, S ? S : 1, num_tiles)))) return rc;
   return GSPLAT_OK;
@@ -325,7 +323,6 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64);
-  R(c->perm, N * 4); R(c->dkeys_a, N * 4); R(c->dkeys_b, N * 4); R(c->dvals_a, N * 4);
   R(c->ranges, (T + 1) * 4); R(c->image, P * 12); R(c->T_px, P * 4); R(c->n_px, P * 4);
   if (!rc) {
     size_t sb1 = 0;
@@ -389,10 +386,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   size_t scan_bytes = c->temp.bytes;
   GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->flags.as<int>(), c->rank.as<int>(), 0, (size_t)N + 1,
                                  rocprim::plus<int>(), st));
-  int rc = gs::depth_order(c->xyz_c_all.as<float>(), N, c->mask.as<unsigned char>(), c->dkeys_a.as<unsigned int>(),
-                           c->dkeys_b.as<unsigned int>(), c->dvals_a.as<int>(), c->perm.as<int>(), c->temp.ptr,
-                           c->temp.bytes, st);
-  if (rc) return rc;
+  int rc = GSPLAT_OK;
   c->mark(0, true, st);
   c->mark(1, false, st);
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
@@ -413,8 +407,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   }
 #undef GS_PRE
   GS_LAUNCH_CHECK();
-  rc = gs::scan_counts_in_depth_order(N, c->perm.as<int>(), c->mask.as<unsigned char>(), c->rank.as<int>(),
-                                      c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
+  rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
   if (rc) return rc;
   c->mark(1, true, st);
   // the one host read-back of the forward: M, S (and the candidate count)
@@ -437,10 +430,11 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   rc = reserve_instances(c, S, num_tiles);
   if (rc) return rc;
   c->mark(2, false, st);
-  rc = gs::emit_sort_ranges(c->uv.as<float>(), c->radius.as<float>(), ntx, nty, N, c->perm.as<int>(),
+  rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                             c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
-                            c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(), c->vals_a.as<int>(),
-                            c->sorted.as<int>(), c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st);
+                            c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
+                            c->pay_a.as<unsigned long long>(), c->pay_b.as<unsigned long long>(), c->sorted.as<int>(),
+                            c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st);
   if (rc) return rc;
   c->mark(2, true, st);
   c->mark(4, false, st);

@@ -212,3 +212,19 @@ def test_pack_gradients_global_layout(gpu, scene):
         assert (p[mask, a:b] == _np(grads[k]).reshape(mask.sum(), b - a)).all(), k
     un = gdist.unpack(packed, L)
     assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3)
+
+
+def test_long_tile_lists(gpu, scene, orc):
+    """Tiles with more than 2048 list entries take the global-memory branch of the per-tile depth sort; lists and
+    image must still match the oracle exactly / within tolerance."""
+    raster = pkg("raster")
+    N, W, H, L = 40000, 64, 48, 0
+    params = scene.make_gaussians(N, W, H, L)
+    params["opacity"][:] = -4.0  # faint: nothing saturates, every list entry matters
+    cam = scene.make_camera(W, H)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
+    assert np.diff(ref["ranges"]).max() > 2048
+    _check_forward(fwd, ref)
