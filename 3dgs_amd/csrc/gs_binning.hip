@@ -177,23 +177,41 @@ __global__ __launch_bounds__(kBlock) void tile_ranges32_kernel(const unsigned in
 // Lists up to kLdsSort entries are sorted in LDS, longer ones in place in global memory by the same workgroup.
 constexpr int kLdsSort = 2048;
 
-template <typename Buf>
+// kWaveLocal: the buffer is LDS.  Thread t of a wave owns comparators whose operands lie in that wave's own
+// 128-element span whenever the comparator distance is <= 64, and a wave executes its LDS operations in order, so
+// those steps need no workgroup barrier (only a compiler fence); for n2 = 512 that removes 42 of 45 barriers.
+template <bool kWaveLocal, typename Buf>
 __device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int tid) {
-  for (int k = 2; k <= n2; k <<= 1) {
-    {  // mirror step
+  // a step whose comparators stay inside one wave's span only needs that wave's own earlier LDS writes; a
+  // workgroup barrier is required whenever the previous OR the next step crosses waves
+  int prev = 1 << 30;  // the loads before the first step were followed by __syncthreads()
+  auto sync = [&](int next) {
+    if (kWaveLocal && prev <= 64 && next <= 64) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      __threadfence_block();
+      __syncthreads();
+    }
+    prev = next;
+  };
+  prev = 0;  // nothing to order before the very first step
+  int lh = 0;  // log2(k / 2)
+  for (int k = 2; k <= n2; k <<= 1, ++lh) {
+    {  // mirror step: comparator distance up to k - 1
+      sync(k >> 1);
       const int half = k >> 1;
       for (int t = tid; t < (n2 >> 1); t += kBlock) {
-        const int base = (t / half) * k, il = t % half;
+        const int base = (t >> lh) << (lh + 1), il = t & (half - 1);
         const int lo = base + il, hi = base + k - 1 - il;
         if (hi < len) {
           const unsigned long long a = p[lo], b = p[hi];
           if (a > b) { p[lo] = b; p[hi] = a; }
         }
       }
-      __threadfence_block();
-      __syncthreads();
     }
     for (int j = k >> 2; j > 0; j >>= 1) {
+      sync(j);
       for (int t = tid; t < (n2 >> 1); t += kBlock) {
         const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
         if (hi < len) {
@@ -201,10 +219,10 @@ __device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int t
           if (a > b) { p[lo] = b; p[hi] = a; }
         }
       }
-      __threadfence_block();
-      __syncthreads();
     }
   }
+  __threadfence_block();
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(kBlock) void tile_depth_sort_kernel(unsigned long long *__restrict__ payload,
@@ -221,11 +239,11 @@ __global__ __launch_bounds__(kBlock) void tile_depth_sort_kernel(unsigned long l
   if (len <= kLdsSort) {
     for (int i = tid; i < len; i += kBlock) buf[i] = payload[start + i];
     __syncthreads();
-    bitonic_sort_block(buf, len, n2, tid);
+    bitonic_sort_block<true>(buf, len, n2, tid);
     for (int i = tid; i < len; i += kBlock) sorted[start + i] = (int)(unsigned int)(buf[i] & 0xFFFFFFFFull);
   } else {
     unsigned long long *p = payload + start;
-    bitonic_sort_block(p, len, n2, tid);
+    bitonic_sort_block<false>(p, len, n2, tid);
     for (int i = tid; i < len; i += kBlock) sorted[start + i] = (int)(unsigned int)(p[i] & 0xFFFFFFFFull);
   }
 }
