@@ -100,6 +100,9 @@ SIGNATURES = {
     "gsplat_context_get_timing": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), _I]),
     "gsplat_pack_gradients_global": (_I, [_P, ctypes.POINTER(Gradients), _I, _I, _P, _P]),
     "gsplat_packed_gradient_width": (_I, [_I]),
+    "gsplat_factored_gradient_width": (_I, [_I]),
+    "gsplat_pack_gradients_factored": (_I, [_P, ctypes.POINTER(Gradients), _I, _I, _I, _P, _P]),
+    "gsplat_unpack_gradients_factored": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
 }
 
 

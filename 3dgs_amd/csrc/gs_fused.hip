@@ -292,6 +292,65 @@ __global__ __launch_bounds__(kBlock) void pack_global_kernel(const unsigned char
   packed[e] = val;
 }
 
+// ---- factored exchange rows (view-sharded training).  Every SH-coefficient gradient of a view is the outer product
+// g_rgb (3) x Y_k(view direction): instead of shipping 3*n_coeffs floats per gaussian through the all-reduce, a
+// rank ships only its g_rgb in a slot of its own (3 floats; the other ranks' slots stay zero, so the SUM all-reduce
+// acts as an all-gather for those columns) and every rank rebuilds sum_r g_rgb^r * Y_k(dir^r) locally from the
+// camera positions.  Row layout: [xyz3 | opacity1 | scale3 | quat4 | visible1 | g_rgb slot 0 .. slot W-1].
+__global__ __launch_bounds__(kBlock) void pack_factored_kernel(const unsigned char *__restrict__ mask,
+                                                               const int *__restrict__ rank_of, int N, int my_rank,
+                                                               int world, gsplat_gradients gr,
+                                                               float *__restrict__ packed) {
+  const int width = 12 + 3 * world;
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (long long)N * width) return;
+  const int i = (int)(e / width), k = (int)(e % width);
+  float val = 0.0f;
+  if (mask[i]) {
+    const size_t j = (size_t)rank_of[i];
+    if (k < 3) val = gr.grad_xyz[3 * j + k];
+    else if (k == 3) val = gr.grad_opacity[j];
+    else if (k < 7) val = gr.grad_scale[3 * j + (k - 4)];
+    else if (k < 11) val = gr.grad_quaternion[4 * j + (k - 7)];
+    else if (k == 11) val = 1.0f;
+    else if ((k - 12) / 3 == my_rank) val = gr.grad_precompute_rgb[3 * j + (k - 12) % 3];
+  }
+  packed[e] = val;
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void unpack_factored_kernel(const float *__restrict__ xyz,
+                                                                 const float *__restrict__ campos_all, int N,
+                                                                 int world, const float *__restrict__ packed,
+                                                                 float *__restrict__ full) {
+  constexpr int n = (L + 1) * (L + 1);
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int wf = 12 + 3 * world, wo = 12 + 3 * n;
+  const float *row = packed + (size_t)i * wf;
+  float *out = full + (size_t)i * wo;
+  float acc[n][3];
+#pragma unroll
+  for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+  const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  for (int r = 0; r < world; ++r) {
+    const float g0 = row[12 + 3 * r], g1 = row[13 + 3 * r], g2 = row[14 + 3 * r];
+    if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+    float dx, dy, dz, len, Y[n];
+    gs::view_dir(px, py, pz, campos_all[3 * r], campos_all[3 * r + 1], campos_all[3 * r + 2], dx, dy, dz, len);
+    gs::sh_basis<L>(dx, dy, dz, Y);
+#pragma unroll
+    for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
+  }
+  out[0] = row[0]; out[1] = row[1]; out[2] = row[2];  // xyz
+#pragma unroll
+  for (int k = 0; k < n; ++k) { out[3 + 3 * k] = acc[k][0]; out[4 + 3 * k] = acc[k][1]; out[5 + 3 * k] = acc[k][2]; }
+  out[3 + 3 * n] = row[3];                                             // opacity
+  out[4 + 3 * n] = row[4]; out[5 + 3 * n] = row[5]; out[6 + 3 * n] = row[6];  // scale
+  out[7 + 3 * n] = row[7]; out[8 + 3 * n] = row[8]; out[9 + 3 * n] = row[9]; out[10 + 3 * n] = row[10];  // quaternion
+  out[11 + 3 * n] = row[11];                                           // visibility count
+}
+
 int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   int rc;
   if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned int)))) return rc;
@@ -308,6 +367,38 @@ int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
 extern "C" {
 
 int gsplat_packed_gradient_width(int l_max) { return 12 + 3 * (l_max + 1) * (l_max + 1); }
+int gsplat_factored_gradient_width(int world_size) { return 12 + 3 * world_size; }
+
+int gsplat_pack_gradients_factored(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians, int rank,
+                                   int world_size, float *packed, void *stream) {
+  GS_REQUIRE(c && grads, "null argument struct");
+  GS_REQUIRE(c->have_forward && num_gaussians == c->N, "does not match the recorded forward");
+  GS_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "bad rank / world_size");
+  GS_REQUIRE_DEV(packed);
+  GS_REQUIRE_DEV(grads->grad_precompute_rgb);  // backward must have been asked for this intermediate
+  const long long total = (long long)num_gaussians * (12 + 3 * world_size);
+  pack_factored_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+      c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, rank, world_size, *grads, packed);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, const float *packed, int l_max,
+                                     int num_gaussians, int world_size, float *full, void *stream) {
+  GS_REQUIRE_DEV(xyz); GS_REQUIRE_DEV(campos_all); GS_REQUIRE_DEV(packed); GS_REQUIRE_DEV(full);
+  GS_REQUIRE(l_max >= 0 && l_max <= 3 && num_gaussians >= 0 && world_size >= 1, "bad sizes");
+  if (num_gaussians == 0) return GSPLAT_OK;
+  const dim3 g(gs::div_up(num_gaussians, kBlock)), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  switch (l_max) {
+    case 0: unpack_factored_kernel<0><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
+    case 1: unpack_factored_kernel<1><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
+    case 2: unpack_factored_kernel<2><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
+    default: unpack_factored_kernel<3><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
+  }
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
 
 int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width, int max_height) {
   GS_REQUIRE(out != nullptr, "out is null");

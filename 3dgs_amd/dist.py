@@ -33,9 +33,11 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            # GSPLAT_DIST_BACKEND=gloo lets several ranks rehearse the exchange step on ONE GPU (RCCL needs one
+            # device per rank); the default on GPUs is nccl = RCCL over xGMI
+            backend = os.environ.get("GSPLAT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -59,25 +61,53 @@ def unpack(packed, l_max):
 
 
 class ViewShardedStep:
-    """forward + backward of this rank's view, then the gradient all-reduce.  Device tensors in, packed[N,width] out."""
+    """forward + backward of this rank's view, then the gradient exchange.  Device tensors in, packed[N,width] out.
 
-    def __init__(self, params, l_max, width, height, config, bg):
+    exchange="factored" (default): the all-reduced buffer carries, per gaussian, the 12 non-SH gradient columns plus
+    one 3-float g_rgb slot per rank (12 + 3*world floats instead of 12 + 3*n_coeffs = 60 at SH degree 3), and one
+    extra row with every rank's camera position; the SH-coefficient gradients sum_r g_rgb^r x Y(dir^r) are rebuilt
+    locally afterwards (gsplat_unpack_gradients_factored).  Still ONE all-reduce per step.
+    exchange="full": all-reduce the complete packed[N, 12+3*n_coeffs] rows.
+    """
+
+    def __init__(self, params, l_max, width, height, config, bg, exchange="factored"):
         from . import raster
+        self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
         self.N = int(params["xyz"].shape[0])
         self.ctx = raster.RasterContext(self.N, width, height)
         self.width_cols = raster.packed_gradient_width(l_max)
-        self.packed = torch.empty(self.N, self.width_cols, dtype=torch.float32, device=params["xyz"].device)
-        self.grads = None
+        dev = params["xyz"].device
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.exchange = exchange
+        self.packed = torch.empty(self.N, self.width_cols, dtype=torch.float32, device=dev)
+        self.fw = raster.factored_gradient_width(self.world)
+        self.factored = torch.zeros(self.N + 1, self.fw, dtype=torch.float32, device=dev) if exchange == "factored" \
+            else None
+        # capacity N: never reallocated
+        self.grads = self.ctx.alloc_gradients(self.N, l_max)
+        self.grads["precompute_rgb"] = torch.empty(self.N, 3, dtype=torch.float32, device=dev)
+
+    def exchange_gradients(self, cam):
+        """Scatter this rank's compacted gradients to global order, sum over ranks, leave the result in self.packed."""
+        if self.exchange == "factored":
+            f = self.factored
+            self.raster.pack_gradients_factored(self.ctx, self.grads, self.N, self.rank, self.world, f)
+            f[self.N].zero_()
+            f[self.N, 12 + 3 * self.rank: 15 + 3 * self.rank] = torch.as_tensor(
+                [float(c) for c in cam["campos"]], dtype=torch.float32, device=f.device)
+            all_reduce_gradients(f)
+            self.raster.unpack_gradients_factored(self.params["xyz"], f[self.N, 12:], f, self.l_max, self.N,
+                                                  self.world, self.packed)
+        else:
+            self.ctx.pack_gradients_global(self.grads, self.l_max, self.N, self.packed)
+            all_reduce_gradients(self.packed)
+        return self.packed
 
     def step(self, cam, grad_image):
         fwd = self.ctx.rasterize_image(self.params, cam, self.config, self.bg, self.l_max)
-        M = fwd["num_culled"]
-        if self.grads is None or self.grads["xyz"].shape[0] < M:
-            self.grads = self.ctx.alloc_gradients(self.N, self.l_max)  # capacity N: never reallocated again
         self.ctx.backward_pass(self.params, cam, grad_image, self.bg, self.l_max, self.grads)
         if self.world > 1:
-            self.ctx.pack_gradients_global(self.grads, self.l_max, self.N, self.packed)
-            all_reduce_gradients(self.packed)
+            self.exchange_gradients(cam)
         return fwd

@@ -168,5 +168,24 @@ class RasterContext:
         return packed
 
 
+def pack_gradients_factored(ctx, grads, num_gaussians, rank, world, factored):
+    gs = RasterContext._grad_struct(grads)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_lib.load().gsplat_pack_gradients_factored(ctx._h, ctypes.byref(gs), int(num_gaussians), int(rank), int(world),
+                                                     _ptr(factored), st))
+    return factored
+
+
+def unpack_gradients_factored(xyz, campos_all, factored, l_max, num_gaussians, world, packed):
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_lib.load().gsplat_unpack_gradients_factored(_ptr(xyz), _ptr(campos_all), _ptr(factored), int(l_max),
+                                                       int(num_gaussians), int(world), _ptr(packed), st))
+    return packed
+
+
+def factored_gradient_width(world):
+    return int(_lib.load().gsplat_factored_gradient_width(int(world)))
+
+
 def packed_gradient_width(l_max):
     return int(_lib.load().gsplat_packed_gradient_width(int(l_max)))

@@ -239,6 +239,18 @@ int gsplat_pack_gradients_global(gsplat_context *ctx, const gsplat_gradients *gr
                                  float *packed, void *stream);
 int gsplat_packed_gradient_width(int l_max);
 
+/* Smaller exchange payload for the same result.  Every SH-coefficient gradient of one view is g_rgb[3] x Y_k(dir),
+ * so a rank only has to ship g_rgb: factored[N, 12 + 3*world] = [xyz3 | opacity1 | scale3 | quat4 | visible1 |
+ * g_rgb of rank 0 | ... | g_rgb of rank world-1] (a rank fills only its own slot; the SUM all-reduce gathers the
+ * slots).  gsplat_unpack_gradients_factored rebuilds the global-order packed[N, 12+3*n_coeffs] buffer from the
+ * reduced rows, the gaussian positions and all ranks' camera positions campos_all[world,3] (device pointer).
+ * gsplat_backward_pass must have been given grad_precompute_rgb. */
+int gsplat_factored_gradient_width(int world_size);
+int gsplat_pack_gradients_factored(gsplat_context *ctx, const gsplat_gradients *grads, int num_gaussians, int rank,
+                                   int world_size, float *factored, void *stream);
+int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, const float *factored, int l_max,
+                                     int num_gaussians, int world_size, float *packed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,40 @@ def test_long_tile_lists(gpu, scene, orc):
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
     assert np.diff(ref["ranges"]).max() > 2048
     _check_forward(fwd, ref)
+
+
+def test_factored_exchange_equals_full_rows(gpu, scene):
+    """Simulates a 3-rank view-sharded step on one GPU: per-view factored rows, summed like the all-reduce would,
+    then unpacked, must equal the sum of the full packed rows of the three views."""
+    torch = gpu
+    raster = pkg("raster")
+    N, W, H, L, world = 3000, 160, 96, 3, 3
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::7, 2] *= -1
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp = raster.device_params(params)
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    fw, pw = raster.factored_gradient_width(world), raster.packed_gradient_width(L)
+    fac_sum = torch.zeros(N + 1, fw, device="cuda")
+    full_sum = torch.zeros(N, pw, device="cuda")
+    for r in range(world):
+        cam = scene.make_camera(W, H, view_index=r + 1)
+        dc = raster.device_camera(cam)
+        fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+        grads = ctx.alloc_gradients(fwd["num_culled"], L)
+        grads["precompute_rgb"] = torch.empty(fwd["num_culled"], 3, device="cuda")
+        ctx.backward_pass(dp, dc, gi, c["bg"], L, grads)
+        fac = torch.zeros(N + 1, fw, device="cuda")
+        raster.pack_gradients_factored(ctx, grads, N, r, world, fac)
+        fac[N, 12 + 3 * r: 15 + 3 * r] = torch.as_tensor(cam["campos"], device="cuda")
+        fac_sum += fac
+        full = torch.empty(N, pw, device="cuda")
+        ctx.pack_gradients_global(grads, L, N, full)
+        full_sum += full
+    out = torch.full((N, pw), float("nan"), device="cuda")
+    raster.unpack_gradients_factored(dp["xyz"], fac_sum[N, 12:].contiguous(), fac_sum, L, N, world, out)
+    a, b = _np(out), _np(full_sum)
+    assert np.isfinite(a).all()
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9)
+    assert (a[:, -1] == b[:, -1]).all()  # visibility counts
