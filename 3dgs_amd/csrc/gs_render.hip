@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
 
   const int start = ranges[tile], total = ranges[tile + 1] - start;
-  float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  // A saturated pixel keeps T = 0 in the running transmittance, so every later splat blends with weight 0 and the
+  // common path needs no per-pixel "done" masking; its real final transmittance and stop index live in T_fin / n.
+  float T = inside ? 1.0f : 0.0f, T_fin = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
   int n = total;
-  bool done = !inside;
+  bool sat = false;
+  int live = __popcll(__ballot(inside));  // wave-uniform count of unsaturated pixels
 
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
@@ -79,41 +82,49 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
     }
     __syncthreads();
-    bool wave_done = __all(done);
-    for (int sb = 0; sb < count && !wave_done; sb += 64) {
+    for (int sb = 0; sb < count && live > 0; sb += 64) {
       const int slot_l = sb + lane;
       const unsigned int bits = slot_l < count ? __float_as_uint(s_r2[slot_l].w) : 0u;
       unsigned long long m = __ballot((bits >> wave) & 1u);
-      while (m != 0ull && !wave_done) {
+      while (m != 0ull && live > 0) {
         const int j = __builtin_ctzll(m);
         m &= m - 1ull;
         const int slot = sb + j;
-        const float4 a = s_r0[slot], b = s_r1[slot], c = s_r2[slot];
+        const float4 a = s_r0[slot], c = s_r2[slot];
+        const float2 b = *reinterpret_cast<const float2 *>(&s_r1[slot]);
+        asm volatile("" ::"v"(c.w));  // keep the 16-byte read: ds_read_b96 costs twice the LDS cycles of ds_read_b128
         const float power = fminf(0.0f, gauss_power(a.z, a.w, b.x, a.x - fpx, a.y - fpy));
         float alpha = fminf(kAlphaMax, b.y * __expf(power));
-        alpha = (alpha > kAlphaMin && !done) ? alpha : 0.0f;
-        const float test_T = T * (1.0f - alpha);
+        alpha = alpha > kAlphaMin ? alpha : 0.0f;
         const float w = alpha * T;
+        const float test_T = T * (1.0f - alpha);
         ar = __builtin_fmaf(c.x, w, ar);
         ag = __builtin_fmaf(c.y, w, ag);
         ab = __builtin_fmaf(c.z, w, ab);
+        const bool trip = test_T < kTMin && T > 0.0f;  // this splat was still accumulated (cuda/render.cu:76-87)
         T = test_T;
-        if (!done && test_T < kTMin) {  // this splat was still accumulated (cuda/render.cu:76-87)
-          done = true;
-          n = base + slot + 1;
+        const unsigned long long tm = __ballot(trip);
+        if (tm != 0ull) {  // rare
+          if (trip) {
+            sat = true;
+            T_fin = test_T;
+            n = base + slot + 1;
+            T = 0.0f;
+          }
+          live -= __popcll(tm);
         }
-        wave_done = __all(done);
       }
     }
-    if (__syncthreads_and(done ? 1 : 0)) break;
+    if (__syncthreads_and(live <= 0 ? 1 : 0)) break;
   }
   if (inside) {
     const int pid = py * width + px;
+    const float Tout = sat ? T_fin : T;
     n_out[pid] = n;
-    T_out[pid] = T;
-    image[3 * pid + 0] = ar + T * bg;
-    image[3 * pid + 1] = ag + T * bg;
-    image[3 * pid + 2] = ab + T * bg;
+    T_out[pid] = Tout;
+    image[3 * pid + 0] = ar + Tout * bg;
+    image[3 * pid + 1] = ag + Tout * bg;
+    image[3 * pid + 2] = ab + Tout * bg;
   }
 }
 
@@ -265,10 +276,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         float gg = __expf(power);
         const float opa = b.y;
         float alpha = fminf(kAlphaMax, opa * gg);
-        const bool valid = inside && (alpha >= kAlphaMin) && (base + slot < n);
-        if (!__any(valid)) continue;
-        alpha = valid ? alpha : 0.0f;
-        gg = valid ? gg : 0.0f;
+        // n is 0 for pixels outside the image, so "inside" needs no separate test
+        const bool valid = (alpha >= kAlphaMin) && (base + slot < n);
+        if (__ballot(valid) == 0ull) continue;
+        // one select, two multiplies: selects on SGPR masks are ~8x the issue cost of a multiply on this chip
+        const float vf = valid ? 1.0f : 0.0f;
+        alpha *= vf;
+        gg *= vf;
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T *= inv;                                           // transmittance in front of this splat
         const float aT = alpha * T;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         c2 = __builtin_fmaf(alpha, d2, c2);
         const float gp = gg * (ga * opa);                   // d/d power
         // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa)
-        if (opa == 1.0f || !__any(gp != 0.0f)) continue;
+        if (opa == 1.0f || __ballot(gp != 0.0f) == 0ull) continue;
         const float gpx = gp * dx, gpy = gp * dy;
         // nine raw sums; signs, the -1/2 factors, (1 - opa) and the 0.5*W / 0.5*H are applied once per gaussian
         // at flush time:  S0 = sum gp, Sx, Sy, Sxx, Sxy, Syy
