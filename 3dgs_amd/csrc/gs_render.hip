@@ -87,31 +87,52 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
       const unsigned int bits = slot_l < count ? __float_as_uint(s_r2[slot_l].w) : 0u;
       unsigned long long m = __ballot((bits >> wave) & 1u);
       while (m != 0ull && live > 0) {
-        const int j = __builtin_ctzll(m);
+        // two visited gaussians per trip: both records are fetched from LDS and both exponentials evaluated before
+        // the (sequential) blending, which halves the loop / LDS-latency overhead per visit
+        const int j0 = __builtin_ctzll(m);
         m &= m - 1ull;
-        const int slot = sb + j;
-        const float4 a = s_r0[slot], c = s_r2[slot];
-        const float2 b = *reinterpret_cast<const float2 *>(&s_r1[slot]);
-        asm volatile("" ::"v"(c.w));  // keep the 16-byte read: ds_read_b96 costs twice the LDS cycles of ds_read_b128
-        const float power = fminf(0.0f, gauss_power(a.z, a.w, b.x, a.x - fpx, a.y - fpy));
-        float alpha = fminf(kAlphaMax, b.y * __expf(power));
-        alpha = alpha > kAlphaMin ? alpha : 0.0f;
-        const float w = alpha * T;
-        const float test_T = T * (1.0f - alpha);
-        ar = __builtin_fmaf(c.x, w, ar);
-        ag = __builtin_fmaf(c.y, w, ag);
-        ab = __builtin_fmaf(c.z, w, ab);
-        const bool trip = test_T < kTMin && T > 0.0f;  // this splat was still accumulated (cuda/render.cu:76-87)
-        T = test_T;
-        const unsigned long long tm = __ballot(trip);
-        if (tm != 0ull) {  // rare
-          if (trip) {
-            sat = true;
-            T_fin = test_T;
-            n = base + slot + 1;
-            T = 0.0f;
+        const bool two = m != 0ull;
+        const int j1 = two ? __builtin_ctzll(m) : j0;
+        m &= m - 1ull;  // no-op on 0
+        const int slot0 = sb + j0, slot1 = sb + j1;
+        const float4 a0 = s_r0[slot0], c0 = s_r2[slot0];
+        const float2 b0 = *reinterpret_cast<const float2 *>(&s_r1[slot0]);
+        const float4 a1 = s_r0[slot1], c1 = s_r2[slot1];
+        const float2 b1 = *reinterpret_cast<const float2 *>(&s_r1[slot1]);
+        asm volatile("" ::"v"(c0.w), "v"(c1.w));  // keep 16-byte reads (ds_read_b96 costs twice the LDS cycles)
+        const float p0 = fminf(0.0f, gauss_power(a0.z, a0.w, b0.x, a0.x - fpx, a0.y - fpy));
+        const float p1 = fminf(0.0f, gauss_power(a1.z, a1.w, b1.x, a1.x - fpx, a1.y - fpy));
+        float al0 = fminf(kAlphaMax, b0.y * __expf(p0));
+        float al1 = fminf(kAlphaMax, b1.y * __expf(p1));
+        al0 = al0 > kAlphaMin ? al0 : 0.0f;
+        al1 = (al1 > kAlphaMin && two) ? al1 : 0.0f;
+        {
+          const float w = al0 * T;
+          const float test_T = T * (1.0f - al0);
+          ar = __builtin_fmaf(c0.x, w, ar);
+          ag = __builtin_fmaf(c0.y, w, ag);
+          ab = __builtin_fmaf(c0.z, w, ab);
+          const bool trip = test_T < kTMin && T > 0.0f;  // this splat was still accumulated (cuda/render.cu:76-87)
+          T = test_T;
+          const unsigned long long tm = __ballot(trip);
+          if (tm != 0ull) {  // rare
+            if (trip) { sat = true; T_fin = test_T; n = base + slot0 + 1; T = 0.0f; }
+            live -= __popcll(tm);
           }
-          live -= __popcll(tm);
+        }
+        {
+          const float w = al1 * T;
+          const float test_T = T * (1.0f - al1);
+          ar = __builtin_fmaf(c1.x, w, ar);
+          ag = __builtin_fmaf(c1.y, w, ag);
+          ab = __builtin_fmaf(c1.z, w, ab);
+          const bool trip = test_T < kTMin && T > 0.0f;
+          T = test_T;
+          const unsigned long long tm = __ballot(trip);
+          if (tm != 0ull) {
+            if (trip) { sat = true; T_fin = test_T; n = base + slot1 + 1; T = 0.0f; }
+            live -= __popcll(tm);
+          }
         }
       }
     }
