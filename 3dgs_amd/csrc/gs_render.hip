@@ -20,8 +20,6 @@
 //   * backward: nine partial sums per (wave, gaussian) are reduced across the wave on DPP,
 //     merged across the four waves in LDS, and flushed once per batch to HBM as whole
 //     64-byte gradient rows (or into the reference's four gradient arrays).
-#include <cstdlib>
-
 #include "gs_common.h"
 #include "gs_render.h"
 
@@ -146,74 +144,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
     image[3 * pid + 0] = ar + Tout * bg;
     image[3 * pid + 1] = ag + Tout * bg;
     image[3 * pid + 2] = ab + Tout * bg;
-  }
-}
-
-// ------------------------------------------------------------------------------ forward, wave-granular
-// Experimental variant: one 64-thread workgroup per 8x8 quadrant, no workgroup barriers.  Each wave walks its
-// tile's list 64 entries at a time (every lane gathers one gaussian), keeps the batch in its private 3 KB of LDS
-// and visits only the entries whose footprint reaches its quadrant.
-template <bool kPacked>
-__global__ __launch_bounds__(64) void render_fwd_wave_kernel(const float4 *__restrict__ recs, RawSplats raw,
-                                                             const int *__restrict__ sorted,
-                                                             const int *__restrict__ ranges, int width, int height,
-                                                             int ntx, int num_tiles, float bg,
-                                                             int *__restrict__ n_out, float *__restrict__ T_out,
-                                                             float *__restrict__ image) {
-  __shared__ float4 s_r0[64], s_r1[64], s_r2[64];
-  const int tile = block_to_tile(blockIdx.x >> 2, num_tiles);
-  if (tile >= num_tiles) return;
-  const int lane = threadIdx.x, quad = blockIdx.x & 3;
-  const int tile_x = tile % ntx, tile_y = tile / ntx;
-  const int qx0 = tile_x * 16 + (quad & 1) * 8, qy0 = tile_y * 16 + (quad >> 1) * 8;
-  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-  const bool inside = px < width && py < height;
-  const float fpx = (float)px, fpy = (float)py;
-  const float fx0 = (float)qx0, fy0 = (float)qy0;
-  const int start = ranges[tile], total = ranges[tile + 1] - start;
-  float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
-  int n = total;
-  bool done = !inside;
-  bool wave_done = __all(done);
-  for (int base = 0; base < total && !wave_done; base += 64) {
-    const int count = min(64, total - base);
-    bool hit = false;
-    if (lane < count) {
-      const int g = sorted[start + base + lane];
-      const SplatRec s = load_record<kPacked>(g, recs, raw);
-      const float u = s.r0.x, v = s.r0.y, hx = s.r1.z, hy = s.r1.w;
-      hit = !(u + hx < fx0) && !(u - hx > fx0 + 7.0f) && !(v + hy < fy0) && !(v - hy > fy0 + 7.0f);
-      s_r0[lane] = s.r0; s_r1[lane] = s.r1; s_r2[lane] = s.r2;
-    }
-    unsigned long long m = __ballot(hit);
-    while (m != 0ull && !wave_done) {
-      const int slot = __builtin_ctzll(m);
-      m &= m - 1ull;
-      const float4 a = s_r0[slot], c = s_r2[slot];
-      const float2 b = *reinterpret_cast<const float2 *>(&s_r1[slot]);
-      const float power = fminf(0.0f, gauss_power(a.z, a.w, b.x, a.x - fpx, a.y - fpy));
-      float alpha = fminf(kAlphaMax, b.y * __expf(power));
-      alpha = (alpha > kAlphaMin && !done) ? alpha : 0.0f;
-      const float test_T = T * (1.0f - alpha);
-      const float w = alpha * T;
-      ar = __builtin_fmaf(c.x, w, ar);
-      ag = __builtin_fmaf(c.y, w, ag);
-      ab = __builtin_fmaf(c.z, w, ab);
-      T = test_T;
-      if (!done && test_T < kTMin) {
-        done = true;
-        n = base + slot + 1;
-      }
-      wave_done = __all(done);
-    }
-  }
-  if (inside) {
-    const int pid = py * width + px;
-    n_out[pid] = n;
-    T_out[pid] = T;
-    image[3 * pid + 0] = ar + T * bg;
-    image[3 * pid + 1] = ag + T * bg;
-    image[3 * pid + 2] = ab + T * bg;
   }
 }
 
@@ -375,10 +305,7 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
-  static const int variant = getenv("GSPLAT_FWD_WAVE") ? atoi(getenv("GSPLAT_FWD_WAVE")) : 0;
-  if (recs && variant)
-    render_fwd_wave_kernel<true><<<dim3(grid.x * 4), dim3(64), 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);
-  else if (recs)
+  if (recs)
     render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);
   else
     render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);

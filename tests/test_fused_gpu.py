@@ -265,3 +265,16 @@ def test_factored_exchange_equals_full_rows(gpu, scene):
     assert np.isfinite(a).all()
     np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9)
     assert (a[:, -1] == b[:, -1]).all()  # visibility counts
+
+
+def test_config2_forward_only(gpu, scene, orc):
+    """BASELINE configs[1]: synthetic 100k gaussians, 800x800, SH degree 0, forward render only."""
+    raster = pkg("raster")
+    N, W, H, L, _ = scene.WORKLOADS["config2"]
+    params = scene.make_gaussians(N, W, H, L)
+    cam = scene.make_camera(W, H)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, c["bg"], L)
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=16)
+    _check_forward(fwd, ref, exact_lists=False)
