@@ -74,7 +74,7 @@ class RasterContext:
     def workspace_bytes(self):
         return int(self._lib.gsplat_context_bytes(self._h))
 
-    STAGES = ("project_cull_depthsort", "preprocess", "emit_tilesort_ranges", "unused", "render_forward", "zero_grad_rows",
+    STAGES = ("project_cull", "preprocess", "bin_sort", "reserved", "render_forward", "zero_grad_rows",
               "render_backward", "preprocess_backward")
 
     def set_timing(self, enabled):

@@ -225,7 +225,7 @@ int gsplat_backward_pass(gsplat_context *ctx, const gsplat_gaussians *gaussians,
                          void *stream);
 
 /* Measurement hook: when enabled, every stage of the two fused passes is bracketed by HIP events on the
- * caller's stream.  Stage ids: 0 project+cull+scan+depth sort, 1 preprocess+scan, 2 emit+tile sort+ranges, 3 unused,
+ * caller's stream.  Stage ids: 0 project+cull+scan, 1 preprocess+scan, 2 emit + tile sort + ranges + per-tile depth sort, 3 reserved,
  * 4 compositing forward, 5 gradient-row memset, 6 compositing backward, 7 per-gaussian backward.
  * gsplat_context_get_timing synchronises the device, writes the per-stage sum of milliseconds and the number
  * of samples since timing was (re)enabled, and returns the number of stages. */
