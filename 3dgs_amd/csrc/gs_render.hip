@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
                                                          int *__restrict__ n_out, float *__restrict__ T_out,
                                                          float *__restrict__ image) {
   __shared__ float4 s_r0[kBatch], s_r1[kBatch], s_r2[kBatch];
+  __shared__ unsigned char s_list[4 * 64];
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -65,10 +66,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   const int start = ranges[tile], total = ranges[tile + 1] - start;
   // A saturated pixel keeps T = 0 in the running transmittance, so every later splat blends with weight 0 and the
   // common path needs no per-pixel "done" masking; its real final transmittance and stop index live in T_fin / n.
-  float T = inside ? 1.0f : 0.0f, T_fin = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  float T = inside ? 1.0f : 0.0f, T_fin = -1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
   int n = total;
-  bool sat = false;
-  int live = __popcll(__ballot(inside));  // wave-uniform count of unsaturated pixels
+  unsigned long long satmask = __ballot(!inside);  // lanes whose pixel is saturated or outside the image
+  int live = satmask != ~0ull ? 1 : 0;             // wave-uniform: some pixel of the quadrant is still unsaturated
 
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
@@ -83,16 +84,24 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
     for (int sb = 0; sb < count && live > 0; sb += 64) {
       const int slot_l = sb + lane;
       const unsigned int bits = slot_l < count ? __float_as_uint(s_r2[slot_l].w) : 0u;
-      unsigned long long m = __ballot((bits >> wave) & 1u);
-      while (m != 0ull && live > 0) {
+      const bool hit = (bits >> wave) & 1u;
+      const unsigned long long m = __ballot(hit);
+      const int cnt = __popcll(m);
+      if (cnt == 0) continue;
+      // The scalar unit, not the VALU, limits this loop (profiles/: ~17 SALU per visit when the hit mask is
+      // popped bit by bit), so the hit slots are compacted once per 64 entries with lane-parallel work: lane t ends
+      // up holding the t-th hit slot and each visit fetches it with one v_readlane.
+      const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+      if (hit) s_list[wave * 64 + pos] = (unsigned char)lane;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int my_hit = sb + (int)s_list[wave * 64 + lane];
+      for (int t = 0; t < cnt; t += 2) {
         // two visited gaussians per trip: both records are fetched from LDS and both exponentials evaluated before
-        // the (sequential) blending, which halves the loop / LDS-latency overhead per visit
-        const int j0 = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const bool two = m != 0ull;
-        const int j1 = two ? __builtin_ctzll(m) : j0;
-        m &= m - 1ull;  // no-op on 0
-        const int slot0 = sb + j0, slot1 = sb + j1;
+        // the (sequential) blending
+        const int slot0 = __builtin_amdgcn_readlane(my_hit, t);
+        const bool two = t + 1 < cnt;
+        const int slot1 = __builtin_amdgcn_readlane(my_hit, two ? t + 1 : t);
         const float4 a0 = s_r0[slot0], c0 = s_r2[slot0];
         const float2 b0 = *reinterpret_cast<const float2 *>(&s_r1[slot0]);
         const float4 a1 = s_r0[slot1], c1 = s_r2[slot1];
@@ -104,32 +113,31 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
         float al1 = fminf(kAlphaMax, b1.y * __expf(p1));
         al0 = al0 > kAlphaMin ? al0 : 0.0f;
         al1 = (al1 > kAlphaMin && two) ? al1 : 0.0f;
-        {
-          const float w = al0 * T;
-          const float test_T = T * (1.0f - al0);
-          ar = __builtin_fmaf(c0.x, w, ar);
-          ag = __builtin_fmaf(c0.y, w, ag);
-          ab = __builtin_fmaf(c0.z, w, ab);
-          const bool trip = test_T < kTMin && T > 0.0f;  // this splat was still accumulated (cuda/render.cu:76-87)
-          T = test_T;
-          const unsigned long long tm = __ballot(trip);
-          if (tm != 0ull) {  // rare
-            if (trip) { sat = true; T_fin = test_T; n = base + slot0 + 1; T = 0.0f; }
-            live -= __popcll(tm);
-          }
-        }
-        {
-          const float w = al1 * T;
-          const float test_T = T * (1.0f - al1);
-          ar = __builtin_fmaf(c1.x, w, ar);
-          ag = __builtin_fmaf(c1.y, w, ag);
-          ab = __builtin_fmaf(c1.z, w, ab);
-          const bool trip = test_T < kTMin && T > 0.0f;
-          T = test_T;
-          const unsigned long long tm = __ballot(trip);
-          if (tm != 0ull) {
-            if (trip) { sat = true; T_fin = test_T; n = base + slot1 + 1; T = 0.0f; }
-            live -= __popcll(tm);
+        // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T * (1 - alpha) < 1e-4" alone
+        // decides the next T; the compare's lane mask doubles as the saturation bookkeeping (one scalar compare per
+        // visit, the per-pixel records are only touched in the rare branch).
+        const float w0 = al0 * T;
+        const float tT0 = T * (1.0f - al0);
+        ar = __builtin_fmaf(c0.x, w0, ar);
+        ag = __builtin_fmaf(c0.y, w0, ag);
+        ab = __builtin_fmaf(c0.z, w0, ab);
+        const unsigned long long s0 = __ballot(tT0 < kTMin);  // this splat was still accumulated (render.cu:76-87)
+        T = tT0 < kTMin ? 0.0f : tT0;
+        const float w1 = al1 * T;
+        const float tT1 = T * (1.0f - al1);
+        ar = __builtin_fmaf(c1.x, w1, ar);
+        ag = __builtin_fmaf(c1.y, w1, ag);
+        ab = __builtin_fmaf(c1.z, w1, ab);
+        const unsigned long long s1 = __ballot(tT1 < kTMin);
+        T = tT1 < kTMin ? 0.0f : tT1;
+        if (s1 != satmask) {  // rare: some pixel saturated in this trip
+          const unsigned long long bit = 1ull << lane;
+          if ((s0 & ~satmask) & bit) { T_fin = tT0; n = base + slot0 + 1; }
+          if ((s1 & ~s0) & bit) { T_fin = tT1; n = base + slot1 + 1; }
+          satmask = s1;
+          if (satmask == ~0ull) {
+            live = 0;
+            break;
           }
         }
       }
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   }
   if (inside) {
     const int pid = py * width + px;
-    const float Tout = sat ? T_fin : T;
+    const float Tout = T_fin >= 0.0f ? T_fin : T;  // T_fin is set by the splat that saturated the pixel
     n_out[pid] = n;
     T_out[pid] = Tout;
     image[3 * pid + 0] = ar + Tout * bg;
