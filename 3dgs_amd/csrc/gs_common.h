@@ -68,6 +68,7 @@ struct DeviceBuffer {
 // temporaries inside the same operators: cuda/culling.cu:400-463, cuda/spherical_harmonics.cu:76-79).
 enum ScratchSlot {
   SCR_COUNTS = 0, SCR_OFFSETS, SCR_KEYS_A, SCR_KEYS_B, SCR_VALS_B, SCR_TEMP, SCR_SPLATS, SCR_MISC, SCR_GRADROWS,
+  SCR_LOSS_MU, SCR_LOSS_S1, SCR_LOSS_S12, SCR_LOSS_ACC,
   SCR_NUM
 };
 DeviceBuffer &scratch(ScratchSlot slot);

@@ -122,6 +122,25 @@ def render_image_backward(uvs, opacity, conic, rgb, background_opacity, sorted_s
         _p(grad_opacity), _p(grad_uv), _p(grad_conic), _stream()))
 
 
+def fused_loss(predicted_data, gt_data, rows, cols, ssim_weight, image_grad, blocking=True):
+    """fused_loss(...) -> loss (cuda_forward.cuh:146-147).  blocking=False skips the read-back and returns None."""
+    out = ctypes.c_float(0.0)
+    check(_lib.load().gsplat_fused_loss(_p(predicted_data), _p(gt_data), rows, cols, ssim_weight, _p(image_grad),
+                                        ctypes.byref(out) if blocking else None, _stream()))
+    return float(out.value) if blocking else None
+
+
+def compute_psnr(predicted_data, gt_data, rows, cols):
+    out = ctypes.c_float(0.0)
+    check(_lib.load().gsplat_compute_psnr(_p(predicted_data), _p(gt_data), rows, cols, ctypes.byref(out), _stream()))
+    return float(out.value)
+
+
+def adam_step(params, param_grads, exp_avg, exp_avg_sq, lr, b1, b2, eps, bias1, bias2, N, S):
+    check(_lib.load().gsplat_adam_step(_p(params), _p(param_grads), _p(exp_avg), _p(exp_avg_sq), lr, b1, b2, eps,
+                                       bias1, bias2, N, S, _stream()))
+
+
 def compact_masked_array(stride, d_source, d_mask, num_culled=None):
     """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride]."""
     N = int(d_mask.numel())

@@ -68,3 +68,19 @@ inline void render_image(const float *uv, const float *opacity, const float *con
                                               weight_per_pixel, image, stream),
                           "render_image");
 }
+
+// "next" row f1: loss + metric (reference declarations: include/gsplat_cuda/cuda_forward.cuh:144-156)
+inline float fused_loss(const float *predicted_data, const float *gt_data, int rows, int cols, const float ssim_weight,
+                        float *image_grad, cudaStream_t stream = 0) {
+  float loss = 0.0f;
+  gsplat_shim::require_ok(gsplat_fused_loss(predicted_data, gt_data, rows, cols, ssim_weight, image_grad, &loss, stream),
+                          "fused_loss");
+  return loss;
+}
+
+inline float compute_psnr(const float *predicted_data, const float *gt_data, int rows, int cols,
+                          cudaStream_t stream = 0) {
+  float psnr = 0.0f;
+  gsplat_shim::require_ok(gsplat_compute_psnr(predicted_data, gt_data, rows, cols, &psnr, stream), "compute_psnr");
+  return psnr;
+}

@@ -142,6 +142,22 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
                                  int image_height, float *grad_rgb, float *grad_opacity, float *grad_uv,
                                  float *grad_conic, void *stream);
 
+/* ---------------------------------------------------- "next" rows: loss, metric, optimizer --- */
+
+/* replaces fused_loss  (cuda_forward.cuh:146-147, cuda/loss.cu:430-471): L1 + SSIM loss and dL/dimage.
+ * image_grad[H,W,3] is overwritten.  If loss_out != NULL the mean loss is read back (blocks the host, as the
+ * reference's return value does); pass NULL to stay asynchronous. */
+int gsplat_fused_loss(const float *predicted_data, const float *gt_data, int rows, int cols, float ssim_weight,
+                      float *image_grad, float *loss_out, void *stream);
+
+/* replaces compute_psnr  (cuda_forward.cuh:158, cuda/loss.cu:510-525); blocks the host */
+int gsplat_compute_psnr(const float *predicted_data, const float *gt_data, int rows, int cols, float *psnr_out,
+                        void *stream);
+
+/* replaces adam_step  (include/gsplat_cuda/optimizer.cuh:27-29, cuda/optimizer.cu:31-44) on N*S elements */
+int gsplat_adam_step(float *params, const float *param_grads, float *exp_avg, float *exp_avg_sq, float lr, float b1,
+                     float b2, float eps, float bias1, float bias2, int N, int S, void *stream);
+
 /* ------------------------------------------------------------- compaction templates --- */
 
 /* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]

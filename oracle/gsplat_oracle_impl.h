@@ -804,6 +804,138 @@ void FN(orc_scatter_masked)(const R *src, const unsigned char *mask, int N, int 
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* F1  fused_loss / compute_psnr   cuda/loss.cu:58-471, 476-525   ("next" row f1)          */
+/* Loss = mean over H*W*3 of (1-w)|p-g| + w(1-SSIM), SSIM from an 11-tap separable Gaussian */
+/* window with CLAMPED borders on pred/gt (:41-46); the gradient convolves the three partial */
+/* derivative maps with ZERO padding (:48-53, 333-337), adds (1-w)*(p>g ? 1 : -1) and scales  */
+/* by 1/(H*W*3) (:419-428).  Interleaved RGB.                                              */
+/* ------------------------------------------------------------------------------------ */
+static const double FN(kGauss11)[11] = {0.001028380123898387,  0.0075987582094967365, 0.036000773310661316,
+                                        0.10936068743467331,   0.21300552785396576,   0.26601171493530273,
+                                        0.21300552785396576,   0.10936068743467331,   0.036000773310661316,
+                                        0.0075987582094967365, 0.001028380123898387};
+
+R FN(orc_fused_loss)(const R *pred, const R *gt, int H, int W, R ssim_weight, R *image_grad, int threads) {
+  const R C1 = (R)(0.01f * 1.0f) * (R)(0.01f * 1.0f), C2 = (R)(0.03f * 1.0f) * (R)(0.03f * 1.0f);
+  const size_t npx = (size_t)H * W;
+  R *hx = (R *)malloc(npx * 3 * 5 * sizeof(R));       /* horizontal pass: sumX, sumX2, sumY, sumY2, sumXY */
+  R *dmu = (R *)malloc(npx * 3 * sizeof(R)), *ds1 = (R *)malloc(npx * 3 * sizeof(R)), *ds12 = (R *)malloc(npx * 3 * sizeof(R));
+  R *hb = (R *)malloc(npx * 3 * 3 * sizeof(R));
+  R w11[11];
+  for (int k = 0; k < 11; ++k) w11[k] = (R)(float)FN(kGauss11)[k];
+  (void)threads;
+  double total = 0.0;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) {
+        R sX = 0, sX2 = 0, sY = 0, sY2 = 0, sXY = 0;
+        for (int d = 1; d <= 5; ++d) {
+          const R w = w11[5 - d];
+          const int xl = x - d < 0 ? 0 : x - d, xr = x + d > W - 1 ? W - 1 : x + d;
+          const R Xl = pred[((size_t)y * W + xl) * 3 + c], Yl = gt[((size_t)y * W + xl) * 3 + c];
+          const R Xr = pred[((size_t)y * W + xr) * 3 + c], Yr = gt[((size_t)y * W + xr) * 3 + c];
+          sX += (Xl + Xr) * w; sX2 += (Xl * Xl + Xr * Xr) * w; sY += (Yl + Yr) * w; sY2 += (Yl * Yl + Yr * Yr) * w;
+          sXY += (Xl * Yl + Xr * Yr) * w;
+        }
+        const R wc = w11[5], Xc = pred[((size_t)y * W + x) * 3 + c], Yc = gt[((size_t)y * W + x) * 3 + c];
+        sX += Xc * wc; sX2 += Xc * Xc * wc; sY += Yc * wc; sY2 += Yc * Yc * wc; sXY += Xc * Yc * wc;
+        R *o = hx + (((size_t)y * W + x) * 3 + c) * 5;
+        o[0] = sX; o[1] = sX2; o[2] = sY; o[3] = sY2; o[4] = sXY;
+      }
+#pragma omp parallel for schedule(static) reduction(+ : total) num_threads(threads > 0 ? threads : 1)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) {
+        R o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+        for (int d = 1; d <= 5; ++d) {
+          const R w = w11[5 - d];
+          const int yt = y - d < 0 ? 0 : y - d, yb = y + d > H - 1 ? H - 1 : y + d;
+          const R *t = hx + (((size_t)yt * W + x) * 3 + c) * 5, *b = hx + (((size_t)yb * W + x) * 3 + c) * 5;
+          o0 += (t[0] + b[0]) * w; o1 += (t[1] + b[1]) * w; o2 += (t[2] + b[2]) * w; o3 += (t[3] + b[3]) * w;
+          o4 += (t[4] + b[4]) * w;
+        }
+        const R *ct = hx + (((size_t)y * W + x) * 3 + c) * 5;
+        const R wc = w11[5];
+        o0 += ct[0] * wc; o1 += ct[1] * wc; o2 += ct[2] * wc; o3 += ct[3] * wc; o4 += ct[4] * wc;
+        const R mu1 = o0, mu2 = o2, mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+        const R s1 = o1 - mu1_sq, s2 = o3 - mu2_sq, s12 = o4 - mu1 * mu2;
+        const R A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = (R)2 * mu1 * mu2 + C1, D = (R)2 * s12 + C2;
+        const R ssim = (Cc * D) / (A * B);
+        const size_t id = ((size_t)y * W + x) * 3 + c;
+        const R l1 = FABS(pred[id] - gt[id]);
+        total += (double)(((R)1 - ssim_weight) * l1 + ssim_weight * ((R)1 - ssim));
+        const R d_mu1 = ((mu2 * (R)2 * D) / (A * B) - (mu2 * (R)2 * Cc) / (A * B) - (mu1 * (R)2 * Cc * D) / (A * A * B) +
+                         (mu1 * (R)2 * Cc * D) / (A * B * B));
+        dmu[id] = -ssim_weight * d_mu1;
+        ds1[id] = -ssim_weight * ((-Cc * D) / (A * B * B));
+        ds12[id] = -ssim_weight * (((R)2 * Cc) / (A * B));
+      }
+  /* backward: zero-padded separable convolution of the three maps */
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) {
+        R a0 = 0, a1 = 0, a2 = 0;
+        for (int d = 1; d <= 5; ++d) {
+          const R w = w11[5 - d];
+          const int xl = x - d, xr = x + d;
+          const size_t il = ((size_t)y * W + (xl < 0 ? 0 : xl)) * 3 + c, ir = ((size_t)y * W + (xr > W - 1 ? W - 1 : xr)) * 3 + c;
+          const R l0 = xl < 0 ? (R)0 : dmu[il], l1 = xl < 0 ? (R)0 : ds1[il], l2 = xl < 0 ? (R)0 : ds12[il];
+          const R r0 = xr >= W ? (R)0 : dmu[ir], r1 = xr >= W ? (R)0 : ds1[ir], r2 = xr >= W ? (R)0 : ds12[ir];
+          a0 += (l0 + r0) * w; a1 += (l1 + r1) * w; a2 += (l2 + r2) * w;
+        }
+        const size_t id = ((size_t)y * W + x) * 3 + c;
+        a0 += dmu[id] * w11[5]; a1 += ds1[id] * w11[5]; a2 += ds12[id] * w11[5];
+        R *o = hb + id * 3;
+        o[0] = a0; o[1] = a1; o[2] = a2;
+      }
+  const R grad_scale = (R)1 / (R)((float)(H * W * 3));
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) {
+        R s0 = 0, s1 = 0, s2 = 0;
+        for (int d = 1; d <= 5; ++d) {
+          const R w = w11[5 - d];
+          const int yt = y - d, yb = y + d;
+          if (yt >= 0) { const R *t = hb + (((size_t)yt * W + x) * 3 + c) * 3; s0 += t[0] * w; s1 += t[1] * w; s2 += t[2] * w; }
+          if (yb < H) { const R *b = hb + (((size_t)yb * W + x) * 3 + c) * 3; s0 += b[0] * w; s1 += b[1] * w; s2 += b[2] * w; }
+        }
+        const size_t id = ((size_t)y * W + x) * 3 + c;
+        const R *ct = hb + id * 3;
+        s0 += ct[0] * w11[5]; s1 += ct[1] * w11[5]; s2 += ct[2] * w11[5];
+        const R ssim_g = s0 + ((R)2 * pred[id]) * s1 + gt[id] * s2;
+        const R l1_g = ((R)1 - ssim_weight) * ((pred[id] > gt[id]) ? (R)1 : (R)-1);
+        image_grad[id] = (ssim_g + l1_g) * grad_scale;
+      }
+  free(hx); free(dmu); free(ds1); free(ds12); free(hb);
+  return (R)(total / (double)((size_t)H * W * 3));
+}
+
+R FN(orc_psnr)(const R *pred, const R *gt, int H, int W) {  /* cuda/loss.cu:476-525 */
+  double acc = 0.0;
+  const size_t n = (size_t)H * W * 3;
+  for (size_t i = 0; i < n; ++i) { const R d = pred[i] - gt[i]; acc += (double)(d * d); }
+  const R mse = (R)(acc / (double)n);
+  if (mse == (R)0) return (R)100;
+  return (R)10 * (R)log10((double)((R)1 / mse));
+}
+
+/* F2  adam_step   cuda/optimizer.cu:6-29   ("next" row f2); NaN gradients count as 0 */
+void FN(orc_adam)(R *p, const R *g, R *m, R *v, R lr, R b1, R b2, R eps, R bias1, R bias2, long n) {
+  for (long i = 0; i < n; ++i) {
+    R gr = g[i];
+    if (gr != gr) gr = (R)0;
+    const R mi = b1 * m[i] + ((R)1 - b1) * gr;
+    const R vi = b2 * v[i] + ((R)1 - b2) * gr * gr;
+    const R m_hat = mi / bias1, v_hat = vi / bias2;
+    p[i] += -lr * m_hat / (SQRT(v_hat) + eps);
+    m[i] = mi; v[i] = vi;
+  }
+}
+
 #undef SH_C0
 #undef SH_C1
 #undef SH_C2

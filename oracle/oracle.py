@@ -39,6 +39,9 @@ def lib():
         _LIB.orc_sorted_gaussian_list_f64.restype = ctypes.c_long
         _LIB.orc_effective_instances_f32.restype = ctypes.c_long
         _LIB.orc_effective_instances_f64.restype = ctypes.c_long
+        for n in ("orc_fused_loss", "orc_psnr"):
+            getattr(_LIB, n + "_f32").restype = ctypes.c_float
+            getattr(_LIB, n + "_f64").restype = ctypes.c_double
     return _LIB
 
 
@@ -255,6 +258,30 @@ def scatter_masked_array(src, mask, stride, dst, dtype=np.float32):
         _fn("orc_scatter_masked", dtype)(_p(src if src.size else np.zeros(1, dtype)), _p(mask), len(mask), int(stride),
                                          _p(dst if dst.size else np.zeros(1, dtype)))
     return dst
+
+
+# ------------------------------------------------------------------------- "next" rows f1 / f2
+def fused_loss(pred, gt, ssim_weight, dtype=np.float32, threads=1):
+    """fused_loss (cuda/loss.cu:430-471): returns (loss, image_grad[H,W,3])."""
+    pred, gt = _a(pred, dtype), _a(gt, dtype)
+    H, W = pred.shape[0], pred.shape[1]
+    grad = np.empty_like(pred)
+    loss = _fn("orc_fused_loss", dtype)(_p(pred), _p(gt), H, W, _r(ssim_weight, dtype), _p(grad), int(threads))
+    return float(loss), grad
+
+
+def compute_psnr(pred, gt, dtype=np.float32):
+    pred, gt = _a(pred, dtype), _a(gt, dtype)
+    return float(_fn("orc_psnr", dtype)(_p(pred), _p(gt), pred.shape[0], pred.shape[1]))
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, b1, b2, eps, bias1, bias2, dtype=np.float32):
+    """adam_step (cuda/optimizer.cu:31-44): returns updated (params, exp_avg, exp_avg_sq)."""
+    p, g = _a(params, dtype).copy(), _a(grads, dtype)
+    m, v = _a(exp_avg, dtype).copy(), _a(exp_avg_sq, dtype).copy()
+    _fn("orc_adam", dtype)(_p(p), _p(g), _p(m), _p(v), _r(lr, dtype), _r(b1, dtype), _r(b2, dtype), _r(eps, dtype),
+                           _r(bias1, dtype), _r(bias2, dtype), ctypes.c_long(p.size))
+    return p, m, v
 
 
 # ------------------------------------------------------------------------------ sequencing

@@ -9,6 +9,7 @@
 
 #include "gsplat_cuda/cuda_backward.cuh"
 #include "gsplat_cuda/cuda_forward.cuh"
+#include "gsplat_cuda/optimizer.cuh"
 
 static int failures = 0;
 #define EXPECT_NEAR(a, b, tol)                                                                          \
@@ -89,6 +90,38 @@ int main() {
     render_image_backward(uv, op, conic, rgb, 1.0f, sorted, ranges, n, T, g_img, 16, 16, g_rgb, g_op, g_uv, g_con);
     auto hg = to_host(g_rgb, 9);
     for (int i = 0; i < 9; ++i) EXPECT_NEAR(std::isfinite(hg[i]) && hg[i] > 0.f, 1, 0);
+  }
+  {  // FusedLossKernel_RGB_Correctness (tests/cuda_forward_test.cpp:783-915) + PSNR
+    const int rows = 16, cols = 16;
+    const float vp[3] = {0.5f, 0.4f, 0.1f}, vg[3] = {0.6f, 0.4f, 0.9f};
+    std::vector<float> hp(rows * cols * 3), hg(rows * cols * 3);
+    for (int i = 0; i < rows * cols; ++i)
+      for (int c = 0; c < 3; ++c) { hp[i * 3 + c] = vp[c]; hg[i * 3 + c] = vg[c]; }
+    float *p = to_device(hp), *g = to_device(hg), *grad = to_device<float>(std::vector<float>(rows * cols * 3));
+    const float loss = fused_loss(p, g, rows, cols, 0.2f, grad, 0);
+    EXPECT_NEAR(loss, 0.2931189, 1e-4);
+    auto h = to_host(grad, rows * cols * 3);
+    const float eg[3] = {-0.00113403f, -0.00104167f, -0.00159930f};
+    for (int r = 5; r < rows - 5; ++r)
+      for (int x = 5; x < cols - 5; ++x)
+        for (int c = 0; c < 3; ++c) EXPECT_NEAR(h[(r * cols + x) * 3 + c], eg[c], 1e-6);
+    EXPECT_NEAR(compute_psnr(p, p, rows, cols), 100.0, 0);
+  }
+  {  // AdamOptimizerTest.Correctness (tests/optimizer_test.cpp:104-138)
+    const int N = 1024;
+    const float lr = 0.001f;
+    std::vector<float> hp(N), hg(N), hm(N), hv(N);
+    for (int i = 0; i < N; ++i) {
+      hp[i] = 0.001f * i; hg[i] = std::sin(0.37f * i); hm[i] = 0.05f * std::cos(0.11f * i); hv[i] = 0.01f * (i % 7);
+    }
+    float *p = to_device(hp), *g = to_device(hg), *m = to_device(hm), *v = to_device(hv);
+    adam_step(p, g, m, v, lr, B1, B2, EPS, 1.0f - B1, 1.0f - B2, N, 1);
+    auto op = to_host(p, N), om = to_host(m, N), ov = to_host(v, N);
+    for (int i = 0; i < N; ++i) {
+      const float ea = B1 * hm[i] + (1.0f - B1) * hg[i], es = B2 * hv[i] + (1.0f - B2) * hg[i] * hg[i];
+      const float step = -lr * (ea / (1.0f - B1)) / (std::sqrt(es / (1.0f - B2)) + EPS);
+      EXPECT_NEAR(op[i], hp[i] + step, 1e-6); EXPECT_NEAR(om[i], ea, 1e-6); EXPECT_NEAR(ov[i], es, 1e-6);
+    }
   }
   (void)hipDeviceSynchronize();
   if (failures == 0) std::printf("shim_test: all checks passed\n");

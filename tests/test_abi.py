@@ -17,7 +17,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib_mod.build()
     lib = lib_mod.load()
     names = _declared()
-    assert len(names) >= 27
+    assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gsplat_hip.h but not exported"
     assert set(names) == set(lib_mod.SIGNATURES), "python binding and header disagree"
@@ -38,4 +38,8 @@ def test_shim_headers_keep_reference_signatures():
               "compute_projection_jacobian_backward", "compute_conic_backward", "compute_sigma_backward",
               "precompute_spherical_harmonics_backward", "render_image_backward"]:
         assert re.search(r"\b%s\s*\(" % n, bwd), n
+    opt = open(os.path.join(ROOT, "include", "gsplat_cuda", "optimizer.cuh")).read()
+    for n in ["fused_loss", "compute_psnr"]:  # "next" row f1 (reference cuda_forward.cuh:144-156)
+        assert re.search(r"\b%s\s*\(" % n, fwd), n
+    assert re.search(r"\badam_step\s*\(", opt) and "B1 = 0.9f" in opt and "EPS = 1e-8f" in opt
     assert "TILE_SIZE_FWD = 16" in fwd and "TILE_SIZE_BWD = 16" in bwd
