@@ -66,6 +66,14 @@ class Gradients(ctypes.Structure):  # gsplat_gradients
                  "grad_uv", "grad_J", "grad_sigma", "grad_xyz_c", "grad_precompute_rgb")]
 
 
+class AdamGroup(ctypes.Structure):  # gsplat_adam_group
+    _fields_ = [("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("grad", ctypes.c_void_p), ("stride", ctypes.c_int), ("packed_column", ctypes.c_int),
+                ("lr", ctypes.c_float)]
+
+
+MAX_ADAM_GROUPS = 8
+
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 SIGNATURES = {
@@ -90,6 +98,8 @@ SIGNATURES = {
     "gsplat_fused_loss": (_I, [_P, _P, _I, _I, _F, _P, ctypes.POINTER(ctypes.c_float), _P]),
     "gsplat_compute_psnr": (_I, [_P, _P, _I, _I, ctypes.POINTER(ctypes.c_float), _P]),
     "gsplat_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P]),
+    "gsplat_optimizer_step": (_I, [_P, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "gsplat_optimizer_step_packed": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _P]),
     "gsplat_compact_masked_array": (_I, [_P, _P, _I, _I, _P, ctypes.POINTER(_I), _P]),
     "gsplat_scatter_masked_array": (_I, [_P, _P, _I, _I, _P, _P]),
     "gsplat_context_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),

@@ -193,6 +193,89 @@ __global__ __launch_bounds__(256) void adam_kernel(long long n, float *__restric
   v[i] = vi;
 }
 
+// ---- masked in-place optimizer step (replaces the ~35 compact/scatter calls of TrainerImpl::optimizer_step,
+// cuda/trainer.cu:1027-1158: only gaussians visible in the view are touched, everything else keeps its moments).
+struct GroupTable {
+  gsplat_adam_group g[GSPLAT_MAX_ADAM_GROUPS];
+  int start[GSPLAT_MAX_ADAM_GROUPS + 1];  // prefix of strides
+  int n;
+};
+
+__device__ __forceinline__ void adam_update(float *param, float *m, float *v, float g, float lr, float b1, float b2,
+                                            float eps, float bias1, float bias2) {
+  if (g != g) g = 0.0f;
+  const float mi = b1 * *m + (1.0f - b1) * g;
+  const float vi = b2 * *v + (1.0f - b2) * g * g;
+  const float m_hat = mi / bias1, v_hat = vi / bias2;
+  *param += -lr * m_hat / (sqrtf(v_hat) + eps);
+  *m = mi;
+  *v = vi;
+}
+
+// kPacked = false: grads are compacted [M,stride] arrays and c2g maps compacted -> global rows.
+// kPacked = true : grads are rows of the packed global layout; a row is live when its last column (views that saw
+//                  the gaussian) is positive.
+template <bool kPacked>
+__global__ __launch_bounds__(256) void optimizer_step_kernel(long long total, GroupTable t,
+                                                             const int *__restrict__ c2g,
+                                                             const float *__restrict__ packed, int width, float b1,
+                                                             float b2, float eps, float bias1, float bias2,
+                                                             const float *__restrict__ grad_uv,
+                                                             float *__restrict__ uv_accum, int *__restrict__ accum_dur) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int per = t.start[t.n];
+  const long long r = idx / per;
+  const int e = (int)(idx - r * per);
+  long long row;
+  if (kPacked) {
+    row = r;
+    if (!(packed[r * width + width - 1] > 0.0f)) return;
+  } else {
+    row = c2g[r];
+  }
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < GSPLAT_MAX_ADAM_GROUPS; ++q) k += (q < t.n && e >= t.start[q]) ? 1 : 0;
+  const gsplat_adam_group &G = t.g[k];
+  const int c = e - t.start[k];
+  const float g = kPacked ? packed[r * width + G.packed_column + c] : G.grad[r * G.stride + c];
+  const long long o = row * G.stride + c;
+  adam_update(&G.param[o], &G.exp_avg[o], &G.exp_avg_sq[o], g, G.lr, b1, b2, eps, bias1, bias2);
+  if (!kPacked && e == 0) {  // densification statistics, cuda/trainer.cu:1136-1157
+    if (uv_accum) {
+      const float u = grad_uv[2 * r], v = grad_uv[2 * r + 1];
+      uv_accum[row] += sqrtf(u * u + v * v);
+    }
+    if (accum_dur) accum_dur[row] += 1;
+  }
+}
+
+int build_group_table(const gsplat_adam_group *groups, int n_groups, bool packed, GroupTable *t, const char *fn) {
+  if (!groups || n_groups < 1 || n_groups > GSPLAT_MAX_ADAM_GROUPS) {
+    gs::set_error("%s: invalid argument: need 1..%d parameter groups", fn, GSPLAT_MAX_ADAM_GROUPS);
+    return GSPLAT_ERR_INVALID_ARG;
+  }
+  t->n = n_groups;
+  t->start[0] = 0;
+  for (int k = 0; k < n_groups; ++k) {
+    const gsplat_adam_group &g = groups[k];
+    if (g.stride < 1 || (packed && g.packed_column < 0)) {
+      gs::set_error("%s: invalid argument: group %d has a bad stride/column", fn, k);
+      return GSPLAT_ERR_INVALID_ARG;
+    }
+    int st;
+    if ((st = gs::check_device_ptr(g.param, "group.param", fn)) || (st = gs::check_device_ptr(g.exp_avg, "group.exp_avg", fn)) ||
+        (st = gs::check_device_ptr(g.exp_avg_sq, "group.exp_avg_sq", fn)))
+      return st;
+    if (!packed && (st = gs::check_device_ptr(g.grad, "group.grad", fn))) return st;
+    t->g[k] = g;
+    t->start[k + 1] = t->start[k] + g.stride;
+  }
+  for (int k = n_groups; k < GSPLAT_MAX_ADAM_GROUPS; ++k) t->start[k + 1] = t->start[n_groups];
+  return GSPLAT_OK;
+}
+
 int read_spread_sum(float *d_acc, hipStream_t st, double *out) {
   int rc = gs::host_words().ensure();
   if (rc) return rc;
@@ -269,6 +352,41 @@ int gsplat_adam_step(float *params, const float *param_grads, float *exp_avg, fl
   if (n == 0) return GSPLAT_OK;
   adam_kernel<<<gs::div_up(n, 256), 256, 0, (hipStream_t)stream>>>(n, params, param_grads, exp_avg, exp_avg_sq, lr, b1,
                                                                   b2, eps, bias1, bias2);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gsplat_adam_group *groups, int n_groups,
+                          float b1, float b2, float eps, float bias1, float bias2, const float *grad_uv,
+                          float *uv_grad_accum, int *grad_accum_dur, void *stream) {
+  GS_REQUIRE(num_culled >= 0, "negative gaussian count");
+  GroupTable t;
+  int rc = build_group_table(groups, n_groups, false, &t, __func__);
+  if (rc) return rc;
+  if (num_culled == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(compact_to_global);
+  if (uv_grad_accum) { GS_REQUIRE_DEV(uv_grad_accum); GS_REQUIRE_DEV(grad_uv); }
+  if (grad_accum_dur) GS_REQUIRE_DEV(grad_accum_dur);
+  const long long total = (long long)num_culled * t.start[t.n];
+  optimizer_step_kernel<false><<<gs::div_up(total, 256), 256, 0, (hipStream_t)stream>>>(
+      total, t, compact_to_global, nullptr, 0, b1, b2, eps, bias1, bias2, grad_uv, uv_grad_accum, grad_accum_dur);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int width, const gsplat_adam_group *groups,
+                                 int n_groups, float b1, float b2, float eps, float bias1, float bias2, void *stream) {
+  GS_REQUIRE(num_gaussians >= 0, "negative gaussian count");
+  GroupTable t;
+  int rc = build_group_table(groups, n_groups, true, &t, __func__);
+  if (rc) return rc;
+  for (int k = 0; k < n_groups; ++k)
+    GS_REQUIRE(groups[k].packed_column + groups[k].stride <= width - 1, "group columns exceed the packed row");
+  if (num_gaussians == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(packed);
+  const long long total = (long long)num_gaussians * t.start[t.n];
+  optimizer_step_kernel<true><<<gs::div_up(total, 256), 256, 0, (hipStream_t)stream>>>(
+      total, t, nullptr, packed, width, b1, b2, eps, bias1, bias2, nullptr, nullptr, nullptr);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

@@ -1,0 +1,91 @@
+"""Host-side mirror of the reference's optimizer step (TrainerImpl::optimizer_step, cuda/trainer.cu:1027-1158;
+constants include/gsplat_cuda/optimizer.cuh:9-11) on top of the C ABI's masked in-place Adam.
+
+The reference compacts every parameter group and both of its moments by the view's mask, calls adam_step on the
+copies and scatters them back.  Here the moments live in global order next to the parameters and one kernel updates
+the visible rows in place; `step` takes the compacted gradients of one view, `step_packed` the all-reduced packed rows
+of a view-sharded step (3dgs_amd/dist.py).  There is no CPU fallback: without the HIP library these calls raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .dist import packed_layout
+from .ops import check
+
+B1, B2, EPS = 0.9, 0.999, 1e-8  # include/gsplat_cuda/optimizer.cuh:9-11
+
+GROUPS = ("xyz", "rgb", "sh", "opacity", "scale", "quaternion")
+
+# config/base.yaml of the reference (learning-rate multipliers of ConfigParameters)
+DEFAULT_LR = dict(base_lr=1e-3, xyz_lr_multiplier_init=1.6e-1, xyz_lr_multiplier_final=1.6e-3, quat_lr_multiplier=1.0,
+                  scale_lr_multiplier=5.0, opacity_lr_multiplier=25.0, rgb_lr_multiplier=2.5, sh_lr_multiplier=0.125,
+                  num_iters=7000)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class AdamOptimizer:
+    """Adam state (exp_avg / exp_avg_sq per group, global order) + densification accumulators.
+
+    params: dict name -> device tensor [N, stride] (xyz rgb sh opacity scale quaternion); updated in place."""
+
+    def __init__(self, params, l_max, lr_config=None, scene_extent=1.0):
+        self.params, self.l_max = params, l_max
+        self.cfg = dict(DEFAULT_LR, **(lr_config or {}))
+        self.scene_extent = float(scene_extent)
+        self.names = [g for g in GROUPS if not (g == "sh" and l_max == 0)]
+        self.exp_avg = {g: torch.zeros_like(params[g]) for g in self.names}
+        self.exp_avg_sq = {g: torch.zeros_like(params[g]) for g in self.names}
+        n = params["xyz"].shape[0]
+        self.uv_grad_accum = torch.zeros(n, device=params["xyz"].device)       # OptimizerAccumulators
+        self.grad_accum_dur = torch.zeros(n, dtype=torch.int32, device=params["xyz"].device)
+        self.cols, self.width = packed_layout(l_max)
+
+    def learning_rates(self, it):
+        """Per-group rates at iteration `it` (cuda/trainer.cu:1049-1071)."""
+        c = self.cfg
+        decay = (c["xyz_lr_multiplier_final"] / c["xyz_lr_multiplier_init"]) ** (float(it) / float(c["num_iters"]))
+        return dict(xyz=self.scene_extent * c["base_lr"] * c["xyz_lr_multiplier_init"] * decay,
+                    rgb=c["base_lr"] * c["rgb_lr_multiplier"], sh=c["base_lr"] * c["sh_lr_multiplier"],
+                    opacity=c["base_lr"] * c["opacity_lr_multiplier"], scale=c["base_lr"] * c["scale_lr_multiplier"],
+                    quaternion=c["base_lr"] * c["quat_lr_multiplier"])
+
+    @staticmethod
+    def bias_corrections(it):
+        return 1.0 - B1 ** (it + 1), 1.0 - B2 ** (it + 1)  # cuda/trainer.cu:1046-1047
+
+    def _groups(self, it, grads=None):
+        lrs = self.learning_rates(it)
+        arr = (_lib.AdamGroup * len(self.names))()
+        for k, g in enumerate(self.names):
+            p = self.params[g]
+            stride = self.cols[g][1] - self.cols[g][0]
+            arr[k].param, arr[k].exp_avg, arr[k].exp_avg_sq = p.data_ptr(), self.exp_avg[g].data_ptr(), self.exp_avg_sq[g].data_ptr()
+            arr[k].grad = grads[g].data_ptr() if grads is not None else None
+            arr[k].stride, arr[k].packed_column, arr[k].lr = stride, self.cols[g][0], lrs[g]
+        return arr
+
+    def step(self, it, fwd, grads):
+        """One view: `fwd` is the dict RasterContext.rasterize_image returned, `grads` the dict filled by
+        backward_pass (compacted order).  When grads carries the "uv" intermediate the densification statistics
+        (uv_grad_accum, grad_accum_dur) are updated as the reference does."""
+        b1c, b2c = self.bias_corrections(it)
+        arr = self._groups(it, grads)
+        uv = grads.get("uv")
+        check(_lib.load().gsplat_optimizer_step(
+            fwd["compact_to_global"].data_ptr() if fwd["num_culled"] else None, int(fwd["num_culled"]), arr,
+            len(self.names), B1, B2, EPS, b1c, b2c, uv.data_ptr() if uv is not None else None,
+            self.uv_grad_accum.data_ptr() if uv is not None else None,
+            self.grad_accum_dur.data_ptr() if uv is not None else None, _stream()))
+
+    def step_packed(self, it, packed):
+        """All-reduced packed rows [N, width] (sum over the views of the step)."""
+        assert packed.shape[1] == self.width and packed.is_contiguous()
+        b1c, b2c = self.bias_corrections(it)
+        arr = self._groups(it)
+        check(_lib.load().gsplat_optimizer_step_packed(packed.data_ptr(), packed.shape[0], self.width, arr,
+                                                       len(self.names), B1, B2, EPS, b1c, b2c, _stream()))

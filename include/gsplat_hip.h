@@ -158,6 +158,34 @@ int gsplat_compute_psnr(const float *predicted_data, const float *gt_data, int r
 int gsplat_adam_step(float *params, const float *param_grads, float *exp_avg, float *exp_avg_sq, float lr, float b1,
                      float b2, float eps, float bias1, float bias2, int N, int S, void *stream);
 
+/* One Adam parameter group: global-order parameter and moment arrays [N,stride] and its learning rate. */
+#define GSPLAT_MAX_ADAM_GROUPS 8
+typedef struct gsplat_adam_group {
+  float *param;             /* [N,stride] device, updated in place                                  */
+  float *exp_avg;           /* [N,stride] device, first moment                                      */
+  float *exp_avg_sq;        /* [N,stride] device, second moment                                     */
+  const float *grad;        /* [M,stride] device, compacted order (gsplat_optimizer_step only)      */
+  int stride;
+  int packed_column;        /* first column in a packed row (gsplat_optimizer_step_packed only)     */
+  float lr;
+} gsplat_adam_group;
+
+/* replaces TrainerImpl::optimizer_step  (cuda/trainer.cu:1027-1158): the reference compacts parameters and both
+ * moments of every group by the view's mask, runs adam_step on the compacted copies and scatters them back
+ * (~35 thrust passes).  Here one kernel updates the visible rows in place through compact_to_global
+ * (gsplat_forward_view.compact_to_global, length num_culled); rows the view did not see keep their moments.
+ * If uv_grad_accum / grad_accum_dur are non-NULL the densification statistics of trainer.cu:1136-1157 are
+ * updated too: uv_grad_accum[i] += |grad_uv[r]|, grad_accum_dur[i] += 1. */
+int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gsplat_adam_group *groups, int n_groups,
+                          float b1, float b2, float eps, float bias1, float bias2, const float *grad_uv,
+                          float *uv_grad_accum, int *grad_accum_dur, void *stream);
+
+/* Multi-view variant: gradients are rows of the all-reduced packed layout
+ * (gsplat_pack_gradients_global / gsplat_unpack_gradients_factored, row width `width`, last column = number of
+ * views that saw the gaussian); rows with a zero count are skipped, which is the union of the per-view masks. */
+int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int width, const gsplat_adam_group *groups,
+                                 int n_groups, float b1, float b2, float eps, float bias1, float bias2, void *stream);
+
 /* ------------------------------------------------------------- compaction templates --- */
 
 /* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]

@@ -1,0 +1,132 @@
+"""GPU tests of the "next" row f2 choreography: the masked in-place optimizer step (gsplat_optimizer_step[_packed])
+against the reference's compact -> adam_step -> scatter sequence (cuda/trainer.cu:1027-1158) restated with the
+oracle's adam_step on numpy-compacted arrays, and a short end-to-end training run
+(rasterize -> fused_loss -> backward_pass -> optimizer step) whose loss must fall."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+GROUPS = ("xyz", "rgb", "sh", "opacity", "scale", "quaternion")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _forward_backward(torch, scene, name="small", view_index=0):
+    raster = pkg("raster")
+    N, W, H, L, _ = scene.WORKLOADS[name]
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::3, 2] *= -1  # a third of the scene sits behind the camera: those rows must not be touched
+    cam = scene.make_camera(W, H, view_index)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    grads = ctx.alloc_gradients(fwd["num_culled"], L, intermediates=True)
+    ctx.backward_pass(dp, dc, torch.as_tensor(scene.make_grad_image(W, H)).cuda(), c["bg"], L, grads)
+    torch.cuda.synchronize()
+    return dict(params=params, dp=dp, dc=dc, ctx=ctx, fwd=fwd, grads=grads, N=N, W=W, H=H, L=L)
+
+
+def _reference_choreography(orc, opt_mod, r, it, m0, v0, lrs):
+    """compact by mask -> adam_step -> scatter, per group, on the CPU oracle."""
+    mask = _np(r["fwd"]["mask"]).astype(bool)
+    b1c, b2c = opt_mod.AdamOptimizer.bias_corrections(it)
+    out = {}
+    for g in GROUPS:
+        p = _np(r["dp"][g]).reshape(r["N"], -1).copy()
+        m, v = m0[g].copy(), v0[g].copy()
+        grad = _np(r["grads"][g]).reshape(int(mask.sum()), -1)
+        pc, mc, vc = orc.adam_step(p[mask], grad, m[mask], v[mask], np.float32(lrs[g]), np.float32(opt_mod.B1),
+                                   np.float32(opt_mod.B2), np.float32(opt_mod.EPS), np.float32(b1c), np.float32(b2c))
+        p[mask], m[mask], v[mask] = pc.reshape(grad.shape), mc.reshape(grad.shape), vc.reshape(grad.shape)
+        out[g] = (p, m, v)
+    return out, mask
+
+
+def test_optimizer_step_matches_compact_adam_scatter(gpu, scene, orc):
+    torch, opt_mod = gpu, pkg("optimizer")
+    r = _forward_backward(torch, scene, "small", view_index=1)
+    opt = opt_mod.AdamOptimizer(r["dp"], r["L"], scene_extent=2.5)
+    rng = np.random.default_rng(0)
+    m0 = {g: (rng.standard_normal((r["N"], opt.cols[g][1] - opt.cols[g][0])) * 1e-4).astype(np.float32) for g in GROUPS}
+    v0 = {g: (rng.random((r["N"], opt.cols[g][1] - opt.cols[g][0])) * 1e-8).astype(np.float32) for g in GROUPS}
+    for g in GROUPS:
+        opt.exp_avg[g].copy_(torch.from_numpy(m0[g]).reshape(opt.exp_avg[g].shape))
+        opt.exp_avg_sq[g].copy_(torch.from_numpy(v0[g]).reshape(opt.exp_avg_sq[g].shape))
+    it = 37
+    ref, mask = _reference_choreography(orc, opt_mod, r, it, m0, v0, opt.learning_rates(it))
+    uv_norm = np.sqrt((_np(r["grads"]["uv"]) ** 2).sum(1))
+    opt.step(it, r["fwd"], r["grads"])
+    torch.cuda.synchronize()
+    assert 0 < mask.sum() < r["N"]  # the view must leave some rows untouched for the test to mean anything
+    for g in GROUPS:
+        p, m, v = ref[g]
+        np.testing.assert_allclose(_np(opt.exp_avg[g]).reshape(p.shape), m, rtol=2e-6, atol=1e-12, err_msg=g)
+        np.testing.assert_allclose(_np(opt.exp_avg_sq[g]).reshape(p.shape), v, rtol=2e-6, atol=1e-20, err_msg=g)
+        np.testing.assert_allclose(_np(r["dp"][g]).reshape(p.shape), p, rtol=2e-6, atol=1e-7, err_msg=g)
+        # rows the view did not see are bit-identical to the start
+        assert (_np(opt.exp_avg[g]).reshape(p.shape)[~mask] == m0[g][~mask]).all()
+    acc, dur = _np(opt.uv_grad_accum), _np(opt.grad_accum_dur)
+    np.testing.assert_allclose(acc[mask], uv_norm, rtol=1e-6)
+    assert (acc[~mask] == 0).all() and (dur == mask.astype(np.int32)).all()
+
+
+def test_packed_step_equals_single_view_step(gpu, scene):
+    """With one view the packed (all-reduced) route must update exactly what the compacted route updates."""
+    torch, opt_mod = gpu, pkg("optimizer")
+    a = _forward_backward(torch, scene, "small", view_index=2)
+    twin = {k: v.clone() for k, v in a["dp"].items()}  # same gradients for both routes (atomics reorder between runs)
+    oa, ob = opt_mod.AdamOptimizer(a["dp"], a["L"]), opt_mod.AdamOptimizer(twin, a["L"])
+    packed = torch.empty(a["N"], ob.width, device="cuda")
+    a["ctx"].pack_gradients_global(a["grads"], a["L"], a["N"], packed)
+    oa.step(5, a["fwd"], a["grads"])
+    ob.step_packed(5, packed)
+    torch.cuda.synchronize()
+    assert not torch.equal(oa.exp_avg["xyz"], torch.zeros_like(oa.exp_avg["xyz"]))
+    for g in GROUPS:
+        assert torch.equal(a["dp"][g], twin[g]), g
+        assert torch.equal(oa.exp_avg[g], ob.exp_avg[g]) and torch.equal(oa.exp_avg_sq[g], ob.exp_avg_sq[g]), g
+
+
+def test_training_iterations_reduce_the_loss(gpu, scene):
+    """rasterize -> fused_loss -> backward -> optimizer step, 30 iterations on one view toward a target rendered
+    from the unperturbed scene: the L1+SSIM loss must drop and PSNR must rise (reference loop: trainer.cu:417-516)."""
+    torch, raster, ops, opt_mod = gpu, pkg("raster"), pkg("ops"), pkg("optimizer")
+    N, W, H, L, _ = scene.WORKLOADS["small"]
+    c = scene.CONFIG
+    truth = scene.make_gaussians(N, W, H, L)
+    cam = raster.device_camera(scene.make_camera(W, H, 0))
+    ctx = raster.RasterContext(N, W, H)
+    target = ctx.rasterize_image(raster.device_params(truth), cam, c, c["bg"], L)["image"].clone()
+    start = {k: np.array(v, copy=True) for k, v in truth.items()}
+    rng = np.random.default_rng(1)
+    start["rgb"] = start["rgb"] + rng.normal(0, 0.5, start["rgb"].shape).astype(np.float32)
+    start["opacity"] = start["opacity"] + rng.normal(0, 0.5, start["opacity"].shape).astype(np.float32)
+    dp = raster.device_params(start)
+    opt = opt_mod.AdamOptimizer(dp, L, scene_extent=1.0)
+    grad_image = torch.empty(H, W, 3, device="cuda")
+    losses, psnrs = [], []
+    for it in range(30):
+        fwd = ctx.rasterize_image(dp, cam, c, c["bg"], L)
+        losses.append(ops.fused_loss(fwd["image"], target, H, W, 0.2, grad_image))
+        psnrs.append(ops.compute_psnr(fwd["image"], target, H, W))
+        grads = ctx.alloc_gradients(fwd["num_culled"], L, intermediates=True)
+        ctx.backward_pass(dp, cam, grad_image, c["bg"], L, grads)
+        opt.step(it, fwd, grads)
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.7 * losses[0], losses
+    assert psnrs[-1] > psnrs[0] + 1.0, psnrs
+
+
+def test_optimizer_argument_errors(gpu, scene):
+    torch, opt_mod, lib_mod = gpu, pkg("optimizer"), pkg("_lib")
+    lib = lib_mod.load()
+    grp = (lib_mod.AdamGroup * 1)()
+    assert lib.gsplat_optimizer_step(None, 0, grp, 0, 0.9, 0.999, 1e-8, 0.1, 0.001, None, None, None, None) == -3
+    assert lib.gsplat_optimizer_step(None, 4, grp, 1, 0.9, 0.999, 1e-8, 0.1, 0.001, None, None, None, None) == -3  # stride 0
+    grp[0].stride = 3
+    assert lib.gsplat_optimizer_step(None, 4, grp, 1, 0.9, 0.999, 1e-8, 0.1, 0.001, None, None, None, None) == -1  # NULL param
