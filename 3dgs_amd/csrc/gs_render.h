@@ -14,7 +14,7 @@ constexpr float kTMin = 0.0001f;             // cuda/render.cu:77
 //   r0 = {u, v, conic00, conic01}
 //   r1 = {conic11, sigmoid(opacity), hx, hy}   hx/hy: half extents of the axis-aligned box that
 //                                              contains every pixel centre with alpha >= 1/255
-//   r2 = {r, g, b, <quadrant hit bits, filled per tile>}
+//   r2 = {r, g, b, <16 block-hit bits, filled per tile>}
 struct SplatRec { float4 r0, r1, r2; };
 
 __device__ __forceinline__ float sigmoid_fast(float logit) { return 1.0f / (1.0f + __expf(-logit)); }
@@ -51,16 +51,20 @@ __device__ __forceinline__ SplatRec make_record(float u, float v, float a, float
   return s;
 }
 
-// 4-bit mask: bit q set when the footprint box may touch 8x8 quadrant q of the tile whose
+// 16-bit mask: bit (4*by + bx) set when the footprint box may touch the 4x4 pixel block (bx, by) of the tile whose
 // first pixel is (x0, y0).  Written so that any NaN makes the test pass.
-__device__ __forceinline__ unsigned int quadrant_hits(const SplatRec &s, float x0, float y0) {
+__device__ __forceinline__ unsigned int subblock_hits(const SplatRec &s, float x0, float y0) {
   const float u = s.r0.x, v = s.r0.y, hx = s.r1.z, hy = s.r1.w;
   const float lo_x = u - hx, hi_x = u + hx, lo_y = v - hy, hi_y = v + hy;
-  const bool xl = !(hi_x < x0) && !(lo_x > x0 + 7.0f);
-  const bool xr = !(hi_x < x0 + 8.0f) && !(lo_x > x0 + 15.0f);
-  const bool yt = !(hi_y < y0) && !(lo_y > y0 + 7.0f);
-  const bool yb = !(hi_y < y0 + 8.0f) && !(lo_y > y0 + 15.0f);
-  return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+  unsigned int xm = 0u, ym = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float o = 4.0f * (float)k;
+    xm |= (!(hi_x < x0 + o) && !(lo_x > x0 + o + 3.0f)) ? (1u << k) : 0u;
+    ym |= (!(hi_y < y0 + o) && !(lo_y > y0 + o + 3.0f)) ? (1u << k) : 0u;
+  }
+  const unsigned int ys = (ym | (ym << 3) | (ym << 6) | (ym << 9)) & 0x1111u;  // bit k -> bit 4k
+  return ys * xm;
 }
 
 // exponent of the gaussian at offset (dx, dy) = (u - px, v - py); 2 FMAs on purpose
@@ -72,22 +76,7 @@ __device__ __forceinline__ float gauss_power(float a, float b, float c, float dx
   return __builtin_fmaf(-bx, dy, -0.5f * t);
 }
 
-// ---- wave64 reduction of NINE values at once.
-// A plain butterfly costs 6 DPP adds per value (54).  Here the values are folded pairwise while the lane groups
-// halve: v_permlane32_swap exchanges the upper half of one register with the lower half of another, so ONE swap +
-// ONE add turns two registers into one that holds the half-wave sums of both values (gfx950 only); the same with
-// v_permlane16_swap across 16-lane rows; the last four steps stay inside a row on DPP.  28 VALU instead of 54.
-// Result: in a lane of row r (= lane >> 4), q0 holds the total of value {0,2,1,3}[r], q1 of value {4,6,5,7}[r],
-// and q2 (row 0 only) of value 8.
-typedef unsigned int gs_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float fold32(float a, float b) {
-  const gs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float fold16(float a, float b) {
-  const gs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
+// ---- DPP helpers
 template <int kCtrl>
 __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false);
@@ -100,25 +89,59 @@ __device__ __forceinline__ float row_sum(float v) {  // every lane of a 16-lane 
   v = dpp_add<0x140>(v);  // row_mirror
   return v;
 }
-struct Sum9 { float q0, q1, q2; };
-__device__ __forceinline__ Sum9 wave_sum9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+// ---- row-level (16 lanes) reduction of NINE values at once, for kernels where every 16-lane row works on its own
+// (gaussian, 4x4 pixel block) pair.  Transposed butterfly: the two stages that pair lanes 4 and 8 apart fold two
+// registers into one with TWO full-rate DPP adds (the second writes only the banks = 4-lane groups that keep the
+// other value, via bank_mask), the two stages inside a quad use a select pair + one DPP add.  21 VALU, no
+// v_permlane, and the nine row totals end up in nine different lanes of ONE register, so one ds_add_f32 adds
+// all of them.  Lane j of a row (bits b3 b2 b1 b0): b1 == 0 -> total of value 4*b0 + 2*b3 + b2; b1 == 1 -> value 8.
+// The block schedules its own DPP hazards (a VGPR written by VALU may be read by a DPP source operand only two
+// instructions later): the leading s_nop covers the inputs, the ordering covers the rest.
+__device__ __forceinline__ float row_sum9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                           float v7, float v8) {
-  const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7);
-  const float r4 = fold32(v8, 0.0f);
-  Sum9 s;
-  s.q0 = row_sum(fold16(r0, r1));
-  s.q1 = row_sum(fold16(r2, r3));
-  s.q2 = row_sum(fold16(r4, 0.0f));
-  return s;
+  float r0, r1, r2, r3, r4, q0, q1, q2, snd, kp, m0, out;
+  const unsigned long long odd = 0xAAAAAAAAAAAAAAAAull, bit1 = 0xCCCCCCCCCCCCCCCCull;
+  asm volatile(
+      "s_nop 1\n\t"
+      // stage A: lanes 4 apart (lane bit 2): banks 0,2 keep the even value, banks 1,3 the odd one
+      "v_add_f32_dpp %[r0], %[v0], %[v0] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r0], %[v1], %[v1] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r1], %[v2], %[v2] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r1], %[v3], %[v3] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r2], %[v4], %[v4] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r2], %[v5], %[v5] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r3], %[v6], %[v6] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r3], %[v7], %[v7] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r4], %[v8], %[v8] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r4], %[v8], %[v8] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      // stage B: lanes 8 apart (lane bit 3): banks 0,1 keep the even register, banks 2,3 the odd one
+      "v_add_f32_dpp %[q0], %[r0], %[r0] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[q0], %[r1], %[r1] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[q1], %[r2], %[r2] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[q1], %[r3], %[r3] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[q2], %[r4], %[r4] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[q2], %[r4], %[r4] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      // stage C: lane bit 0: even lanes keep q0, odd lanes q1; q2 is summed in place
+      "v_cndmask_b32_e64 %[snd], %[q1], %[q0], %[odd]\n\t"
+      "v_cndmask_b32_e64 %[kp], %[q0], %[q1], %[odd]\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %[r0], %[q2], %[q2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %[m0], %[snd], %[kp] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      // stage D: lane bit 1: lanes with the bit clear keep m0 (values 0..7), the others value 8
+      "v_cndmask_b32_e64 %[snd], %[r0], %[m0], %[bit1]\n\t"
+      "v_cndmask_b32_e64 %[kp], %[m0], %[r0], %[bit1]\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %[out], %[snd], %[kp] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [q0] "=&v"(q0),
+        [q1] "=&v"(q1), [q2] "=&v"(q2), [snd] "=&v"(snd), [kp] "=&v"(kp), [m0] "=&v"(m0), [out] "=&v"(out)
+      : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [v4] "v"(v4), [v5] "v"(v5), [v6] "v"(v6),
+        [v7] "v"(v7), [v8] "v"(v8), [odd] "s"(odd), [bit1] "s"(bit1));
+  return out;
 }
-// which of the nine values a lane's q0 / q1 holds
-__device__ __forceinline__ int sum9_index_q0(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }
-__device__ __forceinline__ int sum9_index_q1(int lane) { return 4 + ((lane >> 4) & 1) * 2 + (lane >> 5); }
-__device__ __forceinline__ int wave_max_int(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
+__device__ __host__ __forceinline__ int row_sum9_index(int lane) {
+  return (lane & 2) ? 8 : 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
 }
+__device__ __host__ __forceinline__ bool row_sum9_active(int lane) { return !(lane & 2) || (lane & 15) == 2; }
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
 // neighbouring tiles (which share gaussians) hit the same L2.  Returns >= num_tiles for the

@@ -6,22 +6,36 @@
 // walks the list back to front rebuilding T and the colour behind each splat.
 //
 // Design (not the reference's one-warp-per-tile, 8-pixels-per-lane layout):
-//   * one 256-thread workgroup per tile = four wave64s, each owning one 8x8 pixel quadrant,
+//   * one 256-thread workgroup per tile = four wave64s; every 16-lane ROW of a wave owns one 4x4 pixel block,
 //     one pixel per lane;
-//   * the tile's list is consumed in batches of 256 entries: every thread gathers ONE
-//     gaussian (three 16-byte loads of a 48-byte record, or the reference's four arrays),
-//     evaluates sigmoid(opacity) and a conservative footprint box once, and parks it in LDS;
-//   * each wave ballots the batch's quadrant-hit bits into a 64-bit scalar mask and only
-//     visits gaussians whose footprint can reach its quadrant (skipping is exact: a skipped
-//     gaussian has alpha < 1/255 on every pixel of the quadrant); visited gaussians are read
-//     from LDS at a wave-uniform address (broadcast);
-//   * forward: a wave stops as soon as all 64 pixels are saturated, the workgroup when all
-//     four waves have;
-//   * backward: nine partial sums per (wave, gaussian) are reduced across the wave on DPP,
-//     merged across the four waves in LDS, and flushed once per batch to HBM as whole
-//     64-byte gradient rows (or into the reference's four gradient arrays).
+//   * the tile's list is consumed in batches of 256 entries: every thread gathers ONE gaussian (three 16-byte
+//     loads of a 48-byte record, or the reference's four arrays), evaluates sigmoid(opacity) and a conservative
+//     footprint box once, computes which of the tile's 16 blocks the box reaches, and parks it in LDS;
+//   * each wave compacts, per row, the batch's slots that hit the row's block into a byte list in LDS, and every
+//     row walks ITS OWN list: in one loop trip the four rows of a wave work on four different (gaussian, block)
+//     pairs and a wave's trip count is the longest of its four lists -- on the benchmark scene 1.37x fewer trips
+//     than visiting (gaussian, 8x8 quadrant) pairs (tools/model_trips.py).  Skipping is exact: a skipped gaussian
+//     has alpha < 1/255 on every pixel of the block;
+//   * forward: a row whose 16 pixels are saturated gets no list, a wave stops when its 64 pixels are saturated, the
+//     workgroup when all four waves have;
+//   * backward: the nine partial sums of a (gaussian, block) pair are reduced across the row's 16 lanes only
+//     (gs::row_sum9: 21 full-rate VALU, the nine totals land in nine lanes of one register), merged across the
+//     tile's blocks with ONE ds_add_f64 per trip, and flushed once per batch to HBM as whole 64-byte gradient rows
+//     (or into the reference's four gradient arrays).
 #include "gs_common.h"
 #include "gs_render.h"
+
+#include <cstdlib>
+
+#ifndef GS_ABLATE
+#define GS_ABLATE 0
+#endif
+// Backward batch size: 128 slots keep the block at ~21 KB of LDS (records 6 KB, f64 accumulators 10 KB, lists 4 KB),
+// so the kernel stays VGPR-limited at 6 waves/SIMD; 256 slots (41 KB, 3 blocks/CU) measured 0.76 ms vs 0.57 ms,
+// 64 slots 0.63 ms (twice the barriers).
+#ifndef GS_BWD_BATCH
+#define GS_BWD_BATCH 128
+#endif
 
 namespace gs {
 
@@ -43,25 +57,72 @@ __device__ __forceinline__ SplatRec load_record(int g, const float4 *__restrict_
   }
 }
 
-// ------------------------------------------------------------------------------ forward
+struct GradOut {         // either whole rows ...
+  float *rows;           // [M,16]: rgb3 opacity1 conic3 uv2, 7 pad
+  // ... or the reference operator's four arrays
+  float *rgb, *opacity, *uv, *conic;
+};
+
+constexpr int kListStride = kBatch;  // entries per row list (a batch can put all of its 256 slots on one list)
+
+// bit of (wave, row) in the 16-bit block mask: block (bx, by) = ((wave & 1) * 2 + (row & 1), (wave >> 1) * 2 + (row >> 1))
+__device__ __forceinline__ int wave_first_bit(int wave) { return (wave >> 1) * 8 + (wave & 1) * 2; }
+
+struct RowCounts { int c0, c1, c2, c3; };
+
+// Compacts, for each of the wave's four rows, the slots of the staged batch that hit the row's block
+// (and lie below the row's stop index `lim*` in the backward).  A list entry is the slot's byte offset into the
+// record arrays (slot * 16), so the loop needs no shift; counts are wave-uniform.
+template <int kStride>
+__device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigned short *lists, int count, int wave,
+                                                     int lane, int lim0, int lim1, int lim2, int lim3) {
+  RowCounts rc = {0, 0, 0, 0};
+  const int b0 = wave_first_bit(wave);
+  for (int sb = 0; sb < count; sb += 64) {
+    const int slot = sb + lane;
+    const unsigned int nib = slot < count ? (__float_as_uint(s_r2[slot].w) >> b0) : 0u;
+    const bool h0 = (nib & 1u) && slot < lim0, h1 = (nib & 2u) && slot < lim1;
+    const bool h2 = (nib & 16u) && slot < lim2, h3 = (nib & 32u) && slot < lim3;
+    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+    if ((m0 | m1 | m2 | m3) == 0ull) continue;
+#define GS_MBCNT(m) __builtin_amdgcn_mbcnt_hi((unsigned int)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)(m), 0u))
+    if (h0) lists[0 * kStride + rc.c0 + GS_MBCNT(m0)] = (unsigned short)(slot << 4);
+    if (h1) lists[1 * kStride + rc.c1 + GS_MBCNT(m1)] = (unsigned short)(slot << 4);
+    if (h2) lists[2 * kStride + rc.c2 + GS_MBCNT(m2)] = (unsigned short)(slot << 4);
+    if (h3) lists[3 * kStride + rc.c3 + GS_MBCNT(m3)] = (unsigned short)(slot << 4);
+#undef GS_MBCNT
+    rc.c0 += __popcll(m0); rc.c1 += __popcll(m1); rc.c2 += __popcll(m2); rc.c3 += __popcll(m3);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return rc;
+}
+
 template <bool kPacked>
 __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
-                                                         const int *__restrict__ sorted,
-                                                         const int *__restrict__ ranges, int width, int height,
-                                                         int ntx, int num_tiles, float bg,
-                                                         int *__restrict__ n_out, float *__restrict__ T_out,
-                                                         float *__restrict__ image) {
+                                                              const int *__restrict__ sorted,
+                                                              const int *__restrict__ ranges, int width, int height,
+                                                              int ntx, int num_tiles, float bg,
+                                                              int *__restrict__ n_out, float *__restrict__ T_out,
+                                                              float *__restrict__ image) {
   __shared__ float4 s_r0[kBatch], s_r1[kBatch], s_r2[kBatch];
-  __shared__ unsigned char s_list[4 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride];
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
   const int tile_x = tile % ntx, tile_y = tile / ntx;
-  const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
+  const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
   const bool inside = px < width && py < height;
   const float fpx = (float)px, fpy = (float)py;
   const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
+  unsigned short *lists = s_list + wave * 4 * kListStride;
+  const unsigned short *my_list = lists + row * kListStride;
+  const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
+  const char *r2b = reinterpret_cast<const char *>(s_r2);
+
+  // a row past the end of its list reads stale entries: make sure they are always valid offsets
+  for (int k = tid; k < 16 * kListStride / 2; k += 256) reinterpret_cast<unsigned int *>(s_list)[k] = 0u;
 
   const int start = ranges[tile], total = ranges[tile + 1] - start;
   // A saturated pixel keeps T = 0 in the running transmittance, so every later splat blends with weight 0 and the
@@ -69,7 +130,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   float T = inside ? 1.0f : 0.0f, T_fin = -1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
   int n = total;
   unsigned long long satmask = __ballot(!inside);  // lanes whose pixel is saturated or outside the image
-  int live = satmask != ~0ull ? 1 : 0;             // wave-uniform: some pixel of the quadrant is still unsaturated
+  int live = satmask != ~0ull ? 1 : 0;
 
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
@@ -77,45 +138,41 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
     if (tid < count) {
       const int g = sorted[start + base + tid];
       SplatRec s = load_record<kPacked>(g, recs, raw);
-      s.r2.w = __uint_as_float(quadrant_hits(s, tx0, ty0));
+      s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
+    } else {  // rows past the end of their list read stale slots: keep every slot finite
+      s_r0[tid] = s_r1[tid] = s_r2[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
-    for (int sb = 0; sb < count && live > 0; sb += 64) {
-      const int slot_l = sb + lane;
-      const unsigned int bits = slot_l < count ? __float_as_uint(s_r2[slot_l].w) : 0u;
-      const bool hit = (bits >> wave) & 1u;
-      const unsigned long long m = __ballot(hit);
-      const int cnt = __popcll(m);
-      if (cnt == 0) continue;
-      // The scalar unit, not the VALU, limits this loop (profiles/: ~17 SALU per visit when the hit mask is
-      // popped bit by bit), so the hit slots are compacted once per 64 entries with lane-parallel work: lane t ends
-      // up holding the t-th hit slot and each visit fetches it with one v_readlane.
-      const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-      if (hit) s_list[wave * 64 + pos] = (unsigned char)lane;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int my_hit = sb + (int)s_list[wave * 64 + lane];
-      for (int t = 0; t < cnt; t += 2) {
-        // two visited gaussians per trip: both records are fetched from LDS and both exponentials evaluated before
-        // the (sequential) blending
-        const int slot0 = __builtin_amdgcn_readlane(my_hit, t);
-        const bool two = t + 1 < cnt;
-        const int slot1 = __builtin_amdgcn_readlane(my_hit, two ? t + 1 : t);
-        const float4 a0 = s_r0[slot0], c0 = s_r2[slot0];
-        const float2 b0 = *reinterpret_cast<const float2 *>(&s_r1[slot0]);
-        const float4 a1 = s_r0[slot1], c1 = s_r2[slot1];
-        const float2 b1 = *reinterpret_cast<const float2 *>(&s_r1[slot1]);
+    if (live > 0) {
+      // rows whose 16 pixels are all saturated (or outside) need no list
+      const int big = kBatch;
+      const RowCounts rc = build_row_lists<kListStride>(s_r2, lists, count, wave, lane,
+                                           (unsigned int)(satmask & 0xFFFFull) == 0xFFFFu ? 0 : big,
+                                           (unsigned int)((satmask >> 16) & 0xFFFFull) == 0xFFFFu ? 0 : big,
+                                           (unsigned int)((satmask >> 32) & 0xFFFFull) == 0xFFFFu ? 0 : big,
+                                           (unsigned int)((satmask >> 48) & 0xFFFFull) == 0xFFFFu ? 0 : big);
+      const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+      const int my_cnt = row == 0 ? rc.c0 : (row == 1 ? rc.c1 : (row == 2 ? rc.c2 : rc.c3));
+      for (int i = 0; i < trips; i += 2) {
+        // two list entries per trip: both records are fetched and both exponentials evaluated before the
+        // (sequential) blending; a row past the end of its list blends with alpha 0
+        const unsigned int two = *reinterpret_cast<const unsigned int *>(my_list + i);
+        const int off0 = two & 0xFFFFu, off1 = two >> 16;
+        const bool act0 = i < my_cnt, act1 = i + 1 < my_cnt;
+        const float4 a0 = *reinterpret_cast<const float4 *>(r0b + off0), c0 = *reinterpret_cast<const float4 *>(r2b + off0);
+        const float2 b0 = *reinterpret_cast<const float2 *>(r1b + off0);
+        const float4 a1 = *reinterpret_cast<const float4 *>(r0b + off1), c1 = *reinterpret_cast<const float4 *>(r2b + off1);
+        const float2 b1 = *reinterpret_cast<const float2 *>(r1b + off1);
         asm volatile("" ::"v"(c0.w), "v"(c1.w));  // keep 16-byte reads (ds_read_b96 costs twice the LDS cycles)
         const float p0 = fminf(0.0f, gauss_power(a0.z, a0.w, b0.x, a0.x - fpx, a0.y - fpy));
         const float p1 = fminf(0.0f, gauss_power(a1.z, a1.w, b1.x, a1.x - fpx, a1.y - fpy));
         float al0 = fminf(kAlphaMax, b0.y * __expf(p0));
         float al1 = fminf(kAlphaMax, b1.y * __expf(p1));
-        al0 = al0 > kAlphaMin ? al0 : 0.0f;
-        al1 = (al1 > kAlphaMin && two) ? al1 : 0.0f;
+        al0 = (al0 > kAlphaMin && act0) ? al0 : 0.0f;
+        al1 = (al1 > kAlphaMin && act1) ? al1 : 0.0f;
         // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T * (1 - alpha) < 1e-4" alone
-        // decides the next T; the compare's lane mask doubles as the saturation bookkeeping (one scalar compare per
-        // visit, the per-pixel records are only touched in the rare branch).
+        // decides the next T; the compare's lane mask doubles as the saturation bookkeeping.
         const float w0 = al0 * T;
         const float tT0 = T * (1.0f - al0);
         ar = __builtin_fmaf(c0.x, w0, ar);
@@ -132,8 +189,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
         T = tT1 < kTMin ? 0.0f : tT1;
         if (s1 != satmask) {  // rare: some pixel saturated in this trip
           const unsigned long long bit = 1ull << lane;
-          if ((s0 & ~satmask) & bit) { T_fin = tT0; n = base + slot0 + 1; }
-          if ((s1 & ~s0) & bit) { T_fin = tT1; n = base + slot1 + 1; }
+          if ((s0 & ~satmask) & bit) { T_fin = tT0; n = base + (off0 >> 4) + 1; }
+          if ((s1 & ~s0) & bit) { T_fin = tT1; n = base + (off1 >> 4) + 1; }
           satmask = s1;
           if (satmask == ~0ull) {
             live = 0;
@@ -155,35 +212,47 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   }
 }
 
-// ------------------------------------------------------------------------------ backward
-struct GradOut {         // either whole rows ...
-  float *rows;           // [M,16]: rgb3 opacity1 conic3 uv2, 7 pad
-  // ... or the reference operator's four arrays
-  float *rgb, *opacity, *uv, *conic;
-};
+__device__ __forceinline__ int row_max_int(int v) {  // max over the 16 lanes of a row, in every lane of the row
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+  return v;
+}
 
-template <bool kPacked, bool kRows>
+template <bool kPacked, bool kRows, int kB>
 __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
-                                                         const int *__restrict__ sorted,
-                                                         const int *__restrict__ ranges,
-                                                         const int *__restrict__ n_px,
-                                                         const float *__restrict__ T_px,
-                                                         const float *__restrict__ grad_image, int width, int height,
-                                                         int ntx, int num_tiles, float bg, GradOut out) {
-  __shared__ float4 s_r0[kBatch], s_r1[kBatch], s_r2[kBatch];
-  __shared__ float s_acc[kBatch * 9];
-  __shared__ int s_id[kBatch];
+                                                              const int *__restrict__ sorted,
+                                                              const int *__restrict__ ranges,
+                                                              const int *__restrict__ n_px,
+                                                              const float *__restrict__ T_px,
+                                                              const float *__restrict__ grad_image, int width,
+                                                              int height, int ntx, int num_tiles, float bg,
+                                                              GradOut out) {
+  __shared__ float4 s_r0[kB], s_r1[kB], s_r2[kB];
+  // [slot][9]: rgb, S0, Sx, Sy, Sxx, Sxy, Syy.  Doubles on purpose: on gfx950 ds_add_f32 retires about one LANE
+  // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
+  // a 36-lane instruction), and the merge across the tile's 16 blocks needs one atomic per trip.
+  constexpr int kAcc = 10;  // doubles per slot (nine used): 80 bytes = 5 x the list entry's byte offset
+  __shared__ double s_acc[kB * kAcc];
+  __shared__ int s_id[kB];
+  __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kB];
   __shared__ int s_top;
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
   const int tile_x = tile % ntx, tile_y = tile / ntx;
-  const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
+  const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
   const bool inside = px < width && py < height;
   const float fpx = (float)px, fpy = (float)py;
   const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
   const int start = ranges[tile];
+  unsigned short *lists = s_list + wave * 4 * kB;
+  const unsigned short *my_list = lists + row * kB;
+  const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
+  const char *r2b = reinterpret_cast<const char *>(s_r2);
+  char *accb = reinterpret_cast<char *>(s_acc);
 
   int n = 0;
   float Tf = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
@@ -195,53 +264,56 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
   }
   float T = Tf, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;  // running transmittance, colour behind the current splat
   const float tfb = Tf * (bg * g0 + bg * g1 + bg * g2);  // T_final * (background . grad)
-  const int wave_top = wave_max_int(n);
+  const int row_top_v = row_max_int(n);
+  const int rt0 = __builtin_amdgcn_readlane(row_top_v, 0), rt1 = __builtin_amdgcn_readlane(row_top_v, 16);
+  const int rt2 = __builtin_amdgcn_readlane(row_top_v, 32), rt3 = __builtin_amdgcn_readlane(row_top_v, 48);
+  const int wave_top = max(max(rt0, rt1), max(rt2, rt3));
   if (tid == 0) s_top = 0;
+  // a row past the end of its list reads stale entries: make sure they are always valid offsets
+  for (int k = tid; k < 16 * kB / 2; k += 256) reinterpret_cast<unsigned int *>(s_list)[k] = 0u;
   __syncthreads();
   if (lane == 0) atomicMax(&s_top, wave_top);
   __syncthreads();
   const int top = s_top;  // cuda/render_backward.cu:64,74: start at (max n over the tile) - 1
   if (top <= 0) return;
-  // where this lane's share of the nine wave totals goes (see wave_sum9)
-  const bool row_leader = (lane & 15) == 0;
-  const int acc_q0 = sum9_index_q0(lane) * kBatch, acc_q1 = sum9_index_q1(lane) * kBatch;
+  // where this lane's share of the nine row totals goes (see row_sum9)
+  const bool red_lane = row_sum9_active(lane);
+  const int red_idx = row_sum9_index(lane);
 
-  for (int base = ((top - 1) / kBatch) * kBatch; base >= 0; base -= kBatch) {
-    const int count = min(kBatch, top - base);
+  for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
+    const int count = min(kB, top - base);
     __syncthreads();
-    if (tid < count) {
+    if (tid < count) {  // count <= kB
       const int g = sorted[start + base + tid];
       SplatRec s = load_record<kPacked>(g, recs, raw);
-      s.r2.w = __uint_as_float(quadrant_hits(s, tx0, ty0));
+      s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
       s_id[tid] = g;
+    } else if (tid < kB) {  // rows past the end of their list read stale slots: keep every slot finite
+      s_r0[tid] = s_r1[tid] = s_r2[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) s_acc[k * kBatch + tid] = 0.0f;
+    for (int k = tid; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
     __syncthreads();
-    for (int sb = ((count - 1) >> 6) << 6; sb >= 0; sb -= 64) {
-      if (base + sb >= wave_top) continue;
-      const int slot_l = sb + lane;
-      const unsigned int bits =
-          (slot_l < count && base + slot_l < wave_top) ? __float_as_uint(s_r2[slot_l].w) : 0u;
-      unsigned long long m = __ballot((bits >> wave) & 1u);
-      while (m != 0ull) {
-        const int j = 63 - __builtin_clzll(m);
-        m &= ~(1ull << j);
-        const int slot = sb + j;
-        const float4 a = s_r0[slot], b = s_r1[slot], c = s_r2[slot];
+    if (base < wave_top) {
+      const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, wave, lane, rt0 - base, rt1 - base, rt2 - base, rt3 - base);
+      const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+      const int my_cnt = row == 0 ? rc.c0 : (row == 1 ? rc.c1 : (row == 2 ? rc.c2 : rc.c3));
+      const int n_rel = (n - base) * 16;  // "base + slot < n" on byte offsets
+      for (int i = trips - 1; i >= 0; --i) {
+        const int off = my_list[i];
+        const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
+        const float4 c = *reinterpret_cast<const float4 *>(r2b + off);
         const float dx = a.x - fpx, dy = a.y - fpy;
         const float power = fminf(0.0f, gauss_power(a.z, a.w, b.x, dx, dy));
         float gg = __expf(power);
         const float opa = b.y;
         float alpha = fminf(kAlphaMax, opa * gg);
-        // n is 0 for pixels outside the image, so "inside" needs no separate test
-        const bool valid = (alpha >= kAlphaMin) && (base + slot < n);
+        // a row past the end of its list reads a stale slot: selects (not multiplies) so that garbage cannot
+        // poison the pixel state.  n is 0 for pixels outside the image, so "inside" needs no separate test.
+        const bool valid = (alpha >= kAlphaMin) && (off < n_rel) && (i < my_cnt);
         if (__ballot(valid) == 0ull) continue;
-        // one select, two multiplies: selects on SGPR masks are ~8x the issue cost of a multiply on this chip
-        const float vf = valid ? 1.0f : 0.0f;
-        alpha *= vf;
-        gg *= vf;
+        alpha = valid ? alpha : 0.0f;
+        gg = valid ? gg : 0.0f;
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T *= inv;                                           // transmittance in front of this splat
         const float aT = alpha * T;
@@ -253,46 +325,55 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         c1 = __builtin_fmaf(alpha, d1, c1);
         c2 = __builtin_fmaf(alpha, d2, c2);
         const float gp = gg * (ga * opa);                   // d/d power
-        // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa)
-        if (opa == 1.0f || __ballot(gp != 0.0f) == 0ull) continue;
         const float gpx = gp * dx, gpy = gp * dy;
         // nine raw sums; signs, the -1/2 factors, (1 - opa) and the 0.5*W / 0.5*H are applied once per gaussian
         // at flush time:  S0 = sum gp, Sx, Sy, Sxx, Sxy, Syy
-        const Sum9 r = wave_sum9(v0, v1, v2, gp, gpx, gpy, gpx * dx, gpx * dy, gpy * dy);
-        if (row_leader) {
-          atomicAdd(&s_acc[acc_q0 + slot], r.q0);
-          atomicAdd(&s_acc[acc_q1 + slot], r.q1);
-          if (lane == 0) atomicAdd(&s_acc[8 * kBatch + slot], r.q2);
-        }
+#if GS_ABLATE == 2
+        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(gp), "v"(gpx), "v"(gpy), "v"(gpx * dx), "v"(gpx * dy), "v"(gpy * dy));
+#else
+        const float red = row_sum9(v0, v1, v2, gp, gpx, gpy, gpx * dx, gpx * dy, gpy * dy);
+        // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
+        // gaussian (opa == 1) gets no gradient at all; all-zero sums add nothing either way
+#if GS_ABLATE == 1
+        asm volatile("" ::"v"(red));
+#else
+        if (red_lane && i < my_cnt && opa != 1.0f && red != 0.0f)
+          atomicAdd(reinterpret_cast<double *>(accb + off * 5 + red_idx * 8), (double)red);
+#endif
+#endif
       }
     }
     __syncthreads();
     // flush: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows.
-    // s_acc rows: 0..2 rgb, 3 S0, 4 Sx, 5 Sy, 6 Sxx, 7 Sxy, 8 Syy
     const int k = tid & 15;
     if (k < 9) {
 #pragma unroll 4
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < kB / 16; ++r) {
         const int slot = r * 16 + (tid >> 4);
         if (slot >= count) continue;
+        const double *acc = &s_acc[slot * kAcc];
         float val;
         if (k < 3) {
-          val = s_acc[k * kBatch + slot];
+          val = (float)acc[k];
         } else if (k == 3) {
-          val = s_acc[3 * kBatch + slot] * (1.0f - s_r1[slot].y);              // d/d logit (render_backward.cu:154)
+          val = (float)acc[3] * (1.0f - s_r1[slot].y);        // d/d logit (render_backward.cu:154)
         } else if (k == 4) {
-          val = -0.5f * s_acc[6 * kBatch + slot];                               // conic00
+          val = -0.5f * (float)acc[6];                        // conic00
         } else if (k == 5) {
-          val = -s_acc[7 * kBatch + slot];                                      // conic01
+          val = -(float)acc[7];                               // conic01
         } else if (k == 6) {
-          val = -0.5f * s_acc[8 * kBatch + slot];                               // conic11
+          val = -0.5f * (float)acc[8];                        // conic11
         } else {
-          const float sx = s_acc[4 * kBatch + slot], sy = s_acc[5 * kBatch + slot];
+          const float sx = (float)acc[4], sy = (float)acc[5];
           const float4 a = s_r0[slot];
           val = (k == 7) ? -(a.z * sx + a.w * sy) * (0.5f * (float)width)       // u (render_backward.cu:180-186)
                          : -(s_r1[slot].x * sy + a.w * sx) * (0.5f * (float)height);  // v (:181-187)
         }
         if (val == 0.0f) continue;
+#if GS_ABLATE == 3
+        asm volatile("" ::"v"(val));
+        continue;
+#endif
         const int g = s_id[slot];
         if constexpr (kRows) {
           atomicAdd(&out.rows[(size_t)g * 16 + k], val);
@@ -313,10 +394,11 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
-  if (recs)
+  if (recs) {
     render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);
-  else
+  } else {
     render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);
+  }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
@@ -328,12 +410,13 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   GradOut out = {rows, g_rgb, g_opacity, g_uv, g_conic};
-  if (recs && rows)
-    render_bwd_kernel<true, true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
-  else if (recs)
-    render_bwd_kernel<true, false><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
-  else
-    render_bwd_kernel<false, false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+  if (recs && rows) {
+    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+  } else if (recs) {
+    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+  } else {
+    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+  }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

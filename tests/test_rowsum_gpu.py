@@ -1,0 +1,28 @@
+"""The row-level nine-value reduction of the backward (gs::row_sum9, masked DPP adds in inline assembly) checked
+lane by lane on the GPU: tools/dpp_rowsum_test.hip compares every row total with a host sum."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+SRC = os.path.join(ROOT, "tools", "dpp_rowsum_test.hip")
+EXE = os.path.join(ROOT, "tools", "dpp_rowsum_test")
+
+
+def _build():
+    hdr = os.path.join(ROOT, "3dgs_amd", "csrc", "gs_render.h")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", SRC, "-o", EXE])
+    return EXE
+
+
+def test_rowsum_program_builds():
+    assert os.path.exists(_build())
+
+
+@pytest.mark.gpu
+def test_row_sum9_on_gpu():
+    out = subprocess.run([_build()], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "row_sum9: ok" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,97 @@
+"""Numpy model of compositing loop trips on the benchmark scene: today's (quadrant, gaussian) visits vs per-row
+(4x4 sub-block) queues where a wave's trip count is the max over its four sub-blocks.  CPU only (uses the oracle)."""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+scene = importlib.import_module("3dgs_amd.scene")
+from oracle import oracle as orc
+
+name = sys.argv[1] if len(sys.argv) > 1 else "config3"
+N, W, H, L, _ = scene.WORKLOADS[name]
+params = scene.make_gaussians(N, W, H, L)
+cam = scene.make_camera(W, H, 0)
+c = scene.CONFIG
+f = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=8)
+uv, conic, sorted_ids, ranges = f["uv"], f["conic"], f["sorted"], f["ranges"]
+opa = 1.0 / (1.0 + np.exp(-f["opacity"].reshape(-1))) if "opacity" in f else None
+if opa is None:
+    mask = f["mask"]
+    opa = 1.0 / (1.0 + np.exp(-np.asarray(params["opacity"], np.float32).reshape(-1)[mask]))
+a, b, cc = conic[:, 0], conic[:, 1], conic[:, 2]
+det = a * cc - b * b
+tau2 = 2.0 * np.maximum(0.0, np.log(255.0 * opa)) + 1e-3
+hx = np.sqrt(tau2 * cc / det) * 1.0005 + 0.01
+hy = np.sqrt(tau2 * a / det) * 1.0005 + 0.01
+hx[opa * 255 < 0.999] = -np.inf
+hy[opa * 255 < 0.999] = -np.inf
+ntx = (W + 15) // 16
+T = len(ranges) - 1
+tile_of = np.repeat(np.arange(T), np.diff(ranges))
+g = sorted_ids
+tx0 = (tile_of % ntx) * 16.0
+ty0 = (tile_of // ntx) * 16.0
+lox, hix, loy, hiy = uv[g, 0] - hx[g], uv[g, 0] + hx[g], uv[g, 1] - hy[g], uv[g, 1] + hy[g]
+
+
+def hits1d(lo, hi, o, size, nblk):
+    return [(~(hi < o + k * size)) & (~(lo > o + k * size + size - 1)) for k in range(nblk)]
+
+
+# quadrants
+qx, qy = hits1d(lox, hix, tx0, 8, 2), hits1d(loy, hiy, ty0, 8, 2)
+visits = sum((qx[i] & qy[j]).sum() for i in range(2) for j in range(2))
+print("instances S", len(g), "quadrant visits", visits, "per instance", visits / len(g))
+# 4x4 sub-blocks, AABB
+bx, by = hits1d(lox, hix, tx0, 4, 4), hits1d(loy, hiy, ty0, 4, 4)
+trips = 0
+pairs = 0
+for wy in range(2):
+    for wx in range(2):
+        cnts = []
+        for ry in range(2):
+            for rx in range(2):
+                hit = bx[wx * 2 + rx] & by[wy * 2 + ry]
+                cnts.append(np.bincount(tile_of[hit], minlength=T))
+                pairs += hit.sum()
+        trips += np.max(np.stack(cnts), axis=0).sum()
+print("sub-block pairs", pairs, "row-queue trips (AABB)", trips, "ratio visits/trips", visits / trips,
+      "row occupancy", pairs / (4 * trips))
+
+
+# exact ellipse-vs-rectangle test: min over the rectangle of q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2
+def ellipse_hits_rect(u, v, a, b, c, tau2, x0, x1, y0, y1):
+    # closest point in q-metric: check centre inside, else minimise along the 4 edges
+    inside = (u >= x0) & (u <= x1) & (v >= y0) & (v <= y1)
+    best = np.full(u.shape, np.inf)
+    for (xe) in (x0, x1):
+        dx = xe - u
+        # minimise over y in [y0,y1]: q = a dx^2 + 2 b dx dy + c dy^2 ; dy* = -b dx / c
+        dy = np.clip(-b * dx / c, y0 - v, y1 - v)
+        best = np.minimum(best, a * dx * dx + 2 * b * dx * dy + c * dy * dy)
+    for (ye) in (y0, y1):
+        dy = ye - v
+        dx = np.clip(-b * dy / a, x0 - u, x1 - u)
+        best = np.minimum(best, a * dx * dx + 2 * b * dx * dy + c * dy * dy)
+    return inside | (best <= tau2)
+
+
+ag, bg_, cg, tg = a[g], b[g], cc[g], tau2[g]
+ug, vg = uv[g, 0], uv[g, 1]
+ok = opa[g] * 255 >= 0.999
+trips_e = 0
+pairs_e = 0
+visits_e = 0
+for wy in range(2):
+    for wx in range(2):
+        cnts = []
+        x0, y0 = tx0 + wx * 8, ty0 + wy * 8
+        visits_e += (ellipse_hits_rect(ug, vg, ag, bg_, cg, tg, x0, x0 + 7, y0, y0 + 7) & ok).sum()
+        for ry in range(2):
+            for rx in range(2):
+                xs, ys = tx0 + (wx * 2 + rx) * 4, ty0 + (wy * 2 + ry) * 4
+                hit = ellipse_hits_rect(ug, vg, ag, bg_, cg, tg, xs, xs + 3, ys, ys + 3) & ok
+                cnts.append(np.bincount(tile_of[hit], minlength=T))
+                pairs_e += hit.sum()
+        trips_e += np.max(np.stack(cnts), axis=0).sum()
+print("exact: quadrant visits", visits_e, "sub-block pairs", pairs_e, "row-queue trips", trips_e,
+      "ratio visits/trips", visits / trips_e, "row occupancy", pairs_e / (4 * trips_e))
