@@ -70,61 +70,6 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const float *__restr
   }
 }
 
-__global__ __launch_bounds__(kBlock) void tile_emit_kernel(const float *__restrict__ uv,
-                                                           const float *__restrict__ xyz_c,
-                                                           const float *__restrict__ radius, int ntx, int nty, int N,
-                                                           const unsigned char *__restrict__ mask,
-                                                           const int *__restrict__ rank,
-                                                           const int *__restrict__ offsets,
-                                                           unsigned long long *__restrict__ keys,
-                                                           int *__restrict__ vals) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N || (mask && !mask[i])) return;
-  const int j = rank ? rank[i] : i;
-  int w = offsets[j];
-  const int end = offsets[j + 1];
-  if (w == end) return;
-  const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
-  const float u = uv[2 * j], v = uv[2 * j + 1];
-  const unsigned long long zbits = float_sort_bits(xyz_c[3 * j + 2]);
-  const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
-  const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
-  for (int tx = r.x0; tx < r.x1; ++tx)
-    for (int ty = r.y0; ty < r.y1; ++ty)
-      if (obb_hits_tile(o, tx, ty) && w < end) {
-        keys[w] = ((unsigned long long)(unsigned int)(ty * ntx + tx) << 32) | zbits;
-        vals[w] = j;
-        ++w;
-      }
-}
-
-// ranges[t] = number of instances whose tile id is < t, for t in [0, T]
-// (same outputs as find_tile_boundaries_kernel, cuda/culling.cu:302-343)
-__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const unsigned long long *__restrict__ keys, int S,
-                                                             int num_tiles, int *__restrict__ ranges) {
-  const int s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= S) return;
-  int cur = (int)(keys[s] >> 32);
-  cur = min(max(cur, 0), num_tiles - 1);
-  int prev = -1;
-  if (s > 0) {
-    prev = (int)(keys[s - 1] >> 32);
-    prev = min(max(prev, 0), num_tiles - 1);
-  }
-  for (int t = prev + 1; t <= cur; ++t) ranges[t] = s;
-  if (s == S - 1)
-    for (int t = cur + 1; t <= num_tiles; ++t) ranges[t] = S;
-}
-
-int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
-                     const unsigned char *mask, const int *rank, const int *offsets, unsigned long long *keys,
-                     int *vals, hipStream_t st) {
-  tile_emit_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets, keys,
-                                                        vals);
-  GS_LAUNCH_CHECK();
-  return GSPLAT_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Two-level ordering (used by the fused path and by gsplat_get_sorted_gaussian_list):
 //   1. every gaussian emits (tile id, payload = depth bits << 32 | gaussian id) for the tiles it is listed in;
@@ -292,32 +237,6 @@ int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, i
   tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_b, (int)S, num_tiles, ranges);
   GS_LAUNCH_CHECK();
   tile_depth_sort_kernel<<<num_tiles, kBlock, 0, st>>>(pay_b, ranges, num_tiles, sorted_out);
-  GS_LAUNCH_CHECK();
-  return GSPLAT_OK;
-}
-
-static int key_bits(int num_tiles) {
-  int b = 0;
-  while ((1LL << b) < (long long)num_tiles) ++b;
-  return 32 + (b > 0 ? b : 1);
-}
-
-size_t sort_temp_bytes(size_t S, int num_tiles) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                  (int *)nullptr, (int *)nullptr, S, 0, key_bits(num_tiles), (hipStream_t)0);
-  return bytes;
-}
-
-// keys_a/vals_a hold the S emitted instances; sorted ids go to sorted_out, sorted keys to keys_b
-int sort_and_ranges(unsigned long long *keys_a, unsigned long long *keys_b, int *vals_a, int *sorted_out, size_t S,
-                    int num_tiles, void *temp, size_t temp_bytes, int *ranges, hipStream_t st) {
-  if (S == 0) {
-    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)(num_tiles + 1) * sizeof(int), st));
-    return GSPLAT_OK;
-  }
-  GS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_a, keys_b, vals_a, sorted_out, S, 0, key_bits(num_tiles), st));
-  tile_ranges_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(keys_b, (int)S, num_tiles, ranges);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
