@@ -351,6 +351,64 @@ __global__ __launch_bounds__(kBlock) void unpack_factored_kernel(const float *__
   out[11 + 3 * n] = row[11];                                           // visibility count
 }
 
+// Split exchange: the 12 direction-independent columns (SUM all-reduce) and this view's g_rgb (all-gather).
+__global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char *__restrict__ mask,
+                                                            const int *__restrict__ rank_of, int N,
+                                                            gsplat_gradients gr, float *__restrict__ common,
+                                                            float *__restrict__ rgb) {
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (long long)N * 15) return;
+  const int i = (int)(e / 15), k = (int)(e % 15);
+  float val = 0.0f;
+  if (mask[i]) {
+    const size_t j = (size_t)rank_of[i];
+    if (k < 3) val = gr.grad_xyz[3 * j + k];
+    else if (k == 3) val = gr.grad_opacity[j];
+    else if (k < 7) val = gr.grad_scale[3 * j + (k - 4)];
+    else if (k < 11) val = gr.grad_quaternion[4 * j + (k - 7)];
+    else if (k == 11) val = 1.0f;
+    else val = gr.grad_precompute_rgb[3 * j + (k - 12)];
+  }
+  if (k < 12) common[(size_t)i * 12 + k] = val;
+  else rgb[(size_t)i * 3 + (k - 12)] = val;
+}
+
+// rgb_all: world blocks of `stride` floats; block r = [N,3] g_rgb of rank r followed by that rank's campos[3]
+template <int L>
+__global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__restrict__ xyz, int N, int world,
+                                                              const float *__restrict__ common,
+                                                              const float *__restrict__ rgb_all, size_t stride,
+                                                              float *__restrict__ full) {
+  constexpr int n = (L + 1) * (L + 1);
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int wo = 12 + 3 * n;
+  const float *row = common + (size_t)i * 12;
+  float *out = full + (size_t)i * wo;
+  float acc[n][3];
+#pragma unroll
+  for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+  const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  for (int r = 0; r < world; ++r) {
+    const float *blk = rgb_all + (size_t)r * stride;
+    const float g0 = blk[3 * (size_t)i], g1 = blk[3 * (size_t)i + 1], g2 = blk[3 * (size_t)i + 2];
+    if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+    const float *cp = blk + 3 * (size_t)N;
+    float dx, dy, dz, len, Y[n];
+    gs::view_dir(px, py, pz, cp[0], cp[1], cp[2], dx, dy, dz, len);
+    gs::sh_basis<L>(dx, dy, dz, Y);
+#pragma unroll
+    for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
+  }
+  out[0] = row[0]; out[1] = row[1]; out[2] = row[2];  // xyz
+#pragma unroll
+  for (int k = 0; k < n; ++k) { out[3 + 3 * k] = acc[k][0]; out[4 + 3 * k] = acc[k][1]; out[5 + 3 * k] = acc[k][2]; }
+  out[3 + 3 * n] = row[3];                                             // opacity
+  out[4 + 3 * n] = row[4]; out[5 + 3 * n] = row[5]; out[6 + 3 * n] = row[6];  // scale
+  out[7 + 3 * n] = row[7]; out[8 + 3 * n] = row[8]; out[9 + 3 * n] = row[9]; out[10 + 3 * n] = row[10];  // quaternion
+  out[11 + 3 * n] = row[11];                                           // visibility count
+}
+
 int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   int rc;
   if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned int)))) return rc;
@@ -395,6 +453,37 @@ int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, 
     case 1: unpack_factored_kernel<1><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
     case 2: unpack_factored_kernel<2><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
     default: unpack_factored_kernel<3><<<g, b, 0, st>>>(xyz, campos_all, num_gaussians, world_size, packed, full); break;
+  }
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians, float *common,
+                                float *rgb, void *stream) {
+  GS_REQUIRE(c && grads, "null argument struct");
+  GS_REQUIRE(c->have_forward && num_gaussians == c->N, "does not match the recorded forward");
+  GS_REQUIRE_DEV(common); GS_REQUIRE_DEV(rgb);
+  GS_REQUIRE_DEV(grads->grad_precompute_rgb);  // backward must have been asked for this intermediate
+  const long long total = (long long)num_gaussians * 15;
+  pack_split_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+      c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, *grads, common, rgb);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_unpack_gradients_split(const float *xyz, const float *common, const float *rgb_all, size_t rank_stride,
+                                  int l_max, int num_gaussians, int world_size, float *full, void *stream) {
+  GS_REQUIRE_DEV(xyz); GS_REQUIRE_DEV(common); GS_REQUIRE_DEV(rgb_all); GS_REQUIRE_DEV(full);
+  GS_REQUIRE(l_max >= 0 && l_max <= 3 && num_gaussians >= 0 && world_size >= 1, "bad sizes");
+  GS_REQUIRE(rank_stride >= 3 * (size_t)num_gaussians + 3, "rank_stride must cover [N,3] g_rgb + campos[3]");
+  if (num_gaussians == 0) return GSPLAT_OK;
+  const dim3 g(gs::div_up(num_gaussians, kBlock)), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  switch (l_max) {
+    case 0: unpack_split_kernel<0><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
+    case 1: unpack_split_kernel<1><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
+    case 2: unpack_split_kernel<2><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
+    default: unpack_split_kernel<3><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;

@@ -49,6 +49,14 @@ def all_reduce_gradients(packed):
     return packed
 
 
+def all_gather_blocks(out, block, async_op=False):
+    """out[world, ...] <- every rank's `block`.  One collective; RCCL/NCCL gathers straight into the contiguous
+    buffer, gloo (CPU tests, single-GPU rehearsal) takes the list form."""
+    if dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(out, block, async_op=async_op)
+    return dist.all_gather(list(out.unbind(0)), block, async_op=async_op)
+
+
 def unpack(packed, l_max):
     """Views into the reduced buffer: dict name -> [N, ...] tensor (global gaussian order)."""
     cols, _ = packed_layout(l_max)
@@ -63,14 +71,17 @@ def unpack(packed, l_max):
 class ViewShardedStep:
     """forward + backward of this rank's view, then the gradient exchange.  Device tensors in, packed[N,width] out.
 
-    exchange="factored" (default): the all-reduced buffer carries, per gaussian, the 12 non-SH gradient columns plus
+    exchange="split" (default): the same factorisation as "factored" below, as two concurrent collectives with less
+    traffic: the 12 direction-independent columns are SUM all-reduced ([N,12]) and every rank's g_rgb[N,3] + camera
+    position is all-gathered ([world, N+1, 3]); at 8 ranks a rank moves 168 MB per step instead of 252 MB.
+    exchange="factored": ONE all-reduce whose buffer carries, per gaussian, the 12 non-SH gradient columns plus
     one 3-float g_rgb slot per rank (12 + 3*world floats instead of 12 + 3*n_coeffs = 60 at SH degree 3), and one
     extra row with every rank's camera position; the SH-coefficient gradients sum_r g_rgb^r x Y(dir^r) are rebuilt
     locally afterwards (gsplat_unpack_gradients_factored).  Still ONE all-reduce per step.
     exchange="full": all-reduce the complete packed[N, 12+3*n_coeffs] rows.
     """
 
-    def __init__(self, params, l_max, width, height, config, bg, exchange="factored"):
+    def __init__(self, params, l_max, width, height, config, bg, exchange="split"):
         from . import raster
         self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
@@ -85,13 +96,33 @@ class ViewShardedStep:
         self.fw = raster.factored_gradient_width(self.world)
         self.factored = torch.zeros(self.N + 1, self.fw, dtype=torch.float32, device=dev) if exchange == "factored" \
             else None
+        if exchange == "split":
+            self.common = torch.zeros(self.N, 12, dtype=torch.float32, device=dev)
+            self.rgb = torch.zeros(self.N + 1, 3, dtype=torch.float32, device=dev)          # row N: campos
+            self.rgb_all = torch.zeros(self.world, self.N + 1, 3, dtype=torch.float32, device=dev)
         # capacity N: never reallocated
         self.grads = self.ctx.alloc_gradients(self.N, l_max)
         self.grads["precompute_rgb"] = torch.empty(self.N, 3, dtype=torch.float32, device=dev)
 
+    def describe_exchange(self):
+        mb = lambda t: f"{t.numel() * 4 / 1e6:.0f} MB"
+        if self.exchange == "split":
+            return f"split: all-reduce of {mb(self.common)} + all-gather of {mb(self.rgb)} per rank"
+        return f"{self.exchange}: one all-reduce of {mb(self.factored if self.exchange == 'factored' else self.packed)}"
+
     def exchange_gradients(self, cam):
         """Scatter this rank's compacted gradients to global order, sum over ranks, leave the result in self.packed."""
-        if self.exchange == "factored":
+        if self.exchange == "split":
+            self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, self.rgb)
+            self.rgb[self.N] = torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32,
+                                               device=self.rgb.device)
+            works = [dist.all_reduce(self.common, op=dist.ReduceOp.SUM, async_op=True),
+                     all_gather_blocks(self.rgb_all, self.rgb, async_op=True)]
+            for w in works:
+                w.wait()
+            self.raster.unpack_gradients_split(self.params["xyz"], self.common, self.rgb_all, 3 * (self.N + 1),
+                                               self.l_max, self.N, self.world, self.packed)
+        elif self.exchange == "factored":
             f = self.factored
             self.raster.pack_gradients_factored(self.ctx, self.grads, self.N, self.rank, self.world, f)
             f[self.N].zero_()

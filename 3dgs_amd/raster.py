@@ -183,6 +183,19 @@ def unpack_gradients_factored(xyz, campos_all, factored, l_max, num_gaussians, w
     return packed
 
 
+def pack_gradients_split(ctx, grads, num_gaussians, common, rgb):
+    gs = RasterContext._grad_struct(grads)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_lib.load().gsplat_pack_gradients_split(ctx._h, ctypes.byref(gs), int(num_gaussians), _ptr(common), _ptr(rgb), st))
+
+
+def unpack_gradients_split(xyz, common, rgb_all, rank_stride, l_max, num_gaussians, world, packed):
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_lib.load().gsplat_unpack_gradients_split(_ptr(xyz), _ptr(common), _ptr(rgb_all), int(rank_stride), int(l_max),
+                                                    int(num_gaussians), int(world), _ptr(packed), st))
+    return packed
+
+
 def factored_gradient_width(world):
     return int(_lib.load().gsplat_factored_gradient_width(int(world)))
 

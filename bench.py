@@ -55,7 +55,7 @@ def main():
     gi = scene.make_grad_image(W, H)
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
     dgi = torch.as_tensor(gi).to(dev)
-    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=os.environ.get("GSPLAT_EXCHANGE", "factored"))
+    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=os.environ.get("GSPLAT_EXCHANGE", "split"))
     gen_s = time.time() - t0
 
     def one_step():
@@ -145,9 +145,7 @@ def main():
         "config": {"workload": f"BASELINE configs[2]: synthetic {N} gaussians, {W}x{H}, SH deg {L}, "
                                f"{'forward+backward' if do_bwd else 'forward'}",
                    "views_per_step": world, "parallelism": f"view-sharded dp{world}" if world > 1 else "single GPU",
-                   "exchange": (f"{step.exchange}: one all-reduce of "
-                                f"{(step.factored if step.exchange == 'factored' else step.packed).numel() * 4 / 1e6:.0f} MB")
-                   if world > 1 else "none",
+                   "exchange": step.describe_exchange() if world > 1 else "none",
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": fwd["num_pairs"], "scene_seed": scene.SEED},
         "render_fps_forward_only": fps,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},

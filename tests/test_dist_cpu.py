@@ -60,6 +60,14 @@ def _worker(rank, world, port, out_dir):
     gdist.all_reduce_gradients(packed)
     np.save(os.path.join(out_dir, f"local{rank}.npy"), local.numpy())
     np.save(os.path.join(out_dir, f"reduced{rank}.npy"), packed.numpy())
+    # the split exchange's second collective: every rank's [N+1,3] block lands in out[rank]
+    blocks = torch.zeros(world, N + 1, 3)
+    mine = torch.full((N + 1, 3), float(rank + 1))
+    works = [torch.distributed.all_reduce(torch.ones(4), async_op=True), gdist.all_gather_blocks(blocks, mine, async_op=True)]
+    for wk in works:
+        wk.wait()
+    for rr in range(world):
+        assert (blocks[rr] == float(rr + 1)).all()
     un = gdist.unpack(packed, L)
     assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3) and un["visible"].shape == (N,)
     assert params_all["xyz"].shape == (N, 3)

@@ -245,6 +245,8 @@ def test_factored_exchange_equals_full_rows(gpu, scene):
     fw, pw = raster.factored_gradient_width(world), raster.packed_gradient_width(L)
     fac_sum = torch.zeros(N + 1, fw, device="cuda")
     full_sum = torch.zeros(N, pw, device="cuda")
+    common_sum = torch.zeros(N, 12, device="cuda")           # what the split exchange's all-reduce would hold
+    rgb_all = torch.zeros(world, N + 1, 3, device="cuda")    # ... and its all-gather
     for r in range(world):
         cam = scene.make_camera(W, H, view_index=r + 1)
         dc = raster.device_camera(cam)
@@ -256,6 +258,10 @@ def test_factored_exchange_equals_full_rows(gpu, scene):
         raster.pack_gradients_factored(ctx, grads, N, r, world, fac)
         fac[N, 12 + 3 * r: 15 + 3 * r] = torch.as_tensor(cam["campos"], device="cuda")
         fac_sum += fac
+        common = torch.full((N, 12), float("nan"), device="cuda")
+        raster.pack_gradients_split(ctx, grads, N, common, rgb_all[r])
+        rgb_all[r, N] = torch.as_tensor(cam["campos"], device="cuda")
+        common_sum += common
         full = torch.empty(N, pw, device="cuda")
         ctx.pack_gradients_global(grads, L, N, full)
         full_sum += full
@@ -265,6 +271,9 @@ def test_factored_exchange_equals_full_rows(gpu, scene):
     assert np.isfinite(a).all()
     np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9)
     assert (a[:, -1] == b[:, -1]).all()  # visibility counts
+    out2 = torch.full((N, pw), float("nan"), device="cuda")
+    raster.unpack_gradients_split(dp["xyz"], common_sum, rgb_all, 3 * (N + 1), L, N, world, out2)
+    assert torch.equal(out2, out), "split (all-reduce + all-gather) and factored (one all-reduce) must agree exactly"
 
 
 def test_config2_forward_only(gpu, scene, orc):
