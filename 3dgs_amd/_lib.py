@@ -22,6 +22,7 @@ class GsplatError(RuntimeError):
 def build(force=False):
     """Compile every HIP source for gfx950 with hipcc (works without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    srcs.append(os.path.join(_CSRC, "host", "gs_dataset.cpp"))
     srcs.append(os.path.join(_HERE, "..", "include", "gsplat_hip.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -102,6 +103,8 @@ SIGNATURES = {
     "gsplat_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P]),
     "gsplat_optimizer_step": (_I, [_P, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
     "gsplat_optimizer_step_packed": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _P]),
+    "gsplat_initialize_gaussians": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "gsplat_knn_mean_distance": (_I, [_P, _I, _I, _P, _P]),
     "gsplat_compact_masked_array": (_I, [_P, _P, _I, _I, _P, ctypes.POINTER(_I), _P]),
     "gsplat_scatter_masked_array": (_I, [_P, _P, _I, _I, _P, _P]),
     "gsplat_context_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),

@@ -17,10 +17,12 @@ namespace {
 constexpr int kT = 16, kHalo = 5, kS = kT + 2 * kHalo;  // 26
 constexpr int kSpread = 256;
 
-__constant__ float cGauss[11] = {0.001028380123898387f,  0.0075987582094967365f, 0.036000773310661316f,
-                                 0.10936068743467331f,   0.21300552785396576f,   0.26601171493530273f,
-                                 0.21300552785396576f,   0.10936068743467331f,   0.036000773310661316f,
-                                 0.0075987582094967365f, 0.001028380123898387f};
+// 11-tap window (cuda/loss.cu:12-17); a constexpr table so that the fully unrolled taps become literal operands
+// (a v_fma with an SGPR operand issues 1.7x slower than one with a literal on this chip, profiles/microbench)
+constexpr float cGauss[11] = {0.001028380123898387f,  0.0075987582094967365f, 0.036000773310661316f,
+                              0.10936068743467331f,   0.21300552785396576f,   0.26601171493530273f,
+                              0.21300552785396576f,   0.10936068743467331f,   0.036000773310661316f,
+                              0.0075987582094967365f, 0.001028380123898387f};
 
 __device__ __forceinline__ float wave_sum(float v) {
   v = gs::row_sum(v);
@@ -84,16 +86,18 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(int H, int W, float s
       const float mu1 = o0, mu2 = o2, mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
       const float s1 = o1 - mu1_sq, s2 = o3 - mu2_sq, s12 = o4 - mu1 * mu2;
       const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu1 * mu2 + C1, D = 2.f * s12 + C2;
-      const float ssim = (Cc * D) / (A * B);
+      // the reference's six divisions (cuda/loss.cu:214-236) share two reciprocals: 1/A and 1/B
+      const float iA = __builtin_amdgcn_rcpf(A), iB = __builtin_amdgcn_rcpf(B), iAB = iA * iB;
+      const float ssim = Cc * D * iAB;
       const int ti = ((ly + kHalo) * kS + lx + kHalo) * 6;
       const float l1 = fabsf(sT[ti + c] - sT[ti + 3 + c]);
       loss += (1.0f - ssim_weight) * l1 + ssim_weight * (1.0f - ssim);
-      const float d_mu1 = ((mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * Cc) / (A * B) - (mu1 * 2.f * Cc * D) / (A * A * B) +
-                           (mu1 * 2.f * Cc * D) / (A * B * B));
+      const float two_mu1_ssim = 2.f * mu1 * ssim;
+      const float d_mu1 = 2.f * mu2 * (D - Cc) * iAB - two_mu1_ssim * iA + two_mu1_ssim * iB;
       const size_t id = ((size_t)py * W + px) * 3 + c;
       dm_mu[id] = -ssim_weight * d_mu1;
-      dm_s1[id] = -ssim_weight * ((-Cc * D) / (A * B * B));
-      dm_s12[id] = -ssim_weight * ((2.f * Cc) / (A * B));
+      dm_s1[id] = ssim_weight * (ssim * iB);
+      dm_s12[id] = -ssim_weight * (2.f * Cc * iAB);
     }
     __syncthreads();
   }

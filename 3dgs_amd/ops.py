@@ -141,6 +141,28 @@ def adam_step(params, param_grads, exp_avg, exp_avg_sq, lr, b1, b2, eps, bias1, 
                                        bias1, bias2, N, S, _stream()))
 
 
+def initialize_gaussians(points_xyz, points_rgb):
+    """Gaussians::Initialize (src/gaussian.cpp:38-104) on the GPU.  points_xyz: float64 [N,3] device tensor,
+    points_rgb: uint8 [N,3] device tensor.  Returns the parameter dict (xyz rgb opacity scale quaternion)."""
+    import torch
+    N = int(points_xyz.shape[0])
+    assert points_xyz.dtype == torch.float64 and points_rgb.dtype == torch.uint8
+    z = lambda *s: torch.empty(*s, dtype=torch.float32, device=points_xyz.device)
+    out = dict(xyz=z(N, 3), rgb=z(N, 3), opacity=z(N), scale=z(N, 3), quaternion=z(N, 4))
+    check(_lib.load().gsplat_initialize_gaussians(_p(points_xyz.contiguous()), _p(points_rgb.contiguous()), N,
+                                                  _p(out["xyz"]), _p(out["rgb"]), _p(out["opacity"]), _p(out["scale"]),
+                                                  _p(out["quaternion"]), _stream()))
+    return out
+
+
+def knn_mean_distance(points_xyz, k=3):
+    import torch
+    N = int(points_xyz.shape[0])
+    out = torch.empty(N, dtype=torch.float32, device=points_xyz.device)
+    check(_lib.load().gsplat_knn_mean_distance(_p(points_xyz.contiguous()), N, int(k), _p(out), _stream()))
+    return out
+
+
 def compact_masked_array(stride, d_source, d_mask, num_culled=None):
     """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride]."""
     N = int(d_mask.numel())

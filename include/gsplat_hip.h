@@ -186,6 +186,18 @@ int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gs
 int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int width, const gsplat_adam_group *groups,
                                  int n_groups, float b1, float b2, float eps, float bias1, float bias2, void *stream);
 
+/* replaces Gaussians::Initialize  (src/gaussian.cpp:38-104; host kd-tree + OpenMP in the reference): the initial
+ * gaussians of a sparse point cloud, computed on the GPU.  points_xyz [N,3] doubles and points_rgb [N,3] bytes are
+ * DEVICE arrays (COLMAP's Point3D fields, include/gsplat_host.h reads them); outputs are the GaussianParameters
+ * arrays: xyz [N,3], rgb [N,3] = (rgb/255 - 0.5)/C0, opacity [N] = logit(0.2), scale [N,3] = log(mean distance to the
+ * 3 nearest neighbours, 0.01 if there is none), quaternion [N,4] = (1,0,0,0).  Blocks the host (two small
+ * read-backs size the grid). */
+int gsplat_initialize_gaussians(const double *points_xyz, const unsigned char *points_rgb, int N, float *xyz, float *rgb,
+                                float *opacity, float *scale, float *quaternion, void *stream);
+/* the exact k-nearest-neighbour statistic on its own: mean_dist[i] = mean distance of point i to its k (1..8)
+ * nearest other points (duplicates count as neighbours at distance 0, as in the reference's kd-tree query) */
+int gsplat_knn_mean_distance(const double *points_xyz, int N, int k, float *mean_dist, void *stream);
+
 /* ------------------------------------------------------------- compaction templates --- */
 
 /* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]
