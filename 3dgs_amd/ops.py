@@ -163,6 +163,28 @@ def knn_mean_distance(points_xyz, k=3):
     return out
 
 
+def compute_morton_codes(N, d_xyz, x_max, y_max, z_max, x_min, y_min, z_min, codes):
+    """compute_morton_codes(...) (cuda_forward.cuh:186-188); codes: int64/uint64 device tensor [N]."""
+    check(_lib.load().gsplat_compute_morton_codes(N, _p(d_xyz), x_max, y_max, z_max, x_min, y_min, z_min, _p(codes),
+                                                  _stream()))
+
+
+_ATTRS = ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")
+
+
+def clone_gaussians(N, num_sh_coef, mask, write_ids, src, dst):
+    """clone_gaussians(...) (adaptive_density.cuh:27-31); src / dst: dicts xyz rgb opacity scale quaternion sh."""
+    check(_lib.load().gsplat_clone_gaussians(N, num_sh_coef, _p(mask), _p(write_ids), *[_p(src.get(k)) for k in _ATTRS],
+                                             *[_p(dst.get(k)) for k in _ATTRS], _stream()))
+
+
+def split_gaussians(N, scale_factor, num_sh_coef, mask, write_ids, src, dst, seed=0):
+    """split_gaussians(...) (adaptive_density.cuh:53-57) with an explicit seed."""
+    check(_lib.load().gsplat_split_gaussians(N, scale_factor, num_sh_coef, _p(mask), _p(write_ids),
+                                             *[_p(src.get(k)) for k in _ATTRS], *[_p(dst.get(k)) for k in _ATTRS],
+                                             int(seed), _stream()))
+
+
 def compact_masked_array(stride, d_source, d_mask, num_culled=None):
     """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride]."""
     N = int(d_mask.numel())

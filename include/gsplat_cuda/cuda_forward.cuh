@@ -84,3 +84,13 @@ inline float compute_psnr(const float *predicted_data, const float *gt_data, int
   gsplat_shim::require_ok(gsplat_compute_psnr(predicted_data, gt_data, rows, cols, &psnr, stream), "compute_psnr");
   return psnr;
 }
+
+// "next" row f4 operator (reference declaration: include/gsplat_cuda/cuda_forward.cuh:186-188)
+inline void compute_morton_codes(const int N, const float *d_xyz, const float x_max, const float y_max,
+                                 const float z_max, const float x_min, const float y_min, const float z_min,
+                                 uint64_t *codes, cudaStream_t stream = 0) {
+  static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "64-bit codes");
+  gsplat_shim::require_ok(gsplat_compute_morton_codes(N, d_xyz, x_max, y_max, z_max, x_min, y_min, z_min,
+                                                      reinterpret_cast<unsigned long long *>(codes), stream),
+                          "compute_morton_codes");
+}

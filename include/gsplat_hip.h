@@ -198,6 +198,27 @@ int gsplat_initialize_gaussians(const double *points_xyz, const unsigned char *p
  * nearest other points (duplicates count as neighbours at distance 0, as in the reference's kd-tree query) */
 int gsplat_knn_mean_distance(const double *points_xyz, int N, int k, float *mean_dist, void *stream);
 
+/* replaces compute_morton_codes  (cuda_forward.cuh:174-188, cuda/culling.cu:14-63): 63-bit Morton code of each
+ * position inside the given box, bit-exact with the reference (including its bit-spread masks). */
+int gsplat_compute_morton_codes(int N, const float *xyz, float x_max, float y_max, float z_max, float x_min,
+                                float y_min, float z_min, unsigned long long *codes, void *stream);
+
+/* replaces clone_gaussians  (adaptive_density.cuh:9-31, cuda/adaptive_density.cu:12-66): gaussians with mask[i] set
+ * are copied to row write_ids[i] (exclusive scan of the mask) of the output arrays.  mask is one byte per gaussian. */
+int gsplat_clone_gaussians(int N, int num_sh_coef, const unsigned char *mask, const int *write_ids, const float *xyz_in,
+                           const float *rgb_in, const float *op_in, const float *scale_in, const float *quat_in,
+                           const float *sh_in, float *xyz_out, float *rgb_out, float *op_out, float *scale_out,
+                           float *quat_out, float *sh_out, void *stream);
+
+/* replaces split_gaussians  (adaptive_density.cuh:33-57, cuda/adaptive_density.cu:68-164): every masked gaussian
+ * yields two gaussians at rows 2*write_ids[i] and 2*write_ids[i]+1: centres drawn from N(xyz, R diag(exp(scale))^2 R^T),
+ * scales log(exp(scale)/scale_factor), everything else copied.  `seed` makes the draw reproducible (the reference
+ * seeds from time(NULL); its C++ shim passes that). */
+int gsplat_split_gaussians(int N, float scale_factor, int num_sh_coef, const unsigned char *mask, const int *write_ids,
+                           const float *xyz_in, const float *rgb_in, const float *op_in, const float *scale_in,
+                           const float *quat_in, const float *sh_in, float *xyz_out, float *rgb_out, float *op_out,
+                           float *scale_out, float *quat_out, float *sh_out, unsigned long long seed, void *stream);
+
 /* ------------------------------------------------------------- compaction templates --- */
 
 /* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]

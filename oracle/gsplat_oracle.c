@@ -93,4 +93,82 @@ void orc_init_attributes(const double *pts, const unsigned char *colors, const f
   }
 }
 
+/* F4 operators.  compute_morton_codes: cuda/culling.cu:14-63 (the bit-spread masks are the reference's own). */
+static unsigned long long orc_spread_bits(unsigned long long n) {
+  n &= 0x1FFFFFull;
+  n = (n | (n << 32)) & 0x1F000000FFFFull;
+  n = (n | (n << 16)) & 0x1F0000FF0000FFull;
+  n = (n | (n << 8)) & 0x100F807C0F807C0Full;
+  n = (n | (n << 4)) & 0x1084210842108421ull;
+  n = (n | (n << 2)) & 0x1249249249249249ull;
+  return n;
+}
+static unsigned long long orc_to_u64(float v) {
+  if (!(v > 0.0f)) return 0ull;
+  if (v >= 18446744073709551616.0f) return ~0ull;
+  return (unsigned long long)v;
+}
+void orc_morton_codes(long n, const float *xyz, float x_max, float y_max, float z_max, float x_min, float y_min,
+                      float z_min, unsigned long long *codes) {
+  const float kMax = 2097151.0f;
+  for (long i = 0; i < n; ++i) {
+    const unsigned long long xq = orc_to_u64((xyz[3 * i] - x_min) * (kMax / (x_max - x_min)));
+    const unsigned long long yq = orc_to_u64((xyz[3 * i + 1] - y_min) * (kMax / (y_max - y_min)));
+    const unsigned long long zq = orc_to_u64((xyz[3 * i + 2] - z_min) * (kMax / (z_max - z_min)));
+    codes[i] = (orc_spread_bits(zq) << 2) | (orc_spread_bits(yq) << 1) | orc_spread_bits(xq);
+  }
+}
+
+/* split_gaussians: cuda/adaptive_density.cu:68-164 with the build's counter-based normal generator
+ * (3dgs_amd/csrc/gs_density.hip) in place of time-seeded cuRAND.  clone = the same copies without the draw. */
+static unsigned long long orc_splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static float orc_normal(unsigned long long seed, unsigned long long counter) {
+  const unsigned long long bits = orc_splitmix64(orc_splitmix64(seed) ^ (counter * 0xD1342543DE82EF95ull + 1ull));
+  const float u1 = (float)((bits >> 40) + 1ull) * (1.0f / 16777216.0f);
+  const float u2 = (float)((bits >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+void orc_clone_split(long n, int split, float scale_factor, int num_sh_coef, const unsigned char *mask,
+                     const int *write_ids, const float *xyz, const float *rgb, const float *op, const float *scale,
+                     const float *quat, const float *sh, float *xyz_o, float *rgb_o, float *op_o, float *scale_o,
+                     float *quat_o, float *sh_o, unsigned long long seed) {
+  const long w = (long)num_sh_coef * 3;
+  for (long i = 0; i < n; ++i) {
+    if (!mask[i]) continue;
+    const int copies = split ? 2 : 1;
+    const long base = (long)write_ids[i] * copies;
+    float Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, e[3] = {0, 0, 0};
+    if (split) {
+      for (int a = 0; a < 3; ++a) e[a] = expf(scale[3 * i + a]);
+      const float q0 = quat[4 * i], q1 = quat[4 * i + 1], q2 = quat[4 * i + 2], q3 = quat[4 * i + 3];
+      const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+      const float qw = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+      Rm[0] = 1.0f - 2.0f * (y * y + z * z); Rm[1] = 2.0f * (x * y - qw * z); Rm[2] = 2.0f * (x * z + qw * y);
+      Rm[3] = 2.0f * (x * y + qw * z); Rm[4] = 1.0f - 2.0f * (x * x + z * z); Rm[5] = 2.0f * (y * z - qw * x);
+      Rm[6] = 2.0f * (x * z - qw * y); Rm[7] = 2.0f * (y * z + qw * x); Rm[8] = 1.0f - 2.0f * (x * x + y * y);
+    }
+    for (int j = 0; j < copies; ++j) {
+      const long d = base + j;
+      float v[3] = {0, 0, 0};
+      if (split) {
+        const unsigned long long c = ((unsigned long long)i * 2ull + (unsigned long long)j) * 3ull;
+        for (int a = 0; a < 3; ++a) v[a] = orc_normal(seed, c + a) * e[a];
+      }
+      for (int a = 0; a < 3; ++a) {
+        xyz_o[3 * d + a] = xyz[3 * i + a] + (split ? (v[0] * Rm[3 * a] + v[1] * Rm[3 * a + 1] + v[2] * Rm[3 * a + 2]) : 0.0f);
+        scale_o[3 * d + a] = split ? logf(e[a] / scale_factor) : scale[3 * i + a];
+        rgb_o[3 * d + a] = rgb[3 * i + a];
+      }
+      op_o[d] = op[i];
+      for (int a = 0; a < 4; ++a) quat_o[4 * d + a] = quat[4 * i + a];
+      for (long k = 0; k < w; ++k) sh_o[d * w + k] = sh[i * w + k];
+    }
+  }
+}
+
 int orc_version(void) { return 1; }

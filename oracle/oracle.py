@@ -304,6 +304,35 @@ def initialize_gaussians(points, colors, threads=1):
     return out
 
 
+def compute_morton_codes(xyz, bbox_max, bbox_min):
+    """compute_morton_codes (cuda/culling.cu:41-63): uint64 codes, bit-exact restatement."""
+    p = _a(xyz, np.float32).reshape(-1, 3)
+    codes = np.empty(len(p), np.uint64)
+    f = ctypes.c_float
+    lib().orc_morton_codes(ctypes.c_long(len(p)), _p(p), f(bbox_max[0]), f(bbox_max[1]), f(bbox_max[2]), f(bbox_min[0]),
+                           f(bbox_min[1]), f(bbox_min[2]), _p(codes))
+    return codes
+
+
+def clone_split(g, mask, num_sh_coef, split=False, scale_factor=1.0, seed=0):
+    """clone_gaussians / split_gaussians (cuda/adaptive_density.cu:12-164) on a dict xyz rgb opacity scale quaternion
+    sh; returns the dict of new gaussians (count(mask) rows, twice that for a split)."""
+    mask = _a(mask, np.uint8)
+    n, copies = len(mask), 2 if split else 1
+    wid = (np.cumsum(mask) - mask).astype(np.int32)
+    m = int(mask.sum()) * copies
+    src = {k: _a(g[k], np.float32) for k in ("xyz", "rgb", "opacity", "scale", "quaternion")}
+    sh = _a(g["sh"], np.float32).reshape(n, -1) if num_sh_coef else np.zeros((n, 0), np.float32)
+    out = dict(xyz=np.zeros((m, 3), np.float32), rgb=np.zeros((m, 3), np.float32), opacity=np.zeros(m, np.float32),
+               scale=np.zeros((m, 3), np.float32), quaternion=np.zeros((m, 4), np.float32),
+               sh=np.zeros((m, num_sh_coef * 3), np.float32))
+    lib().orc_clone_split(ctypes.c_long(n), int(split), ctypes.c_float(scale_factor), int(num_sh_coef), _p(mask), _p(wid),
+                          _p(src["xyz"]), _p(src["rgb"]), _p(src["opacity"]), _p(src["scale"]), _p(src["quaternion"]),
+                          _p(sh), _p(out["xyz"]), _p(out["rgb"]), _p(out["opacity"]), _p(out["scale"]),
+                          _p(out["quaternion"]), _p(out["sh"]), ctypes.c_ulonglong(seed))
+    return out
+
+
 # ------------------------------------------------------------------------------ sequencing
 def rasterize(params, camera, near_thresh, mh_dist, padding, bg, l_max, dtype=np.float32, threads=1):
     """Restates rasterize_image (cuda/raster.cu:12-136).

@@ -9,6 +9,7 @@
 
 #include "gsplat_cuda/cuda_backward.cuh"
 #include "gsplat_cuda/cuda_forward.cuh"
+#include "gsplat_cuda/adaptive_density.cuh"
 #include "gsplat_cuda/optimizer.cuh"
 
 static int failures = 0;
@@ -122,6 +123,27 @@ int main() {
       const float step = -lr * (ea / (1.0f - B1)) / (std::sqrt(es / (1.0f - B2)) + EPS);
       EXPECT_NEAR(op[i], hp[i] + step, 1e-6); EXPECT_NEAR(om[i], ea, 1e-6); EXPECT_NEAR(ov[i], es, 1e-6);
     }
+  }
+  {  // ComputeMortonCodes corner cases + SplitGaussiansTest scales (tests/cuda_forward_test.cpp:918, adaptive_density_test.cpp:235)
+    float *xyz = to_device<float>({-10.f, -5.f, 0.f, 10.f, 5.f, 20.f});
+    uint64_t *codes = reinterpret_cast<uint64_t *>(to_device<unsigned long long>({1ull, 1ull}));
+    compute_morton_codes(2, xyz, 10.f, 5.f, 20.f, -10.f, -5.f, 0.f, codes);
+    auto hc = to_host(reinterpret_cast<unsigned long long *>(codes), 2);
+    EXPECT_NEAR(hc[0] == 0ull, 1, 0);
+    EXPECT_NEAR(hc[1] != 0ull, 1, 0);
+    bool *mask = reinterpret_cast<bool *>(to_device<unsigned char>({1, 0}));
+    int *wid = to_device<int>({0, 1});
+    float *p3 = to_device<float>({1, 2, 3, 4, 5, 6}), *op = to_device<float>({0.8f, 0.7f});
+    float *sc = to_device<float>({std::log(2.f), std::log(2.f), std::log(2.f), std::log(.1f), std::log(.1f), std::log(.1f)});
+    float *qt = to_device<float>({1, 0, 0, 0, 1, 0, 0, 0});
+    float *o3 = to_device<float>(std::vector<float>(12)), *oo = to_device<float>(std::vector<float>(4));
+    float *os = to_device<float>(std::vector<float>(12)), *oq = to_device<float>(std::vector<float>(16)), *or3 = to_device<float>(std::vector<float>(12));
+    split_gaussians(2, 1.6f, 0, mask, wid, p3, p3, op, sc, qt, nullptr, o3, or3, oo, os, oq, nullptr);
+    auto hs = to_host(os, 6);
+    for (int i = 0; i < 6; ++i) EXPECT_NEAR(hs[i], std::log(2.0f / 1.6f), 1e-6);
+    clone_gaussians(2, 0, mask, wid, p3, p3, op, sc, qt, nullptr, o3, or3, oo, os, oq, nullptr);
+    auto hx = to_host(o3, 3);
+    EXPECT_NEAR(hx[0], 1.0, 1e-6); EXPECT_NEAR(hx[2], 3.0, 1e-6);
   }
   (void)hipDeviceSynchronize();
   if (failures == 0) std::printf("shim_test: all checks passed\n");
