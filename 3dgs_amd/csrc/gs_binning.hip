@@ -83,14 +83,16 @@ __global__ __launch_bounds__(kBlock) void tile_emit_payload_kernel(const float *
                                                                    int N, const unsigned char *__restrict__ mask,
                                                                    const int *__restrict__ rank,
                                                                    const int *__restrict__ offsets,
+                                                                   long long capacity,
                                                                    unsigned int *__restrict__ keys,
                                                                    unsigned long long *__restrict__ payload) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N || (mask && !mask[i])) return;
   const int j = rank ? rank[i] : i;
   int w = offsets[j];
-  const int end = offsets[j + 1];
-  if (w == end) return;
+  // `capacity` bounds the writes when the kernel is launched before the host knows the instance total
+  const int end = (int)min((long long)offsets[j + 1], capacity);
+  if (w >= end) return;
   const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
   const float u = uv[2 * j], v = uv[2 * j + 1];
   const unsigned long long pay = ((unsigned long long)float_sort_bits(xyz_c[3 * j + 2]) << 32) | (unsigned int)j;
@@ -219,19 +221,31 @@ int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_
   return GSPLAT_OK;
 }
 
+// The emit step on its own: the fused forward launches it with the buffers' capacity BEFORE it waits for the
+// instance total S, so the GPU works through it while the host sleeps on the read-back.
+int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
+                     const unsigned char *mask, const int *rank, const int *offsets, long long capacity,
+                     unsigned int *tkeys, unsigned long long *payload, hipStream_t st) {
+  tile_emit_payload_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets,
+                                                                capacity, tkeys, payload);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
 // emit -> sort by tile -> ranges -> per-tile depth sort.  pay_a/pay_b: S 64-bit payloads each.
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
-                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st) {
+                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st, bool already_emitted) {
   const int num_tiles = ntx * nty;
   if (S == 0) {
     GS_HIP(hipMemsetAsync(ranges, 0, (size_t)(num_tiles + 1) * sizeof(int), st));
     return GSPLAT_OK;
   }
-  tile_emit_payload_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets,
-                                                                tkeys_a, pay_a);
-  GS_LAUNCH_CHECK();
+  if (!already_emitted) {
+    const int rc = launch_tile_emit(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets, (long long)S, tkeys_a, pay_a, st);
+    if (rc) return rc;
+  }
   GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, tkeys_a, tkeys_b, pay_a, pay_b, S, 0,
                                                    tile_bits(num_tiles), st));
   tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_b, (int)S, num_tiles, ranges);
@@ -306,7 +320,7 @@ extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz
   rc = emit_sort_ranges(uv, xyz, radius, n_tiles_x, n_tiles_y, N, nullptr, nullptr, offsets.as<int>(), S,
                         ka.as<unsigned int>(), kb.as<unsigned int>(), pa.as<unsigned long long>(),
                         pb.as<unsigned long long>(), sorted_gaussians, splat_start_end_idx_by_tile_idx, tmp.ptr,
-                        tmp.bytes, st);
+                        tmp.bytes, st, false);
   if (rc) return rc;
   // the reference returns only after its blocking read-backs; keep that contract
   GS_HIP(hipStreamSynchronize(st));

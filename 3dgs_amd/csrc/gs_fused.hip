@@ -15,6 +15,8 @@
 #include <new>
 #include <rocprim/rocprim.hpp>
 
+#include <cstdlib>
+
 #include "gs_common.h"
 #include "gs_math.h"
 #include "gs_render.h"
@@ -26,7 +28,10 @@ int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
-                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st);
+                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st, bool already_emitted);
+int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
+                     const unsigned char *mask, const int *rank, const int *offsets, long long capacity,
+                     unsigned int *tkeys, unsigned long long *payload, hipStream_t st);
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st);
@@ -46,6 +51,13 @@ struct gsplat_context {
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
+  // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
+  volatile unsigned long long *h_pub = nullptr;
+  unsigned long long *d_pub = nullptr, ticket = 0;
+  // 64 spread counters + the 16-byte {M, S, pairs} record, parked behind the N+1 scan flags
+  unsigned long long *pair_counters() const {
+    return reinterpret_cast<unsigned long long *>(flags.as<char>() + (((size_t)max_gaussians + 1) * 4 + 63) / 64 * 64);
+  }
   // optional per-stage HIP-event timing (gsplat_context_set_timing)
   static constexpr int kStages = 8, kSlots = 32;
   bool timing = false;
@@ -87,6 +99,7 @@ struct gsplat_context {
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
+    if (h_pub) { (void)hipHostFree((void *)h_pub); h_pub = nullptr; d_pub = nullptr; }
     for (int a = 0; a < kSlots; ++a)
       for (int b = 0; b < 2 * kStages; ++b)
         if (ev[a][b]) { (void)hipEventDestroy(ev[a][b]); ev[a][b] = nullptr; }
@@ -104,8 +117,10 @@ __global__ __launch_bounds__(kBlock) void project_cull_kernel(const float *__res
                                                               int height, float near_thresh, int padding,
                                                               float *__restrict__ xyz_c, float *__restrict__ uv,
                                                               unsigned char *__restrict__ mask,
-                                                              int *__restrict__ flags) {
+                                                              int *__restrict__ flags,
+                                                              unsigned long long *__restrict__ pair_counters) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < 64) pair_counters[i] = 0ull;  // consumed by preprocess_kernel, two launches later on the same stream
   if (i >= N) {
     if (i == N) flags[N] = 0;
     return;
@@ -142,6 +157,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int N = g.num_gaussians;
   unsigned long long coarse = 0;
+  // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
+  // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
+  if (i <= N && i >= rank[N]) o.counts[i] = 0;
   if (i < N && mask[i]) {
   const int j = rank[i];
   constexpr int n = (L + 1) * (L + 1);
@@ -186,6 +204,26 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) coarse += __shfl_down(coarse, off, 64);
   if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(&o.pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], coarse);
+}
+
+// {M, S, candidate pairs} gathered into one 16-byte record so that the forward's only read-back is one copy
+__global__ __launch_bounds__(64) void publish_counts_kernel(const int *__restrict__ rank_total,
+                                                            const int *__restrict__ offsets_total,
+                                                            const unsigned long long *__restrict__ pair_counters,
+                                                            volatile unsigned long long *out,
+                                                            unsigned long long ticket) {
+  // `out` is pinned host memory mapped into the device: the host polls out[2] for its ticket instead of paying a
+  // copy + stream synchronisation, and the kernels queued behind this one keep the GPU busy meanwhile
+  unsigned long long v = pair_counters[threadIdx.x];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if (threadIdx.x == 0) {
+    out[0] = ((unsigned long long)(unsigned int)*offsets_total << 32) | (unsigned long long)(unsigned int)*rank_total;
+    out[1] = v;
+    __threadfence_system();
+    out[2] = ticket;
+    __threadfence_system();
+  }
 }
 
 struct BwdOut {
@@ -499,7 +537,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   const size_t T = (size_t)((max_width + 15) / 16) * ((max_height + 15) / 16);
   int rc = GSPLAT_OK;
   auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
-  R(c->mask, N + 16); R(c->flags, (N + 1) * 4 + 512); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
+  R(c->mask, N + 16); R(c->flags, (N + 1) * 4 + 1024); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64);
@@ -511,6 +549,18 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
     rc = c->temp.reserve(sb1 > sb2 ? sb1 : sb2);
   }
   if (!rc) rc = reserve_instances(c, 4 * N, (int)T);
+  if (!rc) {
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      gs::set_error("gsplat_context_create: could not map the count record");
+      rc = GSPLAT_ERR_HIP;
+    } else {
+      memset(h, 0, 64);
+      c->h_pub = (volatile unsigned long long *)h;
+      c->d_pub = (unsigned long long *)d;
+    }
+  }
   if (!rc && hipHostMalloc((void **)&c->h_words, 1024, hipHostMallocDefault) != hipSuccess) {
     gs::set_error("gsplat_context_create: hipHostMalloc failed");
     rc = GSPLAT_ERR_HIP;
@@ -561,7 +611,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->mark(0, false, st);
   project_cull_kernel<<<gridN, block, 0, st>>>(g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh,
                                                cfg->cull_mask_padding, c->xyz_c_all.as<float>(), c->uv_all.as<float>(),
-                                               c->mask.as<unsigned char>(), c->flags.as<int>());
+                                               c->mask.as<unsigned char>(), c->flags.as<int>(), c->pair_counters());
   GS_LAUNCH_CHECK();
   size_t scan_bytes = c->temp.bytes;
   GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->flags.as<int>(), c->rank.as<int>(), 0, (size_t)N + 1,
@@ -571,9 +621,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->mark(1, false, st);
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
                c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
-               reinterpret_cast<unsigned long long *>(c->flags.ptr)};  // flags are dead after the scan
-  GS_HIP(hipMemsetAsync(c->counts.ptr, 0, (size_t)(N + 1) * sizeof(int), st));
-  GS_HIP(hipMemsetAsync(c->flags.ptr, 0, 64 * sizeof(unsigned long long), st));
+               c->pair_counters()};
 #define GS_PRE(LL)                                                                                                     \
   preprocess_kernel<LL><<<gridN, block, 0, st>>>(*g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(),        \
                                                  c->xyz_c_all.as<float>(), c->uv_all.as<float>(), fx, fy, tan_fovx,    \
@@ -591,30 +639,54 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   if (rc) return rc;
   c->mark(1, true, st);
   // the one host read-back of the forward: M, S (and the candidate count)
-  GS_HIP(hipMemcpyAsync(&c->h_words[0], c->rank.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(&c->h_words[1], c->offsets.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(&c->h_words[2], c->flags.ptr, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  GS_HIP(hipStreamSynchronize(st));
-  const int M = c->h_words[0];
-  const size_t S = (size_t)c->h_words[1];
-  unsigned long long pairs = 0;
-  for (int k = 0; k < 64; ++k) {
-    unsigned long long part;
-    memcpy(&part, &c->h_words[2 + 2 * k], sizeof(part));
-    pairs += part;
+  const unsigned long long ticket = ++c->ticket;
+  publish_counts_kernel<<<1, 64, 0, st>>>(c->rank.as<int>() + N, c->offsets.as<int>() + N, c->pair_counters(),
+                                         c->d_pub, ticket);
+  GS_LAUNCH_CHECK();
+  // Emit does not need the totals on the host, only room for its writes: launch it bounded by the buffers' capacity
+  // and sleep on the read-back while it runs (the reference blocks five times per forward with the GPU idle).
+  const size_t inst_cap = c->keys_a.bytes / sizeof(unsigned int) - 1;
+  c->mark(2, false, st);
+  rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
+                            c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), (long long)inst_cap,
+                            c->keys_a.as<unsigned int>(), c->pay_a.as<unsigned long long>(), st);
+  if (rc) return rc;
+  {
+    // Poll the mapped record; every few hundred polls ask the runtime about the stream, which both keeps its
+    // submission path moving and tells us when everything queued so far (emit included) has drained.
+    volatile unsigned long long *pub = c->h_pub;
+    long long polls = 0;
+    while (__atomic_load_n(&pub[2], __ATOMIC_ACQUIRE) != ticket) {
+      if ((++polls & 255) == 0) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) {  // stream drained: the record must be there now
+          if (__atomic_load_n(&pub[2], __ATOMIC_ACQUIRE) == ticket) break;
+          gs::set_error("gsplat_rasterize_image: the count record never arrived");
+          return GSPLAT_ERR_HIP;
+        }
+        if (q != hipErrorNotReady) {
+          gs::set_error("gsplat_rasterize_image: %s while waiting for the counts", hipGetErrorString(q));
+          return GSPLAT_ERR_HIP;
+        }
+      }
+      __builtin_ia32_pause();
+    }
   }
+  const unsigned long long word0 = c->h_pub[0], pairs = c->h_pub[1];
+  const int M = (int)(unsigned int)(word0 & 0xFFFFFFFFull);
+  const size_t S = (size_t)(word0 >> 32);
   if (M == 0) {
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;
   }
+  const bool emitted = S <= inst_cap;  // else: grow the instance buffers (synchronises) and emit again
   rc = reserve_instances(c, S, num_tiles);
   if (rc) return rc;
-  c->mark(2, false, st);
   rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                             c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
                             c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
                             c->pay_a.as<unsigned long long>(), c->pay_b.as<unsigned long long>(), c->sorted.as<int>(),
-                            c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st);
+                            c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st, emitted);
   if (rc) return rc;
   c->mark(2, true, st);
   c->mark(4, false, st);

@@ -10,6 +10,7 @@ all-reduce per step (weak scaling: value = views/s over all ranks).
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -66,6 +67,8 @@ def main():
     for _ in range(args.warmup):
         fwd = one_step()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()  # a generation-2 collection in the middle of a timed loop costs tens of milliseconds
     step.ctx.set_timing(True)
     if world > 1:
         dist.barrier()
@@ -85,6 +88,7 @@ def main():
     step.ctx.set_timing(False)
 
     if rank != 0:
+        gc.enable()
         if world > 1:
             dist.barrier()
         return
@@ -113,10 +117,16 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     reps = max(5, min(args.steps, 30))
+    call_ms = []
     for _ in range(reps):
+        ta = time.perf_counter()
         step.ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+        call_ms.append((time.perf_counter() - ta) * 1e3)
     torch.cuda.synchronize()
     fps = reps / (time.perf_counter() - t1)
+    gc.enable()
+    if os.environ.get("GSPLAT_BENCH_DEBUG"):
+        print("forward-only host ms per call:", " ".join(f"{t:.2f}" for t in call_ms), file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a CPU restatement of the reference; the reference has no CPU rasterizer)
     cpu = None
