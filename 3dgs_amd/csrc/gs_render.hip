@@ -75,7 +75,7 @@ struct RowCounts { int c0, c1, c2, c3; };
 // record arrays (slot * 16), so the loop needs no shift; counts are wave-uniform.
 template <int kStride>
 __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigned short *lists, int count, int wave,
-                                                     int lane, int lim0, int lim1, int lim2, int lim3) {
+                                                     int lane, int lim0, int lim1, int lim2, int lim3, int round) {
   RowCounts rc = {0, 0, 0, 0};
   const int b0 = wave_first_bit(wave);
   for (int sb = 0; sb < count; sb += 64) {
@@ -93,6 +93,17 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
 #undef GS_MBCNT
     rc.c0 += __popcll(m0); rc.c1 += __popcll(m1); rc.c2 += __popcll(m2); rc.c3 += __popcll(m3);
   }
+  // Pad the shorter lists up to the wave's trip count (rounded up to `round`) with the sentinel slot kStride, whose
+  // record is all zeros (opacity 0 -> alpha 0): a row past the end of its list then needs no "am I active" test.
+  const int longest = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+  const int padded = (longest + round - 1) / round * round;
+  const unsigned short sentinel = (unsigned short)(kStride << 4);
+  for (int k = lane; k < padded; k += 64) {
+    if (k >= rc.c0) lists[0 * kStride + k] = sentinel;
+    if (k >= rc.c1) lists[1 * kStride + k] = sentinel;
+    if (k >= rc.c2) lists[2 * kStride + k] = sentinel;
+    if (k >= rc.c3) lists[3 * kStride + k] = sentinel;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   return rc;
@@ -105,11 +116,12 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
                                                               int ntx, int num_tiles, float bg,
                                                               int *__restrict__ n_out, float *__restrict__ T_out,
                                                               float *__restrict__ image) {
-  __shared__ float4 s_r0[kBatch], s_r1[kBatch], s_r2[kBatch];
-  __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride];
+  __shared__ float4 s_r0[kBatch + 1], s_r1[kBatch + 1], s_r2[kBatch + 1];  // [kBatch]: the all-zero sentinel record
+  __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride + 2];
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
+  if (tid == 0) s_r0[kBatch] = s_r1[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   const int tile_x = tile % ntx, tile_y = tile / ntx;
   const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
   const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
@@ -120,9 +132,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   const unsigned short *my_list = lists + row * kListStride;
   const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
   const char *r2b = reinterpret_cast<const char *>(s_r2);
-
-  // a row past the end of its list reads stale entries: make sure they are always valid offsets
-  for (int k = tid; k < 16 * kListStride / 2; k += 256) reinterpret_cast<unsigned int *>(s_list)[k] = 0u;
 
   const int start = ranges[tile], total = ranges[tile + 1] - start;
   // A saturated pixel keeps T = 0 in the running transmittance, so every later splat blends with weight 0 and the
@@ -140,8 +149,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
       SplatRec s = load_record<kPacked>(g, recs, raw);
       s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
-    } else {  // rows past the end of their list read stale slots: keep every slot finite
-      s_r0[tid] = s_r1[tid] = s_r2[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
     if (live > 0) {
@@ -151,15 +158,13 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
                                            (unsigned int)(satmask & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 16) & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 32) & 0xFFFFull) == 0xFFFFu ? 0 : big,
-                                           (unsigned int)((satmask >> 48) & 0xFFFFull) == 0xFFFFu ? 0 : big);
+                                           (unsigned int)((satmask >> 48) & 0xFFFFull) == 0xFFFFu ? 0 : big, 2);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
-      const int my_cnt = row == 0 ? rc.c0 : (row == 1 ? rc.c1 : (row == 2 ? rc.c2 : rc.c3));
       for (int i = 0; i < trips; i += 2) {
         // two list entries per trip: both records are fetched and both exponentials evaluated before the
-        // (sequential) blending; a row past the end of its list blends with alpha 0
+        // (sequential) blending; a row past the end of its list reads the sentinel record and blends with alpha 0
         const unsigned int two = *reinterpret_cast<const unsigned int *>(my_list + i);
         const int off0 = two & 0xFFFFu, off1 = two >> 16;
-        const bool act0 = i < my_cnt, act1 = i + 1 < my_cnt;
         const float4 a0 = *reinterpret_cast<const float4 *>(r0b + off0), c0 = *reinterpret_cast<const float4 *>(r2b + off0);
         const float2 b0 = *reinterpret_cast<const float2 *>(r1b + off0);
         const float4 a1 = *reinterpret_cast<const float4 *>(r0b + off1), c1 = *reinterpret_cast<const float4 *>(r2b + off1);
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
         const float p1 = fminf(0.0f, gauss_power(a1.z, a1.w, b1.x, a1.x - fpx, a1.y - fpy));
         float al0 = fminf(kAlphaMax, b0.y * __expf(p0));
         float al1 = fminf(kAlphaMax, b1.y * __expf(p1));
-        al0 = (al0 > kAlphaMin && act0) ? al0 : 0.0f;
-        al1 = (al1 > kAlphaMin && act1) ? al1 : 0.0f;
+        al0 = al0 > kAlphaMin ? al0 : 0.0f;
+        al1 = al1 > kAlphaMin ? al1 : 0.0f;
         // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T * (1 - alpha) < 1e-4" alone
         // decides the next T; the compare's lane mask doubles as the saturation bookkeeping.
         const float w0 = al0 * T;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
                                                               const float *__restrict__ grad_image, int width,
                                                               int height, int ntx, int num_tiles, float bg,
                                                               GradOut out) {
-  __shared__ float4 s_r0[kB], s_r1[kB], s_r2[kB];
+  __shared__ float4 s_r0[kB + 1], s_r1[kB + 1], s_r2[kB + 1];  // [kB]: the all-zero sentinel record
   // [slot][9]: rgb, S0, Sx, Sy, Sxx, Sxy, Syy.  Doubles on purpose: on gfx950 ds_add_f32 retires about one LANE
   // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
   // a 36-lane instruction), and the merge across the tile's 16 blocks needs one atomic per trip.
@@ -268,9 +273,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
   const int rt0 = __builtin_amdgcn_readlane(row_top_v, 0), rt1 = __builtin_amdgcn_readlane(row_top_v, 16);
   const int rt2 = __builtin_amdgcn_readlane(row_top_v, 32), rt3 = __builtin_amdgcn_readlane(row_top_v, 48);
   const int wave_top = max(max(rt0, rt1), max(rt2, rt3));
-  if (tid == 0) s_top = 0;
-  // a row past the end of its list reads stale entries: make sure they are always valid offsets
-  for (int k = tid; k < 16 * kB / 2; k += 256) reinterpret_cast<unsigned int *>(s_list)[k] = 0u;
+  if (tid == 0) {
+    s_top = 0;
+    s_r0[kB] = s_r1[kB] = s_r2[kB] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   __syncthreads();
   if (lane == 0) atomicMax(&s_top, wave_top);
   __syncthreads();
@@ -289,15 +295,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
       s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
       s_id[tid] = g;
-    } else if (tid < kB) {  // rows past the end of their list read stale slots: keep every slot finite
-      s_r0[tid] = s_r1[tid] = s_r2[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     for (int k = tid; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
     __syncthreads();
     if (base < wave_top) {
-      const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, wave, lane, rt0 - base, rt1 - base, rt2 - base, rt3 - base);
+      const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, wave, lane, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
-      const int my_cnt = row == 0 ? rc.c0 : (row == 1 ? rc.c1 : (row == 2 ? rc.c2 : rc.c3));
       const int n_rel = (n - base) * 16;  // "base + slot < n" on byte offsets
       for (int i = trips - 1; i >= 0; --i) {
         const int off = my_list[i];
@@ -308,9 +311,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         float gg = __expf(power);
         const float opa = b.y;
         float alpha = fminf(kAlphaMax, opa * gg);
-        // a row past the end of its list reads a stale slot: selects (not multiplies) so that garbage cannot
-        // poison the pixel state.  n is 0 for pixels outside the image, so "inside" needs no separate test.
-        const bool valid = (alpha >= kAlphaMin) && (off < n_rel) && (i < my_cnt);
+        // a row past the end of its list reads the sentinel record (alpha 0).  n is 0 for pixels outside the image,
+        // so "inside" needs no separate test.
+        const bool valid = (alpha >= kAlphaMin) && (off < n_rel);
         if (__ballot(valid) == 0ull) continue;
         alpha = valid ? alpha : 0.0f;
         gg = valid ? gg : 0.0f;
@@ -332,13 +335,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(gp), "v"(gpx), "v"(gpy), "v"(gpx * dx), "v"(gpx * dy), "v"(gpy * dy));
 #else
         const float red = row_sum9(v0, v1, v2, gp, gpx, gpy, gpx * dx, gpx * dy, gpy * dy);
-        // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
-        // gaussian (opa == 1) gets no gradient at all; all-zero sums add nothing either way
+        // all-zero sums (rows past their list, blocks without a valid pixel) add nothing: skip their atomics
 #if GS_ABLATE == 1
         asm volatile("" ::"v"(red));
 #else
-        if (red_lane && i < my_cnt && opa != 1.0f && red != 0.0f)
-          atomicAdd(reinterpret_cast<double *>(accb + off * 5 + red_idx * 8), (double)red);
+        if (red_lane && red != 0.0f) atomicAdd(reinterpret_cast<double *>(accb + off * 5 + red_idx * 8), (double)red);
 #endif
 #endif
       }
@@ -351,6 +352,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
       for (int r = 0; r < kB / 16; ++r) {
         const int slot = r * 16 + (tid >> 4);
         if (slot >= count) continue;
+        // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
+        // gaussian (sigmoid(opacity) == 1) gets no gradient at all
+        if (s_r1[slot].y == 1.0f) continue;
         const double *acc = &s_acc[slot * kAcc];
         float val;
         if (k < 3) {
