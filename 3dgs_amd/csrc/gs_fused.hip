@@ -28,10 +28,12 @@ int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
-                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st, bool already_emitted);
+                     int *ranges, void *temp, size_t temp_bytes, hipStream_t st, bool already_emitted,
+                     const unsigned long long *hitmask);
 int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
-                     const unsigned char *mask, const int *rank, const int *offsets, long long capacity,
-                     unsigned int *tkeys, unsigned long long *payload, hipStream_t st);
+                     const unsigned char *mask, const int *rank, const int *offsets,
+                     const unsigned long long *hitmask, long long capacity, unsigned int *tkeys,
+                     unsigned long long *payload, hipStream_t st);
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st);
@@ -45,7 +47,7 @@ struct gsplat_context {
   // per-gaussian, global order
   gs::DeviceBuffer mask, flags, rank, xyz_c_all, uv_all;
   // per-gaussian, compacted order
-  gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows;
+  gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows, hitmask;
   // instances
   gs::DeviceBuffer keys_a, keys_b, pay_a, pay_b, sorted, temp;
   // per tile / pixel
@@ -86,7 +88,7 @@ struct gsplat_context {
   bool have_forward = false;
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
-                                     &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &pay_a, &pay_b,
+                                     &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                      &sorted, &temp, &ranges, &image, &T_px, &n_px};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
@@ -94,7 +96,7 @@ struct gsplat_context {
   }
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
-                               &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &keys_a, &keys_b, &pay_a, &pay_b,
+                               &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                &sorted, &temp, &ranges, &image, &T_px, &n_px};
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
@@ -142,6 +144,7 @@ struct PreOut {
   float *xyz_c, *uv, *sigma, *conic, *J, *rgb, *radius;
   float4 *recs;
   int *counts;
+  unsigned long long *hitmask;  // per gaussian: one bit per tile of its coarse rectangle (rectangles of <= 64 tiles)
   unsigned long long *pairs;  // 64 spread counters of coarse candidate pairs (reporting only)
 };
 
@@ -179,16 +182,23 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
   gs::conic_radius(J, sg, vw, mh_dist, con, rad);
   // exact tile count
   int hits = 0;
+  unsigned long long hm = 0ull;
   const gs::TileRect r = gs::coarse_rect(u, v, rad[0], ntx, nty);
   if (r.x1 > r.x0 && r.y1 > r.y0) {
     coarse = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
     const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
+    int bit = 0;
     for (int tx = r.x0; tx < r.x1; ++tx)
-      for (int ty = r.y0; ty < r.y1; ++ty) hits += gs::obb_hits_tile(ob, tx, ty) ? 1 : 0;
+      for (int ty = r.y0; ty < r.y1; ++ty, ++bit) {
+        const bool h = gs::obb_hits_tile(ob, tx, ty);
+        hits += h ? 1 : 0;
+        hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the emit kernel when the rectangle has <= 64 tiles
+      }
   }
   // stores (compacted order)
   o.c2g[j] = i;
   o.counts[j] = hits;
+  o.hitmask[j] = hm;
   o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
   o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
 #pragma unroll
@@ -540,7 +550,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   R(c->mask, N + 16); R(c->flags, (N + 1) * 4 + 1024); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
-  R(c->grad_rows, N * 64);
+  R(c->grad_rows, N * 64); R(c->hitmask, N * 8);
   R(c->ranges, (T + 1) * 4); R(c->image, P * 12); R(c->T_px, P * 4); R(c->n_px, P * 4);
   if (!rc) {
     size_t sb1 = 0;
@@ -621,7 +631,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->mark(1, false, st);
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
                c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
-               c->pair_counters()};
+               c->hitmask.as<unsigned long long>(), c->pair_counters()};
 #define GS_PRE(LL)                                                                                                     \
   preprocess_kernel<LL><<<gridN, block, 0, st>>>(*g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(),        \
                                                  c->xyz_c_all.as<float>(), c->uv_all.as<float>(), fx, fy, tan_fovx,    \
@@ -648,7 +658,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   const size_t inst_cap = c->keys_a.bytes / sizeof(unsigned int) - 1;
   c->mark(2, false, st);
   rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
-                            c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), (long long)inst_cap,
+                            c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
+                            c->hitmask.as<unsigned long long>(), (long long)inst_cap,
                             c->keys_a.as<unsigned int>(), c->pay_a.as<unsigned long long>(), st);
   if (rc) return rc;
   {
@@ -686,7 +697,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
                             c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
                             c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
                             c->pay_a.as<unsigned long long>(), c->pay_b.as<unsigned long long>(), c->sorted.as<int>(),
-                            c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st, emitted);
+                            c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st, emitted,
+                            c->hitmask.as<unsigned long long>());
   if (rc) return rc;
   c->mark(2, true, st);
   c->mark(4, false, st);
