@@ -14,7 +14,7 @@
 //   * each wave compacts, per row, the batch's slots that hit the row's block into a byte list in LDS, and every
 //     row walks ITS OWN list: in one loop trip the four rows of a wave work on four different (gaussian, block)
 //     pairs and a wave's trip count is the longest of its four lists -- on the benchmark scene 1.37x fewer trips
-//     than visiting (gaussian, 8x8 quadrant) pairs (tools/model_trips.py).  Skipping is exact: a skipped gaussian
+//     than visiting (gaussian, 8x8 quadrant) pairs (tests/analysis/model_trips.py).  Skipping is exact: a skipped gaussian
 //     has alpha < 1/255 on every pixel of the block;
 //   * forward: a row whose 16 pixels are saturated gets no list, a wave stops when its 64 pixels are saturated, the
 //     workgroup when all four waves have;

@@ -1,8 +1,8 @@
 """Numpy model of compositing loop trips on the benchmark scene: today's (quadrant, gaussian) visits vs per-row
-(4x4 sub-block) queues where a wave's trip count is the max over its four sub-blocks.  CPU only (uses the oracle)."""
+(4x4 sub-block) queues where a wave's trip count is the max over its four sub-blocks.  CPU only; uses the oracle, hence it lives under tests/ (test infrastructure)."""
 import importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 scene = importlib.import_module("3dgs_amd.scene")
 from oracle import oracle as orc
 
