@@ -15,6 +15,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "gs_common.h"
 #include "gs_math.h"
