@@ -96,6 +96,8 @@ SIGNATURES = {
     "gsplat_compute_sigma_backward": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "gsplat_precompute_spherical_harmonics_backward": (_I, [_P, _P, _P, _F, _F, _F, _P, _I, _I, _P, _P, _P, _P]),
     "gsplat_render_image_backward": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "gsplat_backward_render": (_I, [_P, _P, _F, _P, _P]),
+    "gsplat_backward_gaussians": (_I, [_P, _P, _P, _I, _P, _P]),
     "gsplat_pack_gradients_split": (_I, [_P, _P, _I, _P, _P, _P]),
     "gsplat_unpack_gradients_split": (_I, [_P, _P, _P, _S, _I, _I, _I, _P, _P]),
     "gsplat_fused_loss": (_I, [_P, _P, _I, _I, _F, _P, ctypes.POINTER(ctypes.c_float), _P]),

@@ -53,6 +53,7 @@ struct gsplat_context {
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
+  bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
   // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
@@ -399,6 +400,18 @@ __global__ __launch_bounds__(kBlock) void unpack_factored_kernel(const float *__
   out[11 + 3 * n] = row[11];                                           // visibility count
 }
 
+// g_rgb of this view in global gaussian order, straight from the compositing backward's rows (rows[j][0..2]):
+// available before the per-gaussian backward has run, so its all-gather can overlap that kernel.
+__global__ __launch_bounds__(kBlock) void scatter_rgb_rows_kernel(const unsigned char *__restrict__ mask,
+                                                                  const int *__restrict__ rank_of, int N,
+                                                                  const float *__restrict__ rows,
+                                                                  float *__restrict__ rgb) {
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (long long)N * 3) return;
+  const int i = (int)(e / 3), k = (int)(e % 3);
+  rgb[e] = mask[i] ? rows[(size_t)rank_of[i] * 16 + k] : 0.0f;
+}
+
 // Split exchange: the 12 direction-independent columns (SUM all-reduce) and this view's g_rgb (all-gather).
 __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char *__restrict__ mask,
                                                             const int *__restrict__ rank_of, int N,
@@ -415,10 +428,10 @@ __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char 
     else if (k < 7) val = gr.grad_scale[3 * j + (k - 4)];
     else if (k < 11) val = gr.grad_quaternion[4 * j + (k - 7)];
     else if (k == 11) val = 1.0f;
-    else val = gr.grad_precompute_rgb[3 * j + (k - 12)];
+    else if (rgb) val = gr.grad_precompute_rgb[3 * j + (k - 12)];
   }
   if (k < 12) common[(size_t)i * 12 + k] = val;
-  else rgb[(size_t)i * 3 + (k - 12)] = val;
+  else if (rgb) rgb[(size_t)i * 3 + (k - 12)] = val;
 }
 
 // rgb_all: world blocks of `stride` floats; block r = [N,3] g_rgb of rank r followed by that rank's campos[3]
@@ -510,8 +523,11 @@ int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads
                                 float *rgb, void *stream) {
   GS_REQUIRE(c && grads, "null argument struct");
   GS_REQUIRE(c->have_forward && num_gaussians == c->N, "does not match the recorded forward");
-  GS_REQUIRE_DEV(common); GS_REQUIRE_DEV(rgb);
-  GS_REQUIRE_DEV(grads->grad_precompute_rgb);  // backward must have been asked for this intermediate
+  GS_REQUIRE_DEV(common);
+  if (rgb) {
+    GS_REQUIRE_DEV(rgb);
+    GS_REQUIRE_DEV(grads->grad_precompute_rgb);  // backward must have been asked for this intermediate
+  }
   const long long total = (long long)num_gaussians * 15;
   pack_split_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(
       c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, *grads, common, rgb);
@@ -608,6 +624,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   GS_REQUIRE(((uintptr_t)g->quaternion & 15) == 0, "quaternion must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   c->have_forward = false;
+  c->rows_ready = false;
   const int ntx = (W + 15) / 16, nty = (H + 15) / 16, num_tiles = ntx * nty;
   const float fx = cam->focal_x, fy = cam->focal_y;
   const float tan_fovx = (float)W / (2.0f * fx), tan_fovy = (float)H / (2.0f * fy);  // cuda/raster.cu:92-93
@@ -723,20 +740,15 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   return GSPLAT_OK;
 }
 
-int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam,
-                         const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
-                         void *stream) {
-  GS_REQUIRE(c && g && cam && out, "null argument struct");
+int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_color, float *rgb_global,
+                           void *stream) {
+  GS_REQUIRE(c != nullptr, "null context");
   GS_REQUIRE(c->have_forward, "no forward pass recorded in this context");
-  GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N && cam->width == c->width && cam->height == c->height,
-             "backward arguments do not match the recorded forward pass");
   GS_REQUIRE_DEV(grad_image);
-  GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
-  GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
-  if (l_max > 0) GS_REQUIRE_DEV(out->grad_sh);
-  GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
+  if (rgb_global) GS_REQUIRE_DEV(rgb_global);
   hipStream_t st = (hipStream_t)stream;
   const int M = c->M, W = c->width, H = c->height;
+  c->rows_ready = false;
   c->mark(5, false, st);
   GS_HIP(hipMemsetAsync(c->grad_rows.ptr, 0, (size_t)M * 64, st));
   c->mark(5, true, st);
@@ -746,6 +758,27 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st);
   if (rc) return rc;
   c->mark(6, true, st);
+  if (rgb_global) {
+    scatter_rgb_rows_kernel<<<gs::div_up((long long)c->N * 3, kBlock), kBlock, 0, st>>>(
+        c->mask.as<unsigned char>(), c->rank.as<int>(), c->N, c->grad_rows.as<float>(), rgb_global);
+    GS_LAUNCH_CHECK();
+  }
+  c->rows_ready = true;
+  return GSPLAT_OK;
+}
+
+int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
+                              const gsplat_gradients *out, void *stream) {
+  GS_REQUIRE(c && g && cam && out, "null argument struct");
+  GS_REQUIRE(c->have_forward && c->rows_ready, "gsplat_backward_render has not run for this forward pass");
+  GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N && cam->width == c->width && cam->height == c->height,
+             "backward arguments do not match the recorded forward pass");
+  GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
+  GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
+  if (l_max > 0) GS_REQUIRE_DEV(out->grad_sh);
+  GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = c->M, W = c->width, H = c->height;
   // cuda/trainer.cu:992-995
   const float fx = cam->focal_x, fy = cam->focal_y;
   const float fov_x = (float)(2.0 * atan((double)W / (2.0 * (double)fx)));
@@ -771,6 +804,21 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
   GS_LAUNCH_CHECK();
   c->mark(7, true, st);
   return GSPLAT_OK;
+}
+
+int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam,
+                         const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
+                         void *stream) {
+  GS_REQUIRE(c && g && cam && out, "null argument struct");
+  GS_REQUIRE(c->have_forward, "no forward pass recorded in this context");
+  GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N && cam->width == c->width && cam->height == c->height,
+             "backward arguments do not match the recorded forward pass");
+  GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
+  GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
+  if (l_max > 0) GS_REQUIRE_DEV(out->grad_sh);
+  int rc = gsplat_backward_render(c, grad_image, bg_color, nullptr, stream);
+  if (rc) return rc;
+  return gsplat_backward_gaussians(c, g, cam, l_max, out, stream);
 }
 
 int gsplat_context_set_timing(gsplat_context *c, int enabled) {

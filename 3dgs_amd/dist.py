@@ -96,6 +96,7 @@ class ViewShardedStep:
         self.fw = raster.factored_gradient_width(self.world)
         self.factored = torch.zeros(self.N + 1, self.fw, dtype=torch.float32, device=dev) if exchange == "factored" \
             else None
+        self._rgb_gather = None
         if exchange == "split":
             self.common = torch.zeros(self.N, 12, dtype=torch.float32, device=dev)
             self.rgb = torch.zeros(self.N + 1, 3, dtype=torch.float32, device=dev)          # row N: campos
@@ -113,12 +114,15 @@ class ViewShardedStep:
     def exchange_gradients(self, cam):
         """Scatter this rank's compacted gradients to global order, sum over ranks, leave the result in self.packed."""
         if self.exchange == "split":
-            self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, self.rgb)
-            self.rgb[self.N] = torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32,
-                                               device=self.rgb.device)
-            works = [dist.all_reduce(self.common, op=dist.ReduceOp.SUM, async_op=True),
-                     all_gather_blocks(self.rgb_all, self.rgb, async_op=True)]
-            for w in works:
+            gather = self._rgb_gather  # started by step() behind the per-gaussian backward, or None
+            self._rgb_gather = None
+            if gather is None:
+                self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, self.rgb)
+                self._set_campos(cam)
+                gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+            else:
+                self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, None)
+            for w in (dist.all_reduce(self.common, op=dist.ReduceOp.SUM, async_op=True), gather):
                 w.wait()
             self.raster.unpack_gradients_split(self.params["xyz"], self.common, self.rgb_all, 3 * (self.N + 1),
                                                self.l_max, self.N, self.world, self.packed)
@@ -136,9 +140,20 @@ class ViewShardedStep:
             all_reduce_gradients(self.packed)
         return self.packed
 
+    def _set_campos(self, cam):
+        self.rgb[self.N] = torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32,
+                                           device=self.rgb.device)
+
     def step(self, cam, grad_image):
         fwd = self.ctx.rasterize_image(self.params, cam, self.config, self.bg, self.l_max)
-        self.ctx.backward_pass(self.params, cam, grad_image, self.bg, self.l_max, self.grads)
+        if self.world > 1 and self.exchange == "split":
+            # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
+            self.ctx.backward_render(grad_image, self.bg, self.rgb)
+            self._set_campos(cam)
+            self._rgb_gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+            self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
+        else:
+            self.ctx.backward_pass(self.params, cam, grad_image, self.bg, self.l_max, self.grads)
         if self.world > 1:
             self.exchange_gradients(cam)
         return fwd

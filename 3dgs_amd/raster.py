@@ -160,6 +160,19 @@ class RasterContext:
                                              float(bg_color), int(l_max), ctypes.byref(gs), st))
         return grads
 
+    def backward_render(self, grad_image, bg_color, rgb_global=None):
+        """First half of backward_pass: compositing backward; optionally this view's g_rgb in global order [N,3]."""
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_backward_render(self._h, _ptr(grad_image), float(bg_color), _ptr(rgb_global), st))
+
+    def backward_gaussians(self, params, cam, l_max, grads):
+        """Second half of backward_pass: the per-gaussian operator chain."""
+        g, c = self._structs(params, cam, l_max)
+        gs = self._grad_struct(grads)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_backward_gaussians(self._h, ctypes.byref(g), ctypes.byref(c), int(l_max), ctypes.byref(gs), st))
+        return grads
+
     def pack_gradients_global(self, grads, l_max, num_gaussians, packed):
         gs = self._grad_struct(grads)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -301,6 +301,15 @@ int gsplat_backward_pass(gsplat_context *ctx, const gsplat_gaussians *gaussians,
                          const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
                          void *stream);
 
+/* The same backward in two calls, for hosts that overlap a gradient exchange with it (3dgs_amd/dist.py):
+ * gsplat_backward_render runs the compositing backward (render_image_backward) and, if rgb_global != NULL, leaves this
+ * view's dL/d(precomputed rgb) in GLOBAL gaussian order in rgb_global[N,3] (zero where culled) -- final at that point,
+ * so an all-gather of it can run while gsplat_backward_gaussians executes the per-gaussian operator chain. */
+int gsplat_backward_render(gsplat_context *ctx, const float *grad_image, float bg_color, float *rgb_global,
+                           void *stream);
+int gsplat_backward_gaussians(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
+                              int l_max, const gsplat_gradients *out, void *stream);
+
 /* Measurement hook: when enabled, every stage of the two fused passes is bracketed by HIP events on the
  * caller's stream.  Stage ids: 0 project+cull+scan, 1 preprocess+scan, 2 emit + tile sort + ranges + per-tile depth sort, 3 reserved,
  * 4 compositing forward, 5 gradient-row memset, 6 compositing backward, 7 per-gaussian backward.
@@ -333,7 +342,7 @@ int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, 
  * visible1] is SUM all-reduced, and every rank's g_rgb[N,3] (+ its camera position in row N) is all-gathered into
  * rgb_all = world blocks of rank_stride floats (block r = rank r's [N,3] g_rgb followed by campos[3]).  At 8 ranks
  * and SH degree 3 a rank moves 2*(7/8)*48 MB + 7*12 MB = 168 MB per step instead of 252 MB (one factored all-reduce)
- * or 420 MB (full rows). */
+ * or 420 MB (full rows).  rgb may be NULL when gsplat_backward_render already produced it. */
 int gsplat_pack_gradients_split(gsplat_context *ctx, const gsplat_gradients *grads, int num_gaussians, float *common,
                                 float *rgb, void *stream);
 int gsplat_unpack_gradients_split(const float *xyz, const float *common, const float *rgb_all, size_t rank_stride,

@@ -276,6 +276,38 @@ def test_factored_exchange_equals_full_rows(gpu, scene):
     assert torch.equal(out2, out), "split (all-reduce + all-gather) and factored (one all-reduce) must agree exactly"
 
 
+def test_split_backward_equals_backward_pass(gpu, scene):
+    """gsplat_backward_render + gsplat_backward_gaussians == gsplat_backward_pass, and the g_rgb it leaves in global
+    order is exactly the scatter of the per-gaussian kernel's grad_precompute_rgb (what the exchange overlaps)."""
+    torch = gpu
+    raster = pkg("raster")
+    N, W, H, L, _ = scene.WORKLOADS["small"]
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::4, 2] *= -1
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp, dc = raster.device_params(params), raster.device_camera(scene.make_camera(W, H, 2))
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    M = fwd["num_culled"]
+    g1 = ctx.alloc_gradients(M, L, intermediates=True)
+    ctx.backward_pass(dp, dc, gi, c["bg"], L, g1)
+    g2 = ctx.alloc_gradients(M, L, intermediates=True)
+    rgb_global = torch.full((N + 1, 3), float("nan"), device="cuda")
+    with pytest.raises(pkg("_lib").GsplatError):  # the second half before the first
+        ctx.rasterize_image(dp, dc, c, c["bg"], L)
+        ctx.backward_gaussians(dp, dc, L, g2)
+    ctx.backward_render(gi, c["bg"], rgb_global)
+    ctx.backward_gaussians(dp, dc, L, g2)
+    torch.cuda.synchronize()
+    for k in g1:
+        assert_grad_close(_np(g2[k]), _np(g1[k]), "split " + k, rel=1e-5)
+    want = torch.zeros(N, 3, device="cuda")
+    want[fwd["compact_to_global"].long()] = g2["precompute_rgb"]
+    assert torch.equal(rgb_global[:N], want)
+    assert torch.isnan(rgb_global[N]).all()  # row N (camera position) is the caller's
+
+
 def test_config2_forward_only(gpu, scene, orc):
     """BASELINE configs[1]: synthetic 100k gaussians, 800x800, SH degree 0, forward render only."""
     raster = pkg("raster")
