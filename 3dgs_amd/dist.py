@@ -145,11 +145,13 @@ class ViewShardedStep:
                                            device=self.rgb.device)
 
     def step(self, cam, grad_image):
+        overlap = self.world > 1 and self.exchange == "split"
+        if overlap:
+            self._set_campos(cam)  # a small host-to-device copy: issue it before the GPU has work queued
         fwd = self.ctx.rasterize_image(self.params, cam, self.config, self.bg, self.l_max)
-        if self.world > 1 and self.exchange == "split":
+        if overlap:
             # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
             self.ctx.backward_render(grad_image, self.bg, self.rgb)
-            self._set_campos(cam)
             self._rgb_gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
             self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
         else:
