@@ -110,6 +110,9 @@ SIGNATURES = {
     "gsplat_compute_morton_codes": (_I, [_I, _P, _F, _F, _F, _F, _F, _F, _P, _P]),
     "gsplat_clone_gaussians": (_I, [_I, _I] + [_P] * 14 + [_P]),
     "gsplat_split_gaussians": (_I, [_I, _F, _I] + [_P] * 14 + [ctypes.c_ulonglong, _P]),
+    "gsplat_density_masks": (_I, [_I, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "gsplat_expand_sh": (_I, [_I, _I, _P, _P, _P]),
+    "gsplat_gather_rows": (_I, [_I, _I, _P, _P, _P, _P]),
     "gsplat_compact_masked_array": (_I, [_P, _P, _I, _I, _P, ctypes.POINTER(_I), _P]),
     "gsplat_scatter_masked_array": (_I, [_P, _P, _I, _I, _P, _P]),
     "gsplat_context_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),

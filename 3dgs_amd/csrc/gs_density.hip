@@ -1,7 +1,8 @@
 // gs_density.hip -- operators of the "next" row f4 that the reference declares in its public headers and tests:
 // clone_gaussians / split_gaussians (include/gsplat_cuda/adaptive_density.cuh, cuda/adaptive_density.cu:12-206) and
-// compute_morton_codes (include/gsplat_cuda/cuda_forward.cuh:174-188, cuda/culling.cu:14-63, 345-359).  The policy
-// that decides WHAT to clone, split or prune (TrainerImpl::adaptive_density_step) is host control flow and not here.
+// compute_morton_codes (include/gsplat_cuda/cuda_forward.cuh:174-188, cuda/culling.cu:14-63, 345-359), plus the
+// data-parallel pieces of the policy that drives them (the masks of TrainerImpl::adaptive_density_step, add_sh_band's
+// re-layout, sort_gaussians' gather); the schedule itself lives in 3dgs_amd/trainer.py.
 //
 // split_gaussians draws its two new centres from N(xyz, R diag(exp(scale))^2 R^T).  The reference seeds cuRAND from
 // time(NULL) per call, so its positions are not reproducible; here the normals come from a counter-based generator
@@ -117,6 +118,64 @@ __global__ __launch_bounds__(kBlock) void split_kernel(int N, float scale_factor
   }
 }
 
+// ---- policy half of adaptive density control (TrainerImpl::adaptive_density_step, cuda/trainer.cu:416-575):
+// one pass computes the average screen-space gradient, the largest extent, and the prune / clone / split / keep
+// masks of every gaussian (the reference runs six thrust transforms and three counts).
+__global__ __launch_bounds__(kBlock) void density_masks_kernel(int N, const float *__restrict__ opacity,
+                                                               const float *__restrict__ scale,
+                                                               const float *__restrict__ uv_grad_accum,
+                                                               const int *__restrict__ grad_accum_dur,
+                                                               float op_threshold, float max_scale,
+                                                               float grad_threshold, float clone_scale_threshold,
+                                                               unsigned char *__restrict__ prune,
+                                                               unsigned char *__restrict__ clone,
+                                                               unsigned char *__restrict__ split,
+                                                               unsigned char *__restrict__ keep,
+                                                               int *__restrict__ counts) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  bool p = false, c = false, s = false;
+  if (i < N) {
+    const int dur = grad_accum_dur[i];
+    const float avg = dur == 0 ? 0.0f : uv_grad_accum[i] / (float)dur;               // ComputeAvgGrad
+    const float max_s = fmaxf(expf(scale[3 * (size_t)i]), fmaxf(expf(scale[3 * (size_t)i + 1]),
+                                                                 expf(scale[3 * (size_t)i + 2])));  // ComputeScaleMax
+    // IdentifyPrune (cuda/trainer.cu:438-468): low opacity always goes; an oversized gaussian survives only if it is
+    // about to be split or cloned (the 1.6 is the reference's literal, not config.split_scale_factor)
+    if (opacity[i] < op_threshold) p = true;
+    else if (avg > grad_threshold && (max_s / 1.6f) <= max_scale) p = false;
+    else p = max_s > max_scale;
+    c = !p && avg > grad_threshold && max_s <= clone_scale_threshold;                 // IdentifyClone
+    s = !p && avg > grad_threshold && max_s > clone_scale_threshold;                  // IdentifySplit
+    prune[i] = p; clone[i] = c; split[i] = s;
+    keep[i] = !(p || s);                                                              // CombineMasks
+  }
+  const unsigned long long bp = __ballot(p), bc = __ballot(c), bs = __ballot(s);
+  if ((threadIdx.x & 63) == 0) {
+    if (bp) atomicAdd(&counts[0], __popcll(bp));
+    if (bc) atomicAdd(&counts[1], __popcll(bc));
+    if (bs) atomicAdd(&counts[2], __popcll(bs));
+  }
+}
+
+// add_sh_band (cuda/trainer.cu:363-413): coefficient k of gaussian g moves from g*old+k to g*new+k, new ones are 0
+__global__ __launch_bounds__(kBlock) void expand_sh_kernel(long long total_new, int old_w, int new_w,
+                                                           const float *__restrict__ in, float *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= total_new) return;
+  const long long g = e / new_w;
+  const int k = (int)(e - g * new_w);
+  out[e] = k < old_w ? in[g * old_w + k] : 0.0f;
+}
+
+// sort_gaussians' gather (cuda/trainer.cu:793-851): out row i = in row order[i]
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(long long total, int stride, const int *__restrict__ order,
+                                                             const float *__restrict__ in, float *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= total) return;
+  const long long r = e / stride;
+  out[e] = in[(long long)order[r] * stride + (e - r * stride)];
+}
+
 int check_attr(int N, int num_sh_coef, const unsigned char *mask, const int *write_ids, const Attr &in,
                const AttrOut &out, const char *fn) {
   if (N < 0 || num_sh_coef < 0) { gs::set_error("%s: invalid argument: negative size", fn); return GSPLAT_ERR_INVALID_ARG; }
@@ -172,6 +231,49 @@ int gsplat_split_gaussians(int N, float scale_factor, int num_sh_coef, const uns
   GS_REQUIRE(scale_factor > 0.0f, "scale_factor must be positive");
   split_kernel<<<gs::div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(N, scale_factor, num_sh_coef, mask, write_ids,
                                                                         in, out, seed);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_density_masks(int N, const float *opacity, const float *scale, const float *uv_grad_accum,
+                         const int *grad_accum_dur, float op_threshold, float max_scale, float uv_grad_threshold,
+                         float clone_scale_threshold, unsigned char *prune_mask, unsigned char *clone_mask,
+                         unsigned char *split_mask, unsigned char *keep_mask, int *counts, void *stream) {
+  GS_REQUIRE(N >= 0, "negative size");
+  GS_REQUIRE_DEV(counts);
+  hipStream_t st = (hipStream_t)stream;
+  GS_HIP(hipMemsetAsync(counts, 0, 3 * sizeof(int), st));
+  if (N == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(opacity); GS_REQUIRE_DEV(scale); GS_REQUIRE_DEV(uv_grad_accum); GS_REQUIRE_DEV(grad_accum_dur);
+  GS_REQUIRE_DEV(prune_mask); GS_REQUIRE_DEV(clone_mask); GS_REQUIRE_DEV(split_mask); GS_REQUIRE_DEV(keep_mask);
+  density_masks_kernel<<<gs::div_up(N, kBlock), kBlock, 0, st>>>(N, opacity, scale, uv_grad_accum, grad_accum_dur,
+                                                               op_threshold, max_scale, uv_grad_threshold,
+                                                               clone_scale_threshold, prune_mask, clone_mask, split_mask,
+                                                               keep_mask, counts);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_expand_sh(int N, int l_max_old, const float *sh_in, float *sh_out, void *stream) {
+  GS_REQUIRE(N >= 0 && l_max_old >= 0 && l_max_old <= 2, "expand_sh grows SH degree 0..2 by one band");
+  if (N == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(sh_out);
+  const int old_w = ((l_max_old + 1) * (l_max_old + 1) - 1) * 3, new_w = ((l_max_old + 2) * (l_max_old + 2) - 1) * 3;
+  if (old_w > 0) GS_REQUIRE_DEV(sh_in);
+  GS_REQUIRE(sh_in != sh_out, "expand_sh is not in place");
+  const long long total = (long long)N * new_w;
+  expand_sh_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(total, old_w, new_w, sh_in, sh_out);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_gather_rows(int N, int stride, const int *order, const float *in, float *out, void *stream) {
+  GS_REQUIRE(N >= 0 && stride >= 0, "negative size");
+  if (N == 0 || stride == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(order); GS_REQUIRE_DEV(in); GS_REQUIRE_DEV(out);
+  GS_REQUIRE(in != out, "gather_rows is not in place");
+  const long long total = (long long)N * stride;
+  gather_rows_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(total, stride, order, in, out);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

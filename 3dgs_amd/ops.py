@@ -185,6 +185,39 @@ def split_gaussians(N, scale_factor, num_sh_coef, mask, write_ids, src, dst, see
                                              int(seed), _stream()))
 
 
+def density_masks(opacity, scale, uv_grad_accum, grad_accum_dur, op_threshold, max_scale, uv_grad_threshold,
+                  clone_scale_threshold):
+    """Masks of TrainerImpl::adaptive_density_step (cuda/trainer.cu:416-575).
+    Returns (prune, clone, split, keep) uint8 tensors and the (pruned, cloned, split) counts."""
+    import torch
+    N = int(opacity.shape[0])
+    m = [torch.empty(N, dtype=torch.uint8, device=opacity.device) for _ in range(4)]
+    counts = torch.zeros(3, dtype=torch.int32, device=opacity.device)
+    check(_lib.load().gsplat_density_masks(N, _p(opacity), _p(scale), _p(uv_grad_accum), _p(grad_accum_dur),
+                                           op_threshold, max_scale, uv_grad_threshold, clone_scale_threshold,
+                                           _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]), _p(counts), _stream()))
+    return m[0], m[1], m[2], m[3], [int(c) for c in counts.tolist()]
+
+
+def expand_sh(sh, l_max_old):
+    """add_sh_band's re-layout: [N,(l+1)^2-1,3] -> [N,(l+2)^2-1,3] with the new band zero."""
+    import torch
+    N = int(sh.shape[0])
+    out = torch.empty(N, (l_max_old + 2) ** 2 - 1, 3, dtype=torch.float32, device=sh.device)
+    check(_lib.load().gsplat_expand_sh(N, l_max_old, _p(sh) if l_max_old > 0 else None, _p(out), _stream()))
+    return out
+
+
+def gather_rows(src, order):
+    """out[i] = src[order[i]] along dim 0 (order: int32 device tensor)."""
+    import torch
+    out = torch.empty_like(src)
+    N = int(src.shape[0])
+    stride = src.numel() // N if N else 0
+    check(_lib.load().gsplat_gather_rows(N, stride, _p(order), _p(src), _p(out), _stream()))
+    return out
+
+
 def compact_masked_array(stride, d_source, d_mask, num_culled=None):
     """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride]."""
     N = int(d_mask.numel())

@@ -58,6 +58,7 @@ class RasterContext:
         check(self._lib.gsplat_context_create(ctypes.byref(h), int(max_gaussians), int(max_width), int(max_height)))
         self._h = h
         self._last = None
+        self.max_gaussians, self.max_width, self.max_height = int(max_gaussians), int(max_width), int(max_height)
 
     def close(self):
         if self._h:

@@ -1,0 +1,254 @@
+"""Host-side mirror of the reference's training loop (TrainerImpl, cuda/trainer.cu) -- SURVEY.md section 8f, row f4.
+
+Only the SCHEDULE lives here (what runs at which iteration, config thresholds); every data-parallel step is a HIP
+kernel behind the C ABI: rasterize / loss / backward / masked Adam (rows a-f2) and, for the density policy, the masks,
+clone / split, compaction, SH band re-layout, Morton codes and the row gather of gs_density.hip.  torch is used for
+device memory and for the key sort of the Morton re-order.  There is no CPU fallback.
+
+Parity note: the reference's density control is not reproducible (cuRAND seeded from time(NULL), std::random_device for
+the view order), so this loop is judged statistically (PSNR, gaussian counts), not bit for bit; with a fixed seed it is
+itself deterministic.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops, raster
+from .optimizer import AdamOptimizer, DEFAULT_LR
+
+GROUPS = ("xyz", "rgb", "sh", "opacity", "scale", "quaternion")
+
+# config/base.yaml of the reference: the keys the loop reads
+DEFAULT_CONFIG = dict(
+    DEFAULT_LR, near_thresh=0.3, mh_dist=3.0, cull_mask_padding=100, ssim_frac=0.2, use_background=True,
+    use_background_end=2000, reset_opacity_interval=3000, reset_opacity_value=0.05, reset_opacity_start=1050,
+    reset_opacity_end=5000, max_sh_band=3, add_sh_band_interval=1000, use_split=True, use_clone=True, use_delete=True,
+    adaptive_control_start=500, adaptive_control_end=5000, adaptive_control_interval=100, max_gaussians=4250000,
+    delete_opacity_threshold=0.02, uv_grad_threshold=0.0002, split_scale_factor=1.6)
+
+
+def _logit(p):
+    return math.log(p) - math.log(1.0 - p)
+
+
+class Trainer:
+    """params: dict of device tensors (xyz rgb opacity scale quaternion, optionally sh) as gsplat_initialize_gaussians
+    returns them; views: list of (camera dict for raster.device_camera, ground-truth image tensor [H,W,3] on device)."""
+
+    def __init__(self, params, views, config=None, scene_extent=1.0, seed=0):
+        self.cfg = dict(DEFAULT_CONFIG, **(config or {}))
+        self.views = views
+        self.scene_extent = float(scene_extent)
+        self.seed = int(seed)
+        self.rng = np.random.default_rng(seed)
+        self.iter = 0
+        self.l_max = 0 if params.get("sh") is None or params["sh"].numel() == 0 else \
+            int(round(math.sqrt(params["sh"].shape[1] + 1))) - 1
+        self.params = {k: params[k].contiguous() for k in ("xyz", "rgb", "opacity", "scale", "quaternion")}
+        n = self.num_gaussians
+        self.params["sh"] = params["sh"].contiguous() if self.l_max > 0 else \
+            torch.zeros(n, 0, 3, dtype=torch.float32, device=self.params["xyz"].device)
+        W = max(int(c["width"]) for c, _ in views)
+        H = max(int(c["height"]) for c, _ in views)
+        self.ctx = raster.RasterContext(max(n, 1), W, H)
+        self.ctx_capacity = n
+        self._new_optimizer(None)
+        self.history = []
+
+    # ------------------------------------------------------------------ state
+    @property
+    def num_gaussians(self):
+        return int(self.params["xyz"].shape[0])
+
+    def _new_optimizer(self, moments):
+        """Fresh AdamOptimizer over the current parameter tensors; `moments` = (exp_avg, exp_avg_sq) dicts to adopt."""
+        p = dict(self.params)
+        if self.l_max == 0:
+            p.pop("sh")
+        self.opt = AdamOptimizer(p, self.l_max, lr_config=self.cfg, scene_extent=self.scene_extent)
+        if moments is not None:
+            for g in self.opt.names:
+                self.opt.exp_avg[g], self.opt.exp_avg_sq[g] = moments[0][g], moments[1][g]
+
+    def _context_for(self, n):
+        if n > self.ctx_capacity:  # the workspace is sized for a gaussian count: grow it geometrically
+            self.ctx_capacity = int(n * 1.5) + 1
+            W, H = self.ctx.max_width, self.ctx.max_height
+            self.ctx = raster.RasterContext(self.ctx_capacity, W, H)
+        return self.ctx
+
+    # ------------------------------------------------------------------ one iteration (cuda/trainer.cu:1338-1362)
+    def train_step(self, cam, gt_image):
+        c = self.cfg
+        it = self.iter
+        bg = (it % 255) / 255.0 if (c["use_background"] and it < c["use_background_end"]) else 0.0
+        if it % c["add_sh_band_interval"] == 0 and it >= c["add_sh_band_interval"]:
+            self.add_sh_band()
+        ctx = self._context_for(self.num_gaussians)
+        p = dict(self.params)
+        H, W = int(cam["height"]), int(cam["width"])
+        try:
+            fwd = ctx.rasterize_image(p, cam, c, bg, self.l_max)
+        except Exception as e:  # no gaussian in view: the reference warns and skips the iteration
+            if getattr(e, "code", None) != -5:
+                raise
+            self.iter += 1
+            return None
+        grad_image = torch.empty(H, W, 3, dtype=torch.float32, device=gt_image.device)
+        loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image)
+        grads = ctx.alloc_gradients(fwd["num_culled"], self.l_max, intermediates=True)
+        ctx.backward_pass(p, cam, grad_image, bg, self.l_max, grads)
+        self.opt.step(it, fwd, grads)
+        self.iter += 1
+        return loss
+
+    def maintenance(self):
+        """Density control and opacity reset at the reference's cadence (cuda/trainer.cu:1394-1406); call after
+        train_step.  Uses the iteration index the step just ran with."""
+        c, it = self.cfg, self.iter - 1
+        if it > c["adaptive_control_start"] and it % c["adaptive_control_interval"] == 0 and it < c["adaptive_control_end"]:
+            self.adaptive_density_step()
+            self.sort_gaussians()
+            self.reset_grad_accum()
+        if it > c["reset_opacity_start"] and it % c["reset_opacity_interval"] == 0 and it < c["reset_opacity_end"]:
+            self.reset_opacity()
+            self.reset_grad_accum()
+
+    def train(self, num_iters, log_every=0):
+        for _ in range(num_iters):
+            # the reference walks the first two images in order and then draws uniformly (cuda/trainer.cu:1438-1444)
+            v = self.iter if self.iter < 2 else int(self.rng.integers(0, len(self.views)))
+            cam, gt = self.views[v % len(self.views)]
+            loss = self.train_step(cam, gt)
+            self.maintenance()
+            if loss is not None:
+                self.history.append((self.iter, loss, self.num_gaussians))
+            if log_every and self.iter % log_every == 0:
+                print(f"iter {self.iter}: loss {loss} gaussians {self.num_gaussians}")
+        return self.history
+
+    def evaluate(self, views=None):
+        """Mean PSNR over the views at background 0 (TrainerImpl::evaluate, cuda/trainer.cu:263-360)."""
+        total, views = 0.0, (views or self.views)
+        ctx = self._context_for(self.num_gaussians)
+        for cam, gt in views:
+            fwd = ctx.rasterize_image(dict(self.params), cam, self.cfg, 0.0, self.l_max)
+            total += ops.compute_psnr(fwd["image"], gt, int(cam["height"]), int(cam["width"]))
+        return total / len(views)
+
+    # ------------------------------------------------------------------ policy steps
+    def reset_grad_accum(self):  # cuda/trainer.cu:233-236
+        self.opt.uv_grad_accum.zero_()
+        self.opt.grad_accum_dur.zero_()
+
+    def reset_opacity(self):  # cuda/trainer.cu:238-245
+        self.params["opacity"].fill_(_logit(float(self.cfg["reset_opacity_value"])))
+        self.opt.exp_avg["opacity"].zero_()
+        self.opt.exp_avg_sq["opacity"].zero_()
+
+    def add_sh_band(self):  # cuda/trainer.cu:377-413
+        if self.l_max >= self.cfg["max_sh_band"]:
+            return
+        old = self.l_max
+        m = ({g: self.opt.exp_avg[g] for g in self.opt.names}, {g: self.opt.exp_avg_sq[g] for g in self.opt.names})
+        acc = (self.opt.uv_grad_accum, self.opt.grad_accum_dur)
+        self.params["sh"] = ops.expand_sh(self.params["sh"], old)
+        if old == 0:
+            m[0]["sh"], m[1]["sh"] = torch.zeros_like(self.params["sh"]), torch.zeros_like(self.params["sh"])
+        else:
+            m[0]["sh"], m[1]["sh"] = ops.expand_sh(m[0]["sh"], old), ops.expand_sh(m[1]["sh"], old)
+        self.l_max = old + 1
+        self._new_optimizer(m)
+        self.opt.uv_grad_accum, self.opt.grad_accum_dur = acc
+
+    def adaptive_density_step(self):  # cuda/trainer.cu:518-779
+        c, n = self.cfg, self.num_gaussians
+        max_scale = self.scene_extent * 0.1
+        clone_thresh = self.scene_extent * 0.01
+        prune, clone, split, keep, (n_prune, n_clone, n_split) = ops.density_masks(
+            self.params["opacity"], self.params["scale"], self.opt.uv_grad_accum, self.opt.grad_accum_dur,
+            _logit(float(c["delete_opacity_threshold"])), max_scale, float(c["uv_grad_threshold"]), clone_thresh)
+        if not c["use_delete"]:
+            n_prune = 0
+            keep = (1 - split).to(torch.uint8)
+        if not c["use_clone"]:
+            n_clone, clone = 0, torch.zeros_like(clone)
+        if not c["use_split"]:
+            n_split, split = 0, torch.zeros_like(split)
+            keep = (1 - prune).to(torch.uint8) if c["use_delete"] else torch.ones_like(keep)
+        n_add = n_clone + 2 * n_split
+        new_n = n - n_prune - n_split + n_add
+        if new_n > c["max_gaussians"] or (n_add == 0 and n_prune == 0):
+            return dict(pruned=0, cloned=0, split=0, skipped=new_n > c["max_gaussians"])
+        nsh = (self.l_max + 1) ** 2 - 1 if self.l_max > 0 else 0
+        dev = self.params["xyz"].device
+        src = dict(self.params)
+        src["sh"] = self.params["sh"].reshape(n, -1)
+
+        def fresh(rows):
+            return dict(xyz=torch.empty(rows, 3, device=dev), rgb=torch.empty(rows, 3, device=dev),
+                        opacity=torch.empty(rows, device=dev), scale=torch.empty(rows, 3, device=dev),
+                        quaternion=torch.empty(rows, 4, device=dev), sh=torch.empty(rows, nsh * 3, device=dev))
+
+        def write_ids(mask):
+            m = mask.to(torch.int32)
+            return (torch.cumsum(m, 0, dtype=torch.int32) - m).contiguous()
+
+        clones, splits = fresh(n_clone), fresh(2 * n_split)
+        if n_clone:
+            ops.clone_gaussians(n, nsh, clone, write_ids(clone), src, clones)
+        if n_split:
+            ops.split_gaussians(n, float(c["split_scale_factor"]), nsh, split, write_ids(split), src, splits,
+                                seed=self.seed * 1000003 + self.iter)
+        keep_n = n - n_prune - n_split
+
+        def rebuild(t, stride, new_rows):
+            if stride == 0:  # no SH coefficients yet
+                return torch.empty(new_n, 0, device=dev)
+            kept = ops.compact_masked_array(stride, t.reshape(-1), keep, keep_n)
+            parts = [kept.reshape(keep_n, stride)] + [r.reshape(-1, stride) for r in new_rows]
+            return torch.cat(parts, 0)
+
+        shape = dict(xyz=3, rgb=3, opacity=1, scale=3, quaternion=4, sh=nsh * 3)
+        new_params, m, v = {}, {}, {}
+        for g in GROUPS:
+            s = shape[g]
+            new_params[g] = rebuild(self.params[g], s, [clones[g], splits[g]])
+            if g in self.opt.names:  # kept rows keep their moments, new rows start at zero (cuda/trainer.cu:703-742)
+                z = [torch.zeros(n_clone, s, device=dev), torch.zeros(2 * n_split, s, device=dev)]
+                m[g] = rebuild(self.opt.exp_avg[g], s, z)
+                v[g] = rebuild(self.opt.exp_avg_sq[g], s, z)
+        self.params = dict(xyz=new_params["xyz"], rgb=new_params["rgb"], opacity=new_params["opacity"].reshape(-1),
+                           scale=new_params["scale"], quaternion=new_params["quaternion"],
+                           sh=new_params["sh"].reshape(new_n, nsh, 3))
+        for g in m:
+            tgt = self.params[g].shape
+            m[g], v[g] = m[g].reshape(tgt).contiguous(), v[g].reshape(tgt).contiguous()
+        self._new_optimizer((m, v))
+        return dict(pruned=n_prune, cloned=n_clone, split=n_split, skipped=False)
+
+    def sort_gaussians(self):  # cuda/trainer.cu:853-922: Morton order of the positions
+        n = self.num_gaussians
+        if n == 0:
+            return
+        xyz = self.params["xyz"]
+        lo, hi = xyz.min(0).values.tolist(), xyz.max(0).values.tolist()
+        codes = torch.empty(n, dtype=torch.int64, device=xyz.device)
+        ops.compute_morton_codes(n, xyz, hi[0], hi[1], hi[2], lo[0], lo[1], lo[2], codes)
+        order = torch.sort(codes, stable=True).indices.to(torch.int32).contiguous()  # codes use 63 bits: int64 order is unsigned order
+        for g in GROUPS:
+            if self.params[g].numel():
+                self.params[g] = ops.gather_rows(self.params[g], order)
+        m = ({g: ops.gather_rows(self.opt.exp_avg[g], order) for g in self.opt.names},
+             {g: ops.gather_rows(self.opt.exp_avg_sq[g], order) for g in self.opt.names})
+        acc = (self.opt.uv_grad_accum, self.opt.grad_accum_dur)
+        self._new_optimizer(m)
+        self.opt.uv_grad_accum = ops.gather_rows(acc[0], order)
+        self.opt.grad_accum_dur = ops.gather_rows(acc[1].view(torch.float32), order).view(torch.int32)
+
+    def save_to_ply(self, path):
+        from . import dataset
+        p = {k: v.detach().cpu().numpy() for k, v in self.params.items()}
+        dataset.save_ply(path, p["xyz"], p["rgb"], p["opacity"], p["scale"], p["quaternion"],
+                         p["sh"].reshape(len(p["xyz"]), -1) if self.l_max > 0 else None)

@@ -219,6 +219,22 @@ int gsplat_split_gaussians(int N, float scale_factor, int num_sh_coef, const uns
                            const float *quat_in, const float *sh_in, float *xyz_out, float *rgb_out, float *op_out,
                            float *scale_out, float *quat_out, float *sh_out, unsigned long long seed, void *stream);
 
+/* The data-parallel half of TrainerImpl::adaptive_density_step (cuda/trainer.cu:416-575): per gaussian the average
+ * screen-space gradient uv_grad_accum / grad_accum_dur, the largest extent max(exp(scale)), and the reference's
+ * IdentifyPrune / IdentifyClone / IdentifySplit / CombineMasks decisions.  counts[3] (device) receives the number of
+ * pruned, cloned and split gaussians.  Masks are one byte per gaussian. */
+int gsplat_density_masks(int N, const float *opacity, const float *scale, const float *uv_grad_accum,
+                         const int *grad_accum_dur, float op_threshold, float max_scale, float uv_grad_threshold,
+                         float clone_scale_threshold, unsigned char *prune_mask, unsigned char *clone_mask,
+                         unsigned char *split_mask, unsigned char *keep_mask, int *counts, void *stream);
+
+/* add_sh_band's re-layout (cuda/trainer.cu:363-413): sh_in [N,(l+1)^2-1,3] -> sh_out [N,(l+2)^2-1,3], new
+ * coefficients zero.  l_max_old == 0 just zero-fills the first band. */
+int gsplat_expand_sh(int N, int l_max_old, const float *sh_in, float *sh_out, void *stream);
+
+/* sort_gaussians' gather (cuda/trainer.cu:793-851): out[i, :] = in[order[i], :] for rows of `stride` floats. */
+int gsplat_gather_rows(int N, int stride, const int *order, const float *in, float *out, void *stream);
+
 /* ------------------------------------------------------------- compaction templates --- */
 
 /* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]
