@@ -334,6 +334,11 @@ size_t binning_temp_bytes(size_t N, size_t S, int num_tiles) {
                                                   S ? S : 1, 0, tile_bits(num_tiles), (hipStream_t)0);
   (void)rocprim::exclusive_scan(nullptr, c, (int *)nullptr, (int *)nullptr, 0, N + 1, rocprim::plus<int>(),
                                 (hipStream_t)0);
+  size_t d = 0;  // the dense-scene depth pre-sort (see emit_sort_ranges)
+  (void)rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, d, (unsigned long long *)nullptr,
+                                                  (unsigned long long *)nullptr, (unsigned int *)nullptr,
+                                                  (unsigned int *)nullptr, S ? S : 1, 32, 64, (hipStream_t)0);
+  b = b > d ? b : d;
   return (b > c ? b : c) + 256;
 }
 
@@ -341,6 +346,24 @@ size_t binning_temp_bytes(size_t N, size_t S, int num_tiles) {
 int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_bytes, hipStream_t st) {
   GS_HIP(rocprim::exclusive_scan(temp, temp_bytes, counts, offsets, 0, (size_t)N + 1, rocprim::plus<int>(), st));
   return GSPLAT_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void low_words_kernel(const unsigned long long *__restrict__ in, int S,
+                                                           int *__restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < S) out[i] = (int)(unsigned int)(in[i] & 0xFFFFFFFFull);
+}
+
+// Average list length per tile above which the depth order is established by a global stable sort on the depth bits
+// BEFORE the tile sort (4 more radix passes over all instances) instead of per tile afterwards.  The per-tile network
+// is cheaper for short lists (54 us vs 4 x 39 us on the benchmark scene, ~430 per tile) but grows like n log^2 n and
+// leaves the register kernel above 1024 entries; dense real scenes (thousands per tile) take the global route.
+static long long dense_tile_threshold() {
+  static const long long v = [] {
+    const char *e = getenv("GSPLAT_DENSE_TILE_AVG");
+    return e ? atoll(e) : 768ll;
+  }();
+  return v;
 }
 
 // The emit step on its own: the fused forward launches it with the buffers' capacity BEFORE it waits for the
@@ -370,6 +393,19 @@ int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, i
     const int rc = launch_tile_emit(uv, xyz_c, radius, ntx, nty, N, mask, rank, offsets, hitmask, (long long)S, tkeys_a,
                                     pay_a, st);
     if (rc) return rc;
+  }
+  if ((long long)S > dense_tile_threshold() * (long long)num_tiles) {
+    // dense: stable sort by depth bits first (emission order is id order, so equal depths stay id-ordered), then the
+    // stable tile sort below leaves every tile's list in (depth, id) order and no per-tile pass is needed
+    GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, pay_a, pay_b, tkeys_a, tkeys_b, S, 32, 64, st));
+    GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, tkeys_b, tkeys_a, pay_b, pay_a, S, 0,
+                                                     tile_bits(num_tiles), st));
+    tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_a, (int)S, num_tiles, ranges,
+                                                                        reinterpret_cast<int *>(tkeys_b));
+    GS_LAUNCH_CHECK();
+    low_words_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(pay_a, (int)S, sorted_out);
+    GS_LAUNCH_CHECK();
+    return GSPLAT_OK;
   }
   GS_HIP(rocprim::radix_sort_pairs<OnesweepAlways>(temp, temp_bytes, tkeys_a, tkeys_b, pay_a, pay_b, S, 0,
                                                    tile_bits(num_tiles), st));

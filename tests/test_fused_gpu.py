@@ -214,9 +214,9 @@ def test_pack_gradients_global_layout(gpu, scene):
     assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3)
 
 
-def test_long_tile_lists(gpu, scene, orc):
-    """Tiles with more than 2048 list entries take the global-memory branch of the per-tile depth sort; lists and
-    image must still match the oracle exactly / within tolerance."""
+def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
+    """More than 768 list entries per tile on average: the depth order comes from a global stable pre-sort instead
+    of the per-tile kernels; lists and image must still match the oracle exactly / within tolerance."""
     raster = pkg("raster")
     N, W, H, L = 40000, 64, 48, 0
     params = scene.make_gaussians(N, W, H, L)
@@ -227,6 +227,32 @@ def test_long_tile_lists(gpu, scene, orc):
     fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
     assert np.diff(ref["ranges"]).max() > 2048
+    _check_forward(fwd, ref)
+
+
+def test_few_long_tile_lists_in_a_sparse_scene(gpu, scene, orc):
+    """Low average list length (per-tile sort kernels) but two hot spots: one tile list above 2048 entries (in-place
+    global-memory network) and one between 1025 and 2048 (LDS workgroup network); the rest sorts in registers."""
+    raster = pkg("raster")
+    N, W, H, L = 9500, 256, 144, 0
+    params = scene.make_gaussians(N, W, H, L)
+    params["opacity"][:] = -4.0
+    cam = scene.make_camera(W, H)
+    rng = np.random.default_rng(4)
+    for lo, hi, (cu, cv) in ((5000, 8000, (40.0, 40.0)), (8000, 9500, (200.0, 100.0))):
+        k = hi - lo
+        z = rng.uniform(3.0, 9.0, k)
+        u, v = cu + rng.uniform(-2, 2, k), cv + rng.uniform(-2, 2, k)
+        params["xyz"][lo:hi, 0] = (u - W / 2) * z / cam["fx"]
+        params["xyz"][lo:hi, 1] = (v - H / 2) * z / cam["fy"]
+        params["xyz"][lo:hi, 2] = z
+        params["scale"][lo:hi] = np.log(0.004)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
+    lens = np.diff(ref["ranges"])
+    assert lens.max() > 2048 and ((lens > 1024) & (lens <= 2048)).any() and lens.mean() < 768
     _check_forward(fwd, ref)
 
 
