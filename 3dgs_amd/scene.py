@@ -112,4 +112,7 @@ WORKLOADS = {
     "small": (5000, 256, 144, 3, True),
     "config2": (100_000, 800, 800, 0, False),
     "config3": (1_000_000, 1920, 1080, 3, True),
+    # not a BASELINE config: 4x the density of config3 (~1700 list entries per tile), exercises the dense-scene
+    # binning route and the long-list behaviour of the compositing kernels
+    "dense4m": (4_000_000, 1920, 1080, 3, True),
 }
