@@ -317,6 +317,21 @@ __global__ __launch_bounds__(kBlock) void tile_depth_sort_kernel(unsigned long l
   }
 }
 
+// per-tile depth order: one wave per tile in registers; the few lists above kWaveSortMax entries are listed in
+// `long_tiles` (long_tiles[0] must be 0 on entry) and finished by workgroups of the second kernel
+static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, int num_tiles, size_t S, int *long_tiles,
+                               int *sorted_out, hipStream_t st) {
+  const int max_long = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)kWaveSortMax);  // cannot be more
+  tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
+  GS_LAUNCH_CHECK();
+  if (max_long > 0) {
+    tile_depth_sort_kernel<<<std::min(max_long, 512), kBlock, 0, st>>>(payload, ranges, num_tiles, sorted_out,
+                                                                       long_tiles);
+    GS_LAUNCH_CHECK();
+  }
+  return GSPLAT_OK;
+}
+
 static int tile_bits(int num_tiles) {
   int b = 1;
   while ((1LL << b) < (long long)num_tiles) ++b;
@@ -366,6 +381,119 @@ static long long dense_tile_threshold() {
   return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sparse-scene binning without a global sort.  The per-tile depth sort re-orders every list anyway, so the grouping
+// by tile does not have to be stable -- a counting sort with all atomics in LDS does it:
+//   count:       done by preprocess_kernel itself (gs_fused.hip): workgroup b counts the tiles its slice of the
+//                gaussians hits in an LDS histogram while it runs the hit tests anyway (ds_add_u32 runs at LDS
+//                rate; the same count through L2 atomics would cost more than the radix sort) and writes its
+//                histogram row table[b][0..T);
+//   bin_offsets: one thread per tile turns its column into workgroup-exclusive offsets and a tile total;
+//                an exclusive scan of the totals gives the reference's `ranges`;
+//   bin_scatter: workgroup b loads ranges[t] + table[b][t] as LDS cursors and places every instance with one
+//                returning LDS atomic.
+// 12 bytes per instance are written once (the payload), instead of 24 B x 2 x 2 radix passes + histogram + memsets.
+
+template <typename F>
+__device__ __forceinline__ void for_each_hit_tile(int j, const float *__restrict__ uv, const float *__restrict__ radius,
+                                                  const unsigned long long *__restrict__ hitmask, int ntx, int nty,
+                                                  F f) {
+  const float4 rd = reinterpret_cast<const float4 *>(radius)[j];
+  const float u = uv[2 * j], v = uv[2 * j + 1];
+  const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
+  const int rh = r.y1 - r.y0;
+  if (r.x1 <= r.x0 || rh <= 0) return;
+  if ((r.x1 - r.x0) * rh <= 64) {
+    unsigned long long m = hitmask[j];
+    while (m != 0ull) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1ull;
+      f((r.y0 + b % rh) * ntx + r.x0 + b / rh);
+    }
+  } else {
+    const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
+    for (int tx = r.x0; tx < r.x1; ++tx)
+      for (int ty = r.y0; ty < r.y1; ++ty)
+        if (obb_hits_tile(o, tx, ty)) f(ty * ntx + tx);
+  }
+}
+
+// column t of table -> exclusive prefix over the workgroups; totals[t] = column sum (totals[T] = 0 for the scan).
+// One workgroup per 64 tiles: wave w owns the rows 64w .. 64w+63 of the table (lane = tile, so every load and store
+// is a coalesced 256-byte row segment), keeps its 64 counts in registers and only the four wave sums meet in LDS.
+__global__ __launch_bounds__(256) void bin_offsets_kernel(int T, int *__restrict__ table, int *__restrict__ totals,
+                                                          int *__restrict__ long_tile_count) {
+  static_assert(kBinBlocks == 256, "four waves x 64 table rows");
+  __shared__ int s_sum[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { totals[T] = 0; *long_tile_count = 0; }
+  int v[64], sum = 0;
+  if (t < T) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { v[k] = table[(size_t)(64 * w + k) * T + t]; sum += v[k]; }
+  }
+  s_sum[w][lane] = sum;
+  __syncthreads();
+  if (t >= T) return;
+  int run = 0;
+  for (int q = 0; q < w; ++q) run += s_sum[q][lane];
+  if (w == 3) totals[t] = run + sum;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) { table[(size_t)(64 * w + k) * T + t] = run; run += v[k]; }
+}
+
+__global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *__restrict__ uv,
+                                                                  const float *__restrict__ xyz_c,
+                                                                  const float *__restrict__ radius,
+                                                                  const unsigned long long *__restrict__ hitmask,
+                                                                  const int *__restrict__ rank, int N, int ntx, int nty,
+                                                                  const int *__restrict__ table,
+                                                                  const int *__restrict__ ranges, long long capacity,
+                                                                  unsigned long long *__restrict__ payload) {
+  extern __shared__ int s_cur[];
+  const int T = ntx * nty;
+  for (int t = threadIdx.x; t < T; t += kBinThreads) s_cur[t] = ranges[t] + table[(size_t)blockIdx.x * T + t];
+  __syncthreads();
+  // the compacted gaussians of this workgroup's slice of global indices (rank = exclusive scan of the cull mask)
+  const int lo = rank[(long long)N * blockIdx.x / kBinBlocks], hi = rank[(long long)N * (blockIdx.x + 1) / kBinBlocks];
+  for (int j = lo + threadIdx.x; j < hi; j += kBinThreads) {
+    const unsigned long long pay = ((unsigned long long)float_sort_bits(xyz_c[3 * j + 2]) << 32) | (unsigned int)j;
+    for_each_hit_tile(j, uv, radius, hitmask, ntx, nty, [&](int tile) {
+      const int pos = atomicAdd(&s_cur[tile], 1);
+      if (pos < capacity) payload[pos] = pay;
+    });
+  }
+}
+
+bool binning_supports_counting_sort(int num_tiles) { return num_tiles <= kBinMaxTiles; }
+bool binning_prefers_radix(size_t S, int num_tiles) { return (long long)S > dense_tile_threshold() * (long long)num_tiles; }
+size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 2) * sizeof(int); }
+
+// Phase 1 (needs nothing from the host): per-workgroup offsets and ranges from the histogram rows preprocess_kernel
+// left in `table` (kBinBlocks * T ints, followed by T + 1 totals).
+int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, void *temp, size_t temp_bytes,
+                    hipStream_t st) {
+  const int T = ntx * nty;
+  int *totals = table + (size_t)kBinBlocks * T;
+  bin_offsets_kernel<<<div_up(T, 64), 256, 0, st>>>(T, table, totals, long_tiles);
+  GS_LAUNCH_CHECK();
+  GS_HIP(rocprim::exclusive_scan(temp, temp_bytes, totals, ranges, 0, (size_t)T + 1, rocprim::plus<int>(), st));
+  return GSPLAT_OK;
+}
+
+// Phase 2 (after the host knows S and the buffers hold it): place the payloads, then order every tile by depth.
+int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
+                             const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
+                             const int *table, const int *ranges, size_t S, unsigned long long *payload,
+                             int *long_tiles, int *sorted_out, hipStream_t st) {
+  const int T = ntx * nty;
+  bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
+                                                                             nty, table, ranges, (long long)S, payload);
+  GS_LAUNCH_CHECK();
+  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st);
+}
+
 // The emit step on its own: the fused forward launches it with the buffers' capacity BEFORE it waits for the
 // instance total S, so the GPU works through it while the host sleeps on the read-back.
 int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
@@ -412,16 +540,7 @@ int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, i
   int *long_tiles = reinterpret_cast<int *>(tkeys_a);  // the sort's input keys are dead: reuse them as the list
   tile_ranges32_kernel<<<div_up((long long)S, kBlock), kBlock, 0, st>>>(tkeys_b, (int)S, num_tiles, ranges, long_tiles);
   GS_LAUNCH_CHECK();
-  // per-tile depth order: one wave per tile in registers; the few lists above kWaveSortMax entries are listed in
-  // `long_tiles` and finished by workgroups of the second kernel
-  const int max_long = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)kWaveSortMax);  // cannot be more
-  tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(pay_b, ranges, num_tiles, sorted_out, long_tiles);
-  GS_LAUNCH_CHECK();
-  if (max_long > 0) {
-    tile_depth_sort_kernel<<<std::min(max_long, 512), kBlock, 0, st>>>(pay_b, ranges, num_tiles, sorted_out, long_tiles);
-    GS_LAUNCH_CHECK();
-  }
-  return GSPLAT_OK;
+  return sort_tiles_by_depth(pay_b, ranges, num_tiles, S, long_tiles, sorted_out, st);
 }
 
 }  // namespace gs

@@ -52,6 +52,11 @@ int check_device_ptr(const void *p, const char *name, const char *fn);
     }                                                                                         \
   } while (0)
 
+// Counting-sort binning (gs_binning.hip) and the per-gaussian forward (gs_fused.hip) split the gaussians into the same
+// kBinBlocks contiguous slices: workgroup b of either kernel owns global indices [N*b/kBinBlocks, N*(b+1)/kBinBlocks).
+constexpr int kBinBlocks = 256, kBinThreads = 1024;
+constexpr int kBinMaxTiles = 16384;  // 64 KB of LDS counters; larger tile grids take the radix-sort route
+
 static inline unsigned int div_up(long long a, long long b) { return (unsigned int)((a + b - 1) / b); }
 
 // A growable device buffer (never shrinks).  Growing synchronises the device: it only

@@ -25,6 +25,15 @@ namespace gs {
 // from gs_binning.hip / gs_render.hip
 size_t binning_temp_bytes(size_t N, size_t S, int num_tiles);
 int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_bytes, hipStream_t st);
+bool binning_supports_counting_sort(int num_tiles);
+bool binning_prefers_radix(size_t S, int num_tiles);
+size_t binning_table_bytes(int num_tiles);
+int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, void *temp, size_t temp_bytes,
+                    hipStream_t st);
+int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
+                             const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
+                             const int *table, const int *ranges, size_t S, unsigned long long *payload,
+                             int *long_tiles, int *sorted_out, hipStream_t st);
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
@@ -49,10 +58,11 @@ struct gsplat_context {
   // per-gaussian, compacted order
   gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows, hitmask;
   // instances
-  gs::DeviceBuffer keys_a, keys_b, pay_a, pay_b, sorted, temp;
+  gs::DeviceBuffer keys_a, keys_b, pay_a, pay_b, sorted, temp, bin_table;
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
+  bool dense_route = false;  // binning route of the next forward (follows the last one's density)
   bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
   // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
   volatile unsigned long long *h_pub = nullptr;
@@ -98,7 +108,7 @@ struct gsplat_context {
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                               &sorted, &temp, &ranges, &image, &T_px, &n_px};
+                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px};
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
@@ -150,17 +160,29 @@ struct PreOut {
 };
 
 // ---- B: everything per kept gaussian, written at its compacted slot
+// Launched as kBinBlocks workgroups of kBinThreads: workgroup b owns the global indices [N*b/kBinBlocks,
+// N*(b+1)/kBinBlocks) (plus index N in the last one, for the counts' terminator).  When `table` is given it also
+// histograms the tiles its gaussians hit in LDS -- the count phase of the counting-sort binning, for free next to
+// the separating-axis tests -- and writes the row table[b][0..T).
 template <int L>
-__global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, const float *__restrict__ view,
+__global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaussians g, const float *__restrict__ view,
                                                             const unsigned char *__restrict__ mask,
                                                             const int *__restrict__ rank,
                                                             const float *__restrict__ xyz_c_all,
                                                             const float *__restrict__ uv_all, float fx, float fy,
                                                             float tan_fovx, float tan_fovy, float mh_dist, float cx,
-                                                            float cy, float cz, int ntx, int nty, PreOut o) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  const int N = g.num_gaussians;
+                                                            float cy, float cz, int ntx, int nty, PreOut o,
+                                                            int *__restrict__ table) {
+  extern __shared__ int s_hist[];
+  const int N = g.num_gaussians, T = ntx * nty;
+  if (table) {
+    for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
+    __syncthreads();
+  }
+  const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
+  const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks) + (blockIdx.x == gs::kBinBlocks - 1 ? 1 : 0);
   unsigned long long coarse = 0;
+  for (int i = lo + threadIdx.x; i < hi; i += gs::kBinThreads) {
   // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
   // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
   if (i <= N && i >= rank[N]) o.counts[i] = 0;
@@ -186,14 +208,15 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
   unsigned long long hm = 0ull;
   const gs::TileRect r = gs::coarse_rect(u, v, rad[0], ntx, nty);
   if (r.x1 > r.x0 && r.y1 > r.y0) {
-    coarse = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
+    coarse += (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
     const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
     int bit = 0;
     for (int tx = r.x0; tx < r.x1; ++tx)
       for (int ty = r.y0; ty < r.y1; ++ty, ++bit) {
         const bool h = gs::obb_hits_tile(ob, tx, ty);
         hits += h ? 1 : 0;
-        hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the emit kernel when the rectangle has <= 64 tiles
+        hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the binning kernels when the rectangle has <= 64 tiles
+        if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
       }
   }
   // stores (compacted order)
@@ -210,11 +233,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(gsplat_gaussians g, 
   const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
   o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
   }
+  }
   // candidate-pair count (what call 1 of get_sorted_gaussian_list reports): one atomic per wave, spread over 64
   // counters so that no single address serialises the chip
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) coarse += __shfl_down(coarse, off, 64);
-  if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(&o.pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], coarse);
+  if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(&o.pairs[(blockIdx.x * 16 + (threadIdx.x >> 6)) & 63], coarse);
+  if (table) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += gs::kBinThreads) table[(size_t)blockIdx.x * T + t] = s_hist[t];
+  }
 }
 
 // {M, S, candidate pairs} gathered into one 16-byte record so that the forward's only read-back is one copy
@@ -649,11 +677,20 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
                c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
                c->hitmask.as<unsigned long long>(), c->pair_counters()};
+  // Two binning routes, both exact for any scene; the choice only affects speed, so it follows the LAST forward's
+  // density (the first call starts sparse): sparse = LDS counting sort + per-tile depth sort, dense (more than
+  // ~768 list entries per tile) or very large tile grids = stable radix sorts (gs_binning.hip).
+  const bool sparse = !c->dense_route && gs::binning_supports_counting_sort(num_tiles);
+  int *bin_table = nullptr;
+  if (sparse) {
+    if ((rc = c->bin_table.reserve(gs::binning_table_bytes(num_tiles)))) return rc;
+    bin_table = c->bin_table.as<int>();
+  }
+  const size_t hist_bytes = sparse ? (size_t)num_tiles * sizeof(int) : 0;
 #define GS_PRE(LL)                                                                                                     \
-  preprocess_kernel<LL><<<gridN, block, 0, st>>>(*g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(),        \
-                                                 c->xyz_c_all.as<float>(), c->uv_all.as<float>(), fx, fy, tan_fovx,    \
-                                                 tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1],               \
-                                                 cam->campos[2], ntx, nty, po)
+  preprocess_kernel<LL><<<gs::kBinBlocks, gs::kBinThreads, hist_bytes, st>>>(                                          \
+      *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->xyz_c_all.as<float>(), c->uv_all.as<float>(),  \
+      fx, fy, tan_fovx, tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1], cam->campos[2], ntx, nty, po, bin_table)
   switch (l_max) {
     case 0: GS_PRE(0); break;
     case 1: GS_PRE(1); break;
@@ -662,26 +699,37 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   }
 #undef GS_PRE
   GS_LAUNCH_CHECK();
-  rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
-  if (rc) return rc;
-  c->mark(1, true, st);
+  size_t inst_cap = 0;
+  if (sparse) {
+    c->mark(1, true, st);
+    c->mark(2, false, st);
+    rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), c->temp.ptr, c->temp.bytes, st);
+    if (rc) return rc;
+  } else {
+    rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
+    if (rc) return rc;
+    c->mark(1, true, st);
+  }
   // the one host read-back of the forward: M, S (and the candidate count)
   const unsigned long long ticket = ++c->ticket;
-  publish_counts_kernel<<<1, 64, 0, st>>>(c->rank.as<int>() + N, c->offsets.as<int>() + N, c->pair_counters(),
-                                         c->d_pub, ticket);
+  publish_counts_kernel<<<1, 64, 0, st>>>(c->rank.as<int>() + N,
+                                         sparse ? c->ranges.as<int>() + num_tiles : c->offsets.as<int>() + N,
+                                         c->pair_counters(), c->d_pub, ticket);
   GS_LAUNCH_CHECK();
-  // Emit does not need the totals on the host, only room for its writes: launch it bounded by the buffers' capacity
-  // and sleep on the read-back while it runs (the reference blocks five times per forward with the GPU idle).
-  const size_t inst_cap = c->keys_a.bytes / sizeof(unsigned int) - 1;
-  c->mark(2, false, st);
-  rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
-                            c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
-                            c->hitmask.as<unsigned long long>(), (long long)inst_cap,
-                            c->keys_a.as<unsigned int>(), c->pay_a.as<unsigned long long>(), st);
-  if (rc) return rc;
+  if (!sparse) {
+    // Emit does not need the totals on the host, only room for its writes: launch it bounded by the buffers'
+    // capacity and sleep on the read-back while it runs (the reference blocks five times per forward, GPU idle).
+    inst_cap = c->keys_a.bytes / sizeof(unsigned int) - 1;
+    c->mark(2, false, st);
+    rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
+                              c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
+                              c->hitmask.as<unsigned long long>(), (long long)inst_cap,
+                              c->keys_a.as<unsigned int>(), c->pay_a.as<unsigned long long>(), st);
+    if (rc) return rc;
+  }
   {
     // Poll the mapped record; every few hundred polls ask the runtime about the stream, which both keeps its
-    // submission path moving and tells us when everything queued so far (emit included) has drained.
+    // submission path moving and tells us when everything queued so far has drained.
     volatile unsigned long long *pub = c->h_pub;
     long long polls = 0;
     while (__atomic_load_n(&pub[2], __ATOMIC_ACQUIRE) != ticket) {
@@ -707,15 +755,26 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;
   }
-  const bool emitted = S <= inst_cap;  // else: grow the instance buffers (synchronises) and emit again
+  c->dense_route = gs::binning_prefers_radix(S, num_tiles);
+  const bool emitted = S <= inst_cap;  // dense route: else grow the instance buffers (synchronises) and emit again
+  const void *keys_before = c->keys_a.ptr;
   rc = reserve_instances(c, S, num_tiles);
   if (rc) return rc;
-  rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
-                            c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
-                            c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
-                            c->pay_a.as<unsigned long long>(), c->pay_b.as<unsigned long long>(), c->sorted.as<int>(),
-                            c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st, emitted,
-                            c->hitmask.as<unsigned long long>());
+  if (sparse) {
+    // the long-tile counter lives at the head of keys_a and was zeroed by bin_offsets: redo it if the buffer moved
+    if (c->keys_a.ptr != keys_before) GS_HIP(hipMemsetAsync(c->keys_a.ptr, 0, sizeof(int), st));
+    rc = gs::binning_scatter_and_sort(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(),
+                                      c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
+                                      c->bin_table.as<int>(), c->ranges.as<int>(), S, c->pay_a.as<unsigned long long>(),
+                                      c->keys_a.as<int>(), c->sorted.as<int>(), st);
+  } else {
+    rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
+                              c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
+                              c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
+                              c->pay_a.as<unsigned long long>(), c->pay_b.as<unsigned long long>(),
+                              c->sorted.as<int>(), c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st, emitted,
+                              c->hitmask.as<unsigned long long>());
+  }
   if (rc) return rc;
   c->mark(2, true, st);
   c->mark(4, false, st);

@@ -215,8 +215,10 @@ def test_pack_gradients_global_layout(gpu, scene):
 
 
 def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
-    """More than 768 list entries per tile on average: the depth order comes from a global stable pre-sort instead
-    of the per-tile kernels; lists and image must still match the oracle exactly / within tolerance."""
+    """More than 768 list entries per tile on average.  The binning route follows the previous forward's density: the
+    first call on a context bins with the counting sort + per-tile kernels (lists > 2048 entries: in-place global
+    network), the second takes the dense route (global stable depth pre-sort + stable tile sort).  Both must match the
+    oracle exactly (lists) / within tolerance (image)."""
     raster = pkg("raster")
     N, W, H, L = 40000, 64, 48, 0
     params = scene.make_gaussians(N, W, H, L)
@@ -224,10 +226,12 @@ def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
     cam = scene.make_camera(W, H)
     c = scene.CONFIG
     ctx = raster.RasterContext(N, W, H)
-    fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
-    assert np.diff(ref["ranges"]).max() > 2048
-    _check_forward(fwd, ref)
+    assert np.diff(ref["ranges"]).max() > 2048 and len(ref["sorted"]) > 768 * (len(ref["ranges"]) - 1)
+    for route in ("counting sort", "radix"):
+        fwd = ctx.rasterize_image(dp, dc, c, 0.5, L)
+        _check_forward(fwd, ref)
 
 
 def test_few_long_tile_lists_in_a_sparse_scene(gpu, scene, orc):
