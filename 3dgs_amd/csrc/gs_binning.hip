@@ -61,8 +61,9 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const float *__restr
     if (r.x1 > r.x0 && r.y1 > r.y0) {
       coarse = (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
       const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
-      for (int tx = r.x0; tx < r.x1; ++tx)
-        for (int ty = r.y0; ty < r.y1; ++ty) hits += obb_hits_tile(o, tx, ty) ? 1 : 0;
+      const TileRect sp = obb_span(o, r);
+      for (int tx = sp.x0; tx < sp.x1; ++tx)
+        for (int ty = sp.y0; ty < sp.y1; ++ty) hits += obb_hits_tile(o, tx, ty) ? 1 : 0;
     }
     counts[j] = hits;
   }
@@ -117,8 +118,9 @@ __global__ __launch_bounds__(kBlock) void tile_emit_payload_kernel(const float *
     return;
   }
   const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
-  for (int tx = r.x0; tx < r.x1; ++tx)
-    for (int ty = r.y0; ty < r.y1; ++ty)
+  const TileRect sp = obb_span(o, r);
+  for (int tx = sp.x0; tx < sp.x1; ++tx)
+    for (int ty = sp.y0; ty < sp.y1; ++ty)
       if (obb_hits_tile(o, tx, ty) && w < end) {
         keys[w] = (unsigned int)(ty * ntx + tx);
         payload[w] = pay;
@@ -412,8 +414,9 @@ __device__ __forceinline__ void for_each_hit_tile(int j, const float *__restrict
     }
   } else {
     const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
-    for (int tx = r.x0; tx < r.x1; ++tx)
-      for (int ty = r.y0; ty < r.y1; ++ty)
+    const TileRect sp = obb_span(o, r);
+    for (int tx = sp.x0; tx < sp.x1; ++tx)
+      for (int ty = sp.y0; ty < sp.y1; ++ty)
         if (obb_hits_tile(o, tx, ty)) f(ty * ntx + tx);
   }
 }

@@ -210,10 +210,12 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   if (r.x1 > r.x0 && r.y1 > r.y0) {
     coarse += (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
     const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
-    int bit = 0;
-    for (int tx = r.x0; tx < r.x1; ++tx)
-      for (int ty = r.y0; ty < r.y1; ++ty, ++bit) {
+    const gs::TileRect sp = gs::obb_span(ob, r);
+    const int rh = r.y1 - r.y0;
+    for (int tx = sp.x0; tx < sp.x1; ++tx)
+      for (int ty = sp.y0; ty < sp.y1; ++ty) {
         const bool h = gs::obb_hits_tile(ob, tx, ty);
+        const int bit = (tx - r.x0) * rh + (ty - r.y0);  // position in the full coarse rectangle
         hits += h ? 1 : 0;
         hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the binning kernels when the rectangle has <= 64 tiles
         if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);

@@ -326,6 +326,20 @@ __device__ __forceinline__ bool obb_hits_tile(const Obb &o, int tx, int ty) {
   return true;
 }
 
+// The part of the coarse rectangle whose tiles can pass the two axis-aligned tests of obb_hits_tile: tile tx passes
+// them iff 16(tx+1) >= mnx and 16 tx <= mxx, i.e. ceil(mnx/16) - 1 <= tx <= floor(mxx/16) (the scalings are exact).
+// Tiles outside fail for certain, so looping over this span with the full test changes no membership; NaN bounds keep
+// the whole rectangle (fmaxf / fminf drop the NaN), matching the "NaN passes" rule above.  Typical gaussians need 4-6
+// candidates instead of the reference rectangle's 25.
+__device__ __forceinline__ TileRect obb_span(const Obb &o, const TileRect &r) {
+  TileRect s;
+  s.x0 = (int)fminf(fmaxf((float)r.x0, ceilf(o.mnx * 0.0625f) - 1.0f), (float)r.x1);
+  s.x1 = (int)fmaxf(fminf((float)(r.x1 - 1), floorf(o.mxx * 0.0625f)), (float)(r.x0 - 1)) + 1;
+  s.y0 = (int)fminf(fmaxf((float)r.y0, ceilf(o.mny * 0.0625f) - 1.0f), (float)r.y1);
+  s.y1 = (int)fmaxf(fminf((float)(r.y1 - 1), floorf(o.mxy * 0.0625f)), (float)(r.y0 - 1)) + 1;
+  return s;
+}
+
 // monotone map float -> uint32 (ascending float order == ascending unsigned order)
 __device__ __forceinline__ unsigned int float_sort_bits(float z) {
   const unsigned int b = __float_as_uint(z);
