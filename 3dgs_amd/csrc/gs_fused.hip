@@ -464,8 +464,10 @@ __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char 
   else if (rgb) rgb[(size_t)i * 3 + (k - 12)] = val;
 }
 
-// rgb_all: world blocks of `stride` floats; block r = [N,3] g_rgb of rank r followed by that rank's campos[3]
-template <int L>
+// rgb_all: world blocks of `stride` floats; block r = [N,3] g_rgb of rank r followed by that rank's campos[3].
+// kSh: rebuild the SH-coefficient columns from rgb_all; kCommon: place the twelve all-reduced columns.  The two
+// halves touch disjoint columns of `full`, so the SH half can run while the all-reduce of `common` is in flight.
+template <int L, bool kSh, bool kCommon>
 __global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__restrict__ xyz, int N, int world,
                                                               const float *__restrict__ common,
                                                               const float *__restrict__ rgb_all, size_t stride,
@@ -474,30 +476,34 @@ __global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__res
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   const int wo = 12 + 3 * n;
-  const float *row = common + (size_t)i * 12;
   float *out = full + (size_t)i * wo;
-  float acc[n][3];
+  if constexpr (kSh) {
+    float acc[n][3];
 #pragma unroll
-  for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
-  const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
-  for (int r = 0; r < world; ++r) {
-    const float *blk = rgb_all + (size_t)r * stride;
-    const float g0 = blk[3 * (size_t)i], g1 = blk[3 * (size_t)i + 1], g2 = blk[3 * (size_t)i + 2];
-    if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
-    const float *cp = blk + 3 * (size_t)N;
-    float dx, dy, dz, len, Y[n];
-    gs::view_dir(px, py, pz, cp[0], cp[1], cp[2], dx, dy, dz, len);
-    gs::sh_basis<L>(dx, dy, dz, Y);
+    for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+    for (int r = 0; r < world; ++r) {
+      const float *blk = rgb_all + (size_t)r * stride;
+      const float g0 = blk[3 * (size_t)i], g1 = blk[3 * (size_t)i + 1], g2 = blk[3 * (size_t)i + 2];
+      if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+      const float *cp = blk + 3 * (size_t)N;
+      float dx, dy, dz, len, Y[n];
+      gs::view_dir(px, py, pz, cp[0], cp[1], cp[2], dx, dy, dz, len);
+      gs::sh_basis<L>(dx, dy, dz, Y);
 #pragma unroll
-    for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
+      for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) { out[3 + 3 * k] = acc[k][0]; out[4 + 3 * k] = acc[k][1]; out[5 + 3 * k] = acc[k][2]; }
   }
-  out[0] = row[0]; out[1] = row[1]; out[2] = row[2];  // xyz
-#pragma unroll
-  for (int k = 0; k < n; ++k) { out[3 + 3 * k] = acc[k][0]; out[4 + 3 * k] = acc[k][1]; out[5 + 3 * k] = acc[k][2]; }
-  out[3 + 3 * n] = row[3];                                             // opacity
-  out[4 + 3 * n] = row[4]; out[5 + 3 * n] = row[5]; out[6 + 3 * n] = row[6];  // scale
-  out[7 + 3 * n] = row[7]; out[8 + 3 * n] = row[8]; out[9 + 3 * n] = row[9]; out[10 + 3 * n] = row[10];  // quaternion
-  out[11 + 3 * n] = row[11];                                           // visibility count
+  if constexpr (kCommon) {
+    const float *row = common + (size_t)i * 12;
+    out[0] = row[0]; out[1] = row[1]; out[2] = row[2];                          // xyz
+    out[3 + 3 * n] = row[3];                                                    // opacity
+    out[4 + 3 * n] = row[4]; out[5 + 3 * n] = row[5]; out[6 + 3 * n] = row[6];  // scale
+    out[7 + 3 * n] = row[7]; out[8 + 3 * n] = row[8]; out[9 + 3 * n] = row[9]; out[10 + 3 * n] = row[10];  // quaternion
+    out[11 + 3 * n] = row[11];                                                  // visibility count
+  }
 }
 
 int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
@@ -567,18 +573,33 @@ int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads
 
 int gsplat_unpack_gradients_split(const float *xyz, const float *common, const float *rgb_all, size_t rank_stride,
                                   int l_max, int num_gaussians, int world_size, float *full, void *stream) {
-  GS_REQUIRE_DEV(xyz); GS_REQUIRE_DEV(common); GS_REQUIRE_DEV(rgb_all); GS_REQUIRE_DEV(full);
+  GS_REQUIRE_DEV(full);
+  GS_REQUIRE(common != nullptr || rgb_all != nullptr, "nothing to unpack");
   GS_REQUIRE(l_max >= 0 && l_max <= 3 && num_gaussians >= 0 && world_size >= 1, "bad sizes");
-  GS_REQUIRE(rank_stride >= 3 * (size_t)num_gaussians + 3, "rank_stride must cover [N,3] g_rgb + campos[3]");
+  if (common) GS_REQUIRE_DEV(common);
+  if (rgb_all) {
+    GS_REQUIRE_DEV(rgb_all); GS_REQUIRE_DEV(xyz);
+    GS_REQUIRE(rank_stride >= 3 * (size_t)num_gaussians + 3, "rank_stride must cover [N,3] g_rgb + campos[3]");
+  }
   if (num_gaussians == 0) return GSPLAT_OK;
   const dim3 g(gs::div_up(num_gaussians, kBlock)), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
+#define GS_UNPACK(LL)                                                                                                  \
+  do {                                                                                                                 \
+    if (common && rgb_all)                                                                                             \
+      unpack_split_kernel<LL, true, true><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full);  \
+    else if (rgb_all)                                                                                                  \
+      unpack_split_kernel<LL, true, false><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, nullptr, rgb_all, rank_stride, full); \
+    else                                                                                                               \
+      unpack_split_kernel<LL, false, true><<<g, b, 0, st>>>(nullptr, num_gaussians, world_size, common, nullptr, 0, full);        \
+  } while (0)
   switch (l_max) {
-    case 0: unpack_split_kernel<0><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
-    case 1: unpack_split_kernel<1><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
-    case 2: unpack_split_kernel<2><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
-    default: unpack_split_kernel<3><<<g, b, 0, st>>>(xyz, num_gaussians, world_size, common, rgb_all, rank_stride, full); break;
+    case 0: GS_UNPACK(0); break;
+    case 1: GS_UNPACK(1); break;
+    case 2: GS_UNPACK(2); break;
+    default: GS_UNPACK(3); break;
   }
+#undef GS_UNPACK
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

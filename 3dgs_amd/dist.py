@@ -122,10 +122,13 @@ class ViewShardedStep:
                 gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
             else:
                 self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, None)
-            for w in (dist.all_reduce(self.common, op=dist.ReduceOp.SUM, async_op=True), gather):
-                w.wait()
-            self.raster.unpack_gradients_split(self.params["xyz"], self.common, self.rgb_all, 3 * (self.N + 1),
-                                               self.l_max, self.N, self.world, self.packed)
+            reduce = dist.all_reduce(self.common, op=dist.ReduceOp.SUM, async_op=True)
+            # the SH columns only need the gathered g_rgb: rebuild them while the all-reduce is in flight
+            gather.wait()
+            self.raster.unpack_gradients_split(self.params["xyz"], None, self.rgb_all, 3 * (self.N + 1), self.l_max,
+                                               self.N, self.world, self.packed)
+            reduce.wait()
+            self.raster.unpack_gradients_split(None, self.common, None, 0, self.l_max, self.N, self.world, self.packed)
         elif self.exchange == "factored":
             f = self.factored
             self.raster.pack_gradients_factored(self.ctx, self.grads, self.N, self.rank, self.world, f)

@@ -358,7 +358,9 @@ int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, 
  * visible1] is SUM all-reduced, and every rank's g_rgb[N,3] (+ its camera position in row N) is all-gathered into
  * rgb_all = world blocks of rank_stride floats (block r = rank r's [N,3] g_rgb followed by campos[3]).  At 8 ranks
  * and SH degree 3 a rank moves 2*(7/8)*48 MB + 7*12 MB = 168 MB per step instead of 252 MB (one factored all-reduce)
- * or 420 MB (full rows).  rgb may be NULL when gsplat_backward_render already produced it. */
+ * or 420 MB (full rows).  rgb may be NULL when gsplat_backward_render already produced it.  The unpack may be issued in
+ * two halves that write disjoint columns of `packed`: common == NULL rebuilds only the SH columns (it can run while the
+ * all-reduce of `common` is still in flight), rgb_all == NULL places only the twelve reduced columns. */
 int gsplat_pack_gradients_split(gsplat_context *ctx, const gsplat_gradients *grads, int num_gaussians, float *common,
                                 float *rgb, void *stream);
 int gsplat_unpack_gradients_split(const float *xyz, const float *common, const float *rgb_all, size_t rank_stride,
