@@ -105,6 +105,32 @@ def test_lower_sh_degrees(gpu, scene, orc, l_max):
     _check_backward(grads, bref)
 
 
+@pytest.mark.parametrize("shape", [(1, 17, 9, 0), (3, 33, 31, 1), (37, 100, 7, 2), (255, 16, 16, 3), (257, 130, 66, 3)])
+def test_odd_sizes_match_oracle(gpu, scene, orc, shape):
+    """Gaussian counts around the workgroup partition sizes and image sizes that are not multiples of the tile."""
+    torch = gpu
+    raster = pkg("raster")
+    N, W, H, L = shape
+    params = scene.make_gaussians(N, W, H, L)
+    cam = scene.make_camera(W, H, 1)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    try:
+        fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    except pkg("_lib").GsplatError as e:
+        assert e.code == -5  # nothing visible from this pose: the oracle must agree
+        ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L)
+        assert int(ref["mask"].sum()) == 0
+        return
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L)
+    _check_forward(fwd, ref)
+    gi = scene.make_grad_image(W, H)
+    grads = ctx.alloc_gradients(fwd["num_culled"], L)
+    ctx.backward_pass(dp, dc, torch.as_tensor(gi).cuda(), c["bg"], L, grads)
+    _check_backward(grads, orc.backward_pass(ref, cam, gi, c["bg"], L))
+
+
 def test_culling_and_empty_view(gpu, scene):
     """Gaussians behind the camera are culled; a view that sees nothing is an error code, not an exit
     (cuda/raster.cu:38-41)."""
