@@ -96,6 +96,7 @@ SIGNATURES = {
     "gsplat_compute_sigma_backward": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "gsplat_precompute_spherical_harmonics_backward": (_I, [_P, _P, _P, _F, _F, _F, _P, _I, _I, _P, _P, _P, _P]),
     "gsplat_render_image_backward": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "gsplat_context_set_binning_route": (_I, [_P, _I]),
     "gsplat_backward_render": (_I, [_P, _P, _F, _P, _P]),
     "gsplat_backward_gaussians": (_I, [_P, _P, _P, _I, _P, _P]),
     "gsplat_pack_gradients_split": (_I, [_P, _P, _I, _P, _P, _P]),

@@ -63,6 +63,7 @@ struct gsplat_context {
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
   bool dense_route = false;  // binning route of the next forward (follows the last one's density)
+  int forced_route = 0;      // gsplat_context_set_binning_route: 0 auto, 1 counting sort, 2 radix sorts
   bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
   // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
   volatile unsigned long long *h_pub = nullptr;
@@ -703,7 +704,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   // Two binning routes, both exact for any scene; the choice only affects speed, so it follows the LAST forward's
   // density (the first call starts sparse): sparse = LDS counting sort + per-tile depth sort, dense (more than
   // ~768 list entries per tile) or very large tile grids = stable radix sorts (gs_binning.hip).
-  const bool sparse = !c->dense_route && gs::binning_supports_counting_sort(num_tiles);
+  const bool want_dense = c->forced_route == 2 || (c->forced_route == 0 && c->dense_route);
+  const bool sparse = !want_dense && gs::binning_supports_counting_sort(num_tiles);
   int *bin_table = nullptr;
   if (sparse) {
     if ((rc = c->bin_table.reserve(gs::binning_table_bytes(num_tiles)))) return rc;
@@ -901,6 +903,13 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
   int rc = gsplat_backward_render(c, grad_image, bg_color, nullptr, stream);
   if (rc) return rc;
   return gsplat_backward_gaussians(c, g, cam, l_max, out, stream);
+}
+
+int gsplat_context_set_binning_route(gsplat_context *c, int route) {
+  GS_REQUIRE(c != nullptr, "null context");
+  GS_REQUIRE(route >= 0 && route <= 2, "route: 0 auto, 1 counting sort, 2 radix sorts");
+  c->forced_route = route;
+  return GSPLAT_OK;
 }
 
 int gsplat_context_set_timing(gsplat_context *c, int enabled) {

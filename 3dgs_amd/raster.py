@@ -78,6 +78,10 @@ class RasterContext:
     STAGES = ("project_cull", "preprocess", "bin_sort", "reserved", "render_forward", "zero_grad_rows",
               "render_backward", "preprocess_backward")
 
+    def set_binning_route(self, route):
+        """0 automatic, 1 LDS counting sort + per-tile depth sort, 2 stable radix sorts (identical results)."""
+        check(self._lib.gsplat_context_set_binning_route(self._h, int(route)))
+
     def set_timing(self, enabled):
         check(self._lib.gsplat_context_set_timing(self._h, int(bool(enabled))))
 

@@ -326,6 +326,11 @@ int gsplat_backward_render(gsplat_context *ctx, const float *grad_image, float b
 int gsplat_backward_gaussians(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
                               int l_max, const gsplat_gradients *out, void *stream);
 
+/* Binning route of the fused forward.  0 (default): automatic -- the LDS counting sort + per-tile depth sort, or, when
+ * the previous forward had more than ~768 list entries per tile (dense real scenes) or the tile grid exceeds 16384
+ * tiles, stable radix sorts on (depth bits, tile).  1 / 2 force one route.  Both produce identical lists. */
+int gsplat_context_set_binning_route(gsplat_context *ctx, int route);
+
 /* Measurement hook: when enabled, every stage of the two fused passes is bracketed by HIP events on the
  * caller's stream.  Stage ids: 0 project+cull+scan, 1 preprocess+scan, 2 emit + tile sort + ranges + per-tile depth sort, 3 reserved,
  * 4 compositing forward, 5 gradient-row memset, 6 compositing backward, 7 per-gaussian backward.

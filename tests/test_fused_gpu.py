@@ -131,6 +131,28 @@ def test_odd_sizes_match_oracle(gpu, scene, orc, shape):
     _check_backward(grads, orc.backward_pass(ref, cam, gi, c["bg"], L))
 
 
+def test_instance_buffers_grow(gpu, scene, orc):
+    """Large gaussians: many more than 4 instances per gaussian, so the context has to grow its instance buffers in
+    the middle of the forward (after the speculative part has run), on either binning route."""
+    raster = pkg("raster")
+    N, W, H, L = 300, 256, 144, 1
+    params = scene.make_gaussians(N, W, H, L)
+    params["scale"] += 2.5          # ~12x larger: rectangles of dozens of tiles (also beyond the 64-tile hit mask)
+    params["opacity"][:] = -3.0
+    cam = scene.make_camera(W, H)
+    c = scene.CONFIG
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
+    assert len(ref["sorted"]) > 6 * N
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    for route in (1, 2):  # fresh contexts: growth on the first call of each route
+        ctx = raster.RasterContext(N, W, H)
+        ctx.set_binning_route(route)
+        before = ctx.workspace_bytes
+        _check_forward(ctx.rasterize_image(dp, dc, c, 0.5, L), ref)
+        assert ctx.workspace_bytes > before
+        _check_forward(ctx.rasterize_image(dp, dc, c, 0.5, L), ref)
+
+
 def test_culling_and_empty_view(gpu, scene):
     """Gaussians behind the camera are culled; a view that sees nothing is an error code, not an exit
     (cuda/raster.cu:38-41)."""
@@ -255,7 +277,8 @@ def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
     dp, dc = raster.device_params(params), raster.device_camera(cam)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
     assert np.diff(ref["ranges"]).max() > 2048 and len(ref["sorted"]) > 768 * (len(ref["ranges"]) - 1)
-    for route in ("counting sort", "radix"):
+    for route in (0, 0, 1, 2):  # automatic (counting sort first, then radix), then each forced
+        ctx.set_binning_route(route)
         fwd = ctx.rasterize_image(dp, dc, c, 0.5, L)
         _check_forward(fwd, ref)
 
