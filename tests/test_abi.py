@@ -45,4 +45,12 @@ def test_shim_headers_keep_reference_signatures():
     dens = open(os.path.join(ROOT, "include", "gsplat_cuda", "adaptive_density.cuh")).read()
     assert re.search(r"\bcompute_morton_codes\s*\(", fwd)  # "next" row f4 operators
     assert re.search(r"\bclone_gaussians\s*\(", dens) and re.search(r"\bsplit_gaussians\s*\(", dens)
+    data = open(os.path.join(ROOT, "include", "gsplat_cuda", "cuda_data.cuh")).read()
+    rast = open(os.path.join(ROOT, "include", "gsplat_cuda", "raster.cuh")).read()
+    for n in ["GaussianParameters", "OptimizerParameters", "GaussianGradients", "GradientAccumulators", "CameraParameters",
+              "CudaDataManager", "ForwardPassData"]:  # cuda_data.cuh:11-86
+        assert re.search(r"struct\s+%s\b" % n, data), n
+    for n in ["compact_masked_array", "scatter_masked_array"]:
+        assert re.search(r"\b%s\s*\(" % n, data), n
+    assert re.search(r"\brasterize_image\s*\(", rast)  # raster.cuh:22-24
     assert "TILE_SIZE_FWD = 16" in fwd and "TILE_SIZE_BWD = 16" in bwd

@@ -8,16 +8,19 @@ import pytest
 from conftest import ROOT, pkg
 
 EXE = os.path.join(ROOT, "tests", "cpp", "shim_test")
+RASTER_EXE = os.path.join(ROOT, "tests", "cpp", "raster_shim_test")
 
 
-def _build():
+def _build(name="shim_test"):
     lib = pkg("_lib").build()
-    src = os.path.join(ROOT, "tests", "cpp", "shim_test.cpp")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", name)
+    hdrs = [os.path.join(ROOT, "include", "gsplat_cuda", h) for h in os.listdir(os.path.join(ROOT, "include", "gsplat_cuda"))]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in [src, lib] + hdrs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", "-I",
                                os.path.join(ROOT, "include"), src, "-x", "none", lib, "-Wl,-rpath," + os.path.dirname(lib),
-                               "-o", EXE])
-    return EXE
+                               "-o", exe])
+    return exe
 
 
 def test_host_written_against_reference_headers_compiles():
@@ -28,5 +31,18 @@ def test_host_written_against_reference_headers_compiles():
 def test_shim_known_answers_on_gpu():
     exe = _build()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
+
+
+def test_raster_header_host_compiles():
+    """raster.cuh / cuda_data.cuh: rasterize_image(...) and the compaction templates with the reference's signatures
+    (thrust vectors via rocThrust, stand-ins for the Eigen-based host types)."""
+    assert os.path.exists(_build("raster_shim_test"))
+
+
+@pytest.mark.gpu
+def test_raster_shim_on_gpu():
+    out = subprocess.run([_build("raster_shim_test")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
