@@ -39,7 +39,10 @@
 
 namespace gs {
 
-constexpr int kBatch = 256;
+#ifndef GS_FWD_BATCH
+#define GS_FWD_BATCH 256
+#endif
+constexpr int kBatch = GS_FWD_BATCH;
 
 struct RawSplats {  // the reference operator's input arrays
   const float *uv, *opacity, *conic, *rgb;
