@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void adam_kernel(long long n, float *__restric
 // cuda/trainer.cu:1027-1158: only gaussians visible in the view are touched, everything else keeps its moments).
 struct GroupTable {
   gsplat_adam_group g[GSPLAT_MAX_ADAM_GROUPS];
-  int start[GSPLAT_MAX_ADAM_GROUPS + 1];  // prefix of strides
+  int start[GSPLAT_MAX_ADAM_GROUPS + 1];      // prefix of strides
+  int blk_start[GSPLAT_MAX_ADAM_GROUPS + 1];  // prefix of workgroups per group (filled by group_blocks)
   int n;
 };
 
@@ -219,34 +220,34 @@ __device__ __forceinline__ void adam_update(float *param, float *m, float *v, fl
 // kPacked = false: grads are compacted [M,stride] arrays and c2g maps compacted -> global rows.
 // kPacked = true : grads are rows of the packed global layout; a row is live when its last column (views that saw
 //                  the gaussian) is positive.
+// Workgroups are dealt to the parameter groups in order (blk_start[k] .. blk_start[k+1]), so the group -- its
+// pointers, stride and learning rate -- is uniform per workgroup and lives in scalar registers; thread i of a group
+// owns element i of that group's [rows, stride] gradient array, i.e. the gradient read is perfectly coalesced.
 template <bool kPacked>
-__global__ __launch_bounds__(256) void optimizer_step_kernel(long long total, GroupTable t,
-                                                             const int *__restrict__ c2g,
+__global__ __launch_bounds__(256) void optimizer_step_kernel(int rows, GroupTable t, const int *__restrict__ c2g,
                                                              const float *__restrict__ packed, int width, float b1,
                                                              float b2, float eps, float bias1, float bias2,
                                                              const float *__restrict__ grad_uv,
                                                              float *__restrict__ uv_accum, int *__restrict__ accum_dur) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int per = t.start[t.n];
-  const long long r = idx / per;
-  const int e = (int)(idx - r * per);
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < GSPLAT_MAX_ADAM_GROUPS; ++q) k += (q < t.n && (int)blockIdx.x >= t.blk_start[q]) ? 1 : 0;
+  const gsplat_adam_group G = t.g[k];
+  const unsigned int i = (blockIdx.x - (unsigned int)t.blk_start[k]) * 256u + threadIdx.x;
+  const unsigned int stride = (unsigned int)G.stride;
+  if (i >= (unsigned int)rows * stride) return;
+  const unsigned int r = i / stride, c = i - r * stride;
   long long row;
   if (kPacked) {
     row = r;
-    if (!(packed[r * width + width - 1] > 0.0f)) return;
+    if (!(packed[(size_t)r * width + width - 1] > 0.0f)) return;
   } else {
     row = c2g[r];
   }
-  int k = 0;
-#pragma unroll
-  for (int q = 1; q < GSPLAT_MAX_ADAM_GROUPS; ++q) k += (q < t.n && e >= t.start[q]) ? 1 : 0;
-  const gsplat_adam_group &G = t.g[k];
-  const int c = e - t.start[k];
-  const float g = kPacked ? packed[r * width + G.packed_column + c] : G.grad[r * G.stride + c];
-  const long long o = row * G.stride + c;
+  const float g = kPacked ? packed[(size_t)r * width + G.packed_column + c] : G.grad[i];
+  const long long o = row * stride + c;
   adam_update(&G.param[o], &G.exp_avg[o], &G.exp_avg_sq[o], g, G.lr, b1, b2, eps, bias1, bias2);
-  if (!kPacked && e == 0) {  // densification statistics, cuda/trainer.cu:1136-1157
+  if (!kPacked && k == 0 && c == 0) {  // densification statistics, cuda/trainer.cu:1136-1157
     if (uv_accum) {
       const float u = grad_uv[2 * r], v = grad_uv[2 * r + 1];
       uv_accum[row] += sqrtf(u * u + v * v);
@@ -278,6 +279,16 @@ int build_group_table(const gsplat_adam_group *groups, int n_groups, bool packed
   }
   for (int k = n_groups; k < GSPLAT_MAX_ADAM_GROUPS; ++k) t->start[k + 1] = t->start[n_groups];
   return GSPLAT_OK;
+}
+
+// workgroups of 256 threads per group for `rows` rows; returns the total
+static long long group_blocks(GroupTable *t, long long rows) {
+  long long run = 0;
+  for (int k = 0; k <= GSPLAT_MAX_ADAM_GROUPS; ++k) {
+    t->blk_start[k] = (int)run;
+    if (k < t->n) run += (rows * t->g[k].stride + 255) / 256;
+  }
+  return run;
 }
 
 int read_spread_sum(float *d_acc, hipStream_t st, double *out) {
@@ -371,9 +382,10 @@ int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gs
   GS_REQUIRE_DEV(compact_to_global);
   if (uv_grad_accum) { GS_REQUIRE_DEV(uv_grad_accum); GS_REQUIRE_DEV(grad_uv); }
   if (grad_accum_dur) GS_REQUIRE_DEV(grad_accum_dur);
-  const long long total = (long long)num_culled * t.start[t.n];
-  optimizer_step_kernel<false><<<gs::div_up(total, 256), 256, 0, (hipStream_t)stream>>>(
-      total, t, compact_to_global, nullptr, 0, b1, b2, eps, bias1, bias2, grad_uv, uv_grad_accum, grad_accum_dur);
+  GS_REQUIRE((long long)num_culled * t.start[t.n] < (1ll << 31), "too many parameters for one launch");
+  const long long blocks = group_blocks(&t, num_culled);
+  optimizer_step_kernel<false><<<(unsigned int)blocks, 256, 0, (hipStream_t)stream>>>(
+      num_culled, t, compact_to_global, nullptr, 0, b1, b2, eps, bias1, bias2, grad_uv, uv_grad_accum, grad_accum_dur);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
@@ -388,9 +400,10 @@ int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int wid
     GS_REQUIRE(groups[k].packed_column + groups[k].stride <= width - 1, "group columns exceed the packed row");
   if (num_gaussians == 0) return GSPLAT_OK;
   GS_REQUIRE_DEV(packed);
-  const long long total = (long long)num_gaussians * t.start[t.n];
-  optimizer_step_kernel<true><<<gs::div_up(total, 256), 256, 0, (hipStream_t)stream>>>(
-      total, t, nullptr, packed, width, b1, b2, eps, bias1, bias2, nullptr, nullptr, nullptr);
+  GS_REQUIRE((long long)num_gaussians * t.start[t.n] < (1ll << 31), "too many parameters for one launch");
+  const long long blocks = group_blocks(&t, num_gaussians);
+  optimizer_step_kernel<true><<<(unsigned int)blocks, 256, 0, (hipStream_t)stream>>>(
+      num_gaussians, t, nullptr, packed, width, b1, b2, eps, bias1, bias2, nullptr, nullptr, nullptr);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
