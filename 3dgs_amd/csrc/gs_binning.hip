@@ -469,6 +469,26 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
   }
 }
 
+// ranges[0..T] = exclusive scan of totals[0..T) (ranges[T] = S): one workgroup, T <= kBinMaxTiles.  Replaces a
+// three-kernel rocPRIM scan of a few thousand integers.
+__global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__restrict__ totals, int *__restrict__ ranges) {
+  __shared__ int s_part[1024];
+  const int per = (T + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, T);
+  int sum = 0;
+  for (int t = lo; t < hi; ++t) sum += totals[t];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = s_part[threadIdx.x] - sum;
+  for (int t = lo; t < hi; ++t) { ranges[t] = run; run += totals[t]; }
+  if (threadIdx.x == 1023) ranges[T] = s_part[1023];
+}
+
 bool binning_supports_counting_sort(int num_tiles) { return num_tiles <= kBinMaxTiles; }
 bool binning_prefers_radix(size_t S, int num_tiles) { return (long long)S > dense_tile_threshold() * (long long)num_tiles; }
 size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 2) * sizeof(int); }
@@ -481,7 +501,9 @@ int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, 
   int *totals = table + (size_t)kBinBlocks * T;
   bin_offsets_kernel<<<div_up(T, 64), 256, 0, st>>>(T, table, totals, long_tiles);
   GS_LAUNCH_CHECK();
-  GS_HIP(rocprim::exclusive_scan(temp, temp_bytes, totals, ranges, 0, (size_t)T + 1, rocprim::plus<int>(), st));
+  (void)temp; (void)temp_bytes;
+  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges);
+  GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
 
