@@ -471,7 +471,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
 
 // ranges[0..T] = exclusive scan of totals[0..T) (ranges[T] = S): one workgroup, T <= kBinMaxTiles.  Replaces a
 // three-kernel rocPRIM scan of a few thousand integers.
-__global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__restrict__ totals, int *__restrict__ ranges) {
+// It also publishes the forward's host record {M | S << 32, candidate pairs, ticket} (see publish_counts_kernel in
+// gs_fused.hip) when `pub` is given: S is known here first, and it saves a launch on the path to the host's wake-up.
+__global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__restrict__ totals, int *__restrict__ ranges,
+                                                          const int *__restrict__ m_total,
+                                                          const unsigned long long *__restrict__ pair_counters,
+                                                          volatile unsigned long long *pub, unsigned long long ticket) {
   __shared__ int s_part[1024];
   const int per = (T + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, T);
   int sum = 0;
@@ -484,6 +489,18 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
     s_part[threadIdx.x] += v;
     __syncthreads();
   }
+  if (pub && threadIdx.x < 64) {
+    unsigned long long v = pair_counters[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) {
+      pub[0] = ((unsigned long long)(unsigned int)s_part[1023] << 32) | (unsigned long long)(unsigned int)*m_total;
+      pub[1] = v;
+      __threadfence_system();
+      pub[2] = ticket;
+      __threadfence_system();
+    }
+  }
   int run = s_part[threadIdx.x] - sum;
   for (int t = lo; t < hi; ++t) { ranges[t] = run; run += totals[t]; }
   if (threadIdx.x == 1023) ranges[T] = s_part[1023];
@@ -495,14 +512,14 @@ size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_til
 
 // Phase 1 (needs nothing from the host): per-workgroup offsets and ranges from the histogram rows preprocess_kernel
 // left in `table` (kBinBlocks * T ints, followed by T + 1 totals).
-int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, void *temp, size_t temp_bytes,
+int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
+                    const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
                     hipStream_t st) {
   const int T = ntx * nty;
   int *totals = table + (size_t)kBinBlocks * T;
   bin_offsets_kernel<<<div_up(T, 64), 256, 0, st>>>(T, table, totals, long_tiles);
   GS_LAUNCH_CHECK();
-  (void)temp; (void)temp_bytes;
-  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges);
+  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, m_total, pair_counters, pub, ticket);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

@@ -28,7 +28,8 @@ int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_
 bool binning_supports_counting_sort(int num_tiles);
 bool binning_prefers_radix(size_t S, int num_tiles);
 size_t binning_table_bytes(int num_tiles);
-int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, void *temp, size_t temp_bytes,
+int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
+                    const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
                     hipStream_t st);
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
@@ -725,22 +726,22 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
 #undef GS_PRE
   GS_LAUNCH_CHECK();
   size_t inst_cap = 0;
+  // the one host read-back of the forward: M, S (and the candidate count)
+  const unsigned long long ticket = ++c->ticket;
   if (sparse) {
     c->mark(1, true, st);
     c->mark(2, false, st);
-    rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), c->temp.ptr, c->temp.bytes, st);
+    rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), c->rank.as<int>() + N,
+                             c->pair_counters(), c->d_pub, ticket, st);  // publishes the record too
     if (rc) return rc;
   } else {
     rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
     if (rc) return rc;
     c->mark(1, true, st);
+    publish_counts_kernel<<<1, 64, 0, st>>>(c->rank.as<int>() + N, c->offsets.as<int>() + N, c->pair_counters(), c->d_pub,
+                                           ticket);
+    GS_LAUNCH_CHECK();
   }
-  // the one host read-back of the forward: M, S (and the candidate count)
-  const unsigned long long ticket = ++c->ticket;
-  publish_counts_kernel<<<1, 64, 0, st>>>(c->rank.as<int>() + N,
-                                         sparse ? c->ranges.as<int>() + num_tiles : c->offsets.as<int>() + N,
-                                         c->pair_counters(), c->d_pub, ticket);
-  GS_LAUNCH_CHECK();
   if (!sparse) {
     // Emit does not need the totals on the host, only room for its writes: launch it bounded by the buffers'
     // capacity and sleep on the read-back while it runs (the reference blocks five times per forward, GPU idle).
