@@ -76,6 +76,60 @@ __device__ __forceinline__ float gauss_power(float a, float b, float c, float dx
   return __builtin_fmaf(-bx, dy, -0.5f * t);
 }
 
+// ---- staged (LDS) form of a record.  The compositing loops evaluate opa * exp(min(0, power)) as one base-2
+// exponential with the opacity folded into the exponent,
+//   log2(opa * exp(power)) = a2 dx^2 + b2 dx dy + c2 dy^2 + log2(opa),   (a2, b2, c2) = -log2(e) * (a/2, b, c/2),
+// which takes four VALU instructions fewer per (pixel, gaussian) than power -> * log2(e) -> exp -> * opa.
+// r0 = (u, v, a2, b2), r1 = (c2, log2 opa, opa, hy), r2 = (rgb, hit mask).  Both directions use the same form, so
+// the backward recomputes the forward's alpha bit for bit.
+constexpr float kLog2e = 1.44269504088896340736f;
+
+#ifndef GS_NATURAL_POWER
+#define GS_NATURAL_POWER 0
+#endif
+__device__ __forceinline__ void stage_record(SplatRec &s) {
+  const float opa = s.r1.y;
+#if GS_NATURAL_POWER
+  s.r1.z = opa;
+  return;
+#endif
+  s.r0.z *= -0.5f * kLog2e;
+  s.r0.w *= -kLog2e;
+  s.r1.x *= -0.5f * kLog2e;
+  s.r1.y = __log2f(opa);  // -inf for opacity 0: alpha 0
+  s.r1.z = opa;
+}
+
+// the all-zero sentinel record a list is padded with: alpha = 2^-inf = 0 at every pixel
+__device__ __forceinline__ float4 sentinel_r1() { return make_float4(0.0f, GS_NATURAL_POWER ? 0.0f : -INFINITY, 0.0f, 0.0f); }
+
+// log2 of the unclamped alpha; min(.., log2 opa) is the reference's min(0, power)
+__device__ __forceinline__ float log2_alpha(float a2, float b2, float c2, float lopa, float dx, float dy) {
+  float t = a2 * dx;
+  t = __builtin_fmaf(b2, dy, t);
+  float q = __builtin_fmaf(t, dx, lopa);
+  q = __builtin_fmaf(c2 * dy, dy, q);
+  float r;  // fminf() would first canonicalise the loaded lopa (one more VALU instruction per evaluation)
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(lopa));
+  return r;
+}
+
+// the conic entries back from their staged form (flush of the backward): a = a2 * kConicDiag, b = b2 * kConicOff
+#if GS_NATURAL_POWER
+constexpr float kConicDiag = 1.0f, kConicOff = 1.0f;
+#else
+constexpr float kConicDiag = -2.0f / kLog2e, kConicOff = -1.0f / kLog2e;
+#endif
+
+// opa * exp(min(0, power)) from a staged record
+__device__ __forceinline__ float staged_alpha(float a2, float b2, float c2, float lopa, float dx, float dy) {
+#if GS_NATURAL_POWER
+  return lopa * __expf(fminf(0.0f, gauss_power(a2, b2, c2, dx, dy)));
+#else
+  return __builtin_amdgcn_exp2f(log2_alpha(a2, b2, c2, lopa, dx, dy));
+#endif
+}
+
 // ---- DPP helpers
 template <int kCtrl>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -142,6 +196,84 @@ __device__ __host__ __forceinline__ int row_sum9_index(int lane) {
   return (lane & 2) ? 8 : 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
 }
 __device__ __host__ __forceinline__ bool row_sum9_active(int lane) { return !(lane & 2) || (lane & 15) == 2; }
+
+// ---- the backward's nine row sums, products included.  Every sum is (a per-pixel factor) x (a lane constant):
+//   rgb_c = sum aT * grad_c(pixel),   S_m = sum gp * m(cx, cy),  m in {1, cx, cy, cx^2, cx cy, cy^2},
+// with (cx, cy) the pixel's position relative to the TILE centre (the moments about the gaussian's own centre follow
+// per gaussian at flush time: dx = X - cx with X = u - tile centre).  So the first butterfly stage needs no separate
+// products: with the partner lane l ^ 7 (row_half_mirror, which also swaps the two banks of a pair) a register of the
+// stage is  F * W_own + dpp(F) * W_partner  = one v_mul + one v_fmac_dpp, W_* loop-invariant per lane.
+// Ten instructions instead of nine products + ten adds.  Later stages as in row_sum9.
+struct RowWeights {  // banks 0,2 (lane bit 2 clear) | banks 1,3
+  float a_own, a_par;  // grad0 | grad1          x aT
+  float b_own, b_par;  // grad2 | (unused)       x aT
+  float c_own, c_par;  // 1     | cx             x gp
+  float d_own, d_par;  // cy    | cx^2           x gp
+  float e_own, e_par;  // cx cy | cy^2           x gp
+};
+
+// lane = lane in the wave, (cx, cy) and grad[3] this lane's pixel; *_par are the same quantities of lane ^ 7
+__device__ __forceinline__ RowWeights make_row_weights(int lane, float cx, float cy, float g0, float g1, float g2) {
+  const bool odd = lane & 4;
+  auto partner = [](float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141 /* row_half_mirror */, 0xF, 0xF, false));
+  };
+  RowWeights w;
+  w.a_own = odd ? g1 : g0;  w.a_par = partner(odd ? g0 : g1);  // the partner sits in the other kind of bank
+  w.b_own = g2;             w.b_par = partner(g2);
+  w.c_own = odd ? cx : 1.0f;       w.c_par = partner(odd ? 1.0f : cx);
+  w.d_own = odd ? cx * cx : cy;    w.d_par = partner(odd ? cy : cx * cx);
+  w.e_own = odd ? cy * cy : cx * cy;  w.e_par = partner(odd ? cx * cy : cy * cy);
+  return w;
+}
+
+__device__ __forceinline__ float row_moments9(float aT, float gp, const RowWeights &w) {
+  float r0, r1, r2, r3, r4;  // few temporaries on purpose: the backward sits at a VGPR-occupancy step
+  const unsigned long long odd = 0xAAAAAAAAAAAAAAAAull, bit1 = 0xCCCCCCCCCCCCCCCCull;
+  asm volatile(
+      // stage A (lane bit 2, partner l ^ 7): the five plain products first, they double as the wait states between
+      // the instruction that wrote gp and its first DPP read
+      "v_mul_f32 %[r0], %[aT], %[a_own]\n\t"
+      "v_mul_f32 %[r1], %[aT], %[b_own]\n\t"
+      "v_mul_f32 %[r2], %[gp], %[c_own]\n\t"
+      "v_mul_f32 %[r3], %[gp], %[d_own]\n\t"
+      "v_mul_f32 %[r4], %[gp], %[e_own]\n\t"
+      "v_fmac_f32_dpp %[r0], %[aT], %[a_par] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[r1], %[aT], %[b_par] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[r2], %[gp], %[c_par] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[r3], %[gp], %[d_par] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[r4], %[gp], %[e_par] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      // stage B: lanes 8 apart (lane bit 3), in place: banks 0,1 keep the even register, banks 2,3 take the odd one
+      // (row_shl:8 with bound_ctrl:0 adds 0 in banks 2,3); the (cx cy | cy^2) register pairs with itself: one rotate
+      "v_add_f32_dpp %[r0], %[r0], %[r0] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r0], %[r1], %[r1] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r2], %[r2], %[r2] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r2], %[r3], %[r3] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[r4], %[r4], %[r4] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      // stage C: lane bit 0: even lanes keep r0, odd lanes r2; r4 is summed in place
+      "v_cndmask_b32_e64 %[r1], %[r2], %[r0], %[odd]\n\t"
+      "v_cndmask_b32_e64 %[r3], %[r0], %[r2], %[odd]\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %[r4], %[r4], %[r4] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %[r1], %[r1], %[r3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      // stage D: lane bit 1: lanes with the bit clear keep r1 (values 0..7), the others the r4 pair
+      "v_cndmask_b32_e64 %[r0], %[r4], %[r1], %[bit1]\n\t"
+      "v_cndmask_b32_e64 %[r2], %[r1], %[r4], %[bit1]\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %[r0], %[r0], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4)
+      : [aT] "v"(aT), [gp] "v"(gp), [a_own] "v"(w.a_own), [a_par] "v"(w.a_par), [b_own] "v"(w.b_own),
+        [b_par] "v"(w.b_par), [c_own] "v"(w.c_own), [c_par] "v"(w.c_par), [d_own] "v"(w.d_own), [d_par] "v"(w.d_par),
+        [e_own] "v"(w.e_own), [e_par] "v"(w.e_par), [odd] "s"(odd), [bit1] "s"(bit1));
+  return r0;
+}
+// which of the nine sums a lane of `out` holds: 0..2 rgb, 3 S_1, 4 S_cx, 5 S_cy, 6 S_cx2, 7 S_cxcy, 8 S_cy2; -1: none
+__device__ __host__ __forceinline__ int row_moments9_index(int lane) {
+  const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+  if (b1) return (b0 == 0 && b3 == 0) ? 7 + b2 : -1;  // the (cx cy | cy^2) register: lanes 2 and 6 of the row
+  const int a = 4 * b0 + 2 * b3 + b2;                  // A0..A7 = rgb0 rgb1 rgb2 (dup) S_1 S_cx S_cy S_cx2
+  return a < 3 ? a : (a == 3 ? -1 : a - 1);
+}
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
 // neighbouring tiles (which share gaussians) hit the same L2.  Returns >= num_tiles for the

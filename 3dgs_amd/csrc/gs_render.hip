@@ -27,6 +27,9 @@
 
 #include <cstdlib>
 
+#ifndef GS_PIPE
+#define GS_PIPE 0
+#endif
 #ifndef GS_ABLATE
 #define GS_ABLATE 0
 #endif
@@ -124,7 +127,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
-  if (tid == 0) s_r0[kBatch] = s_r1[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (tid == 0) {
+    s_r0[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s_r1[kBatch] = sentinel_r1();
+  }
   const int tile_x = tile % ntx, tile_y = tile / ntx;
   const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
   const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
       const int g = sorted[start + base + tid];
       SplatRec s = load_record<kPacked>(g, recs, raw);
       s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
+      stage_record(s);
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
     }
     __syncthreads();
@@ -173,10 +180,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
         const float4 a1 = *reinterpret_cast<const float4 *>(r0b + off1), c1 = *reinterpret_cast<const float4 *>(r2b + off1);
         const float2 b1 = *reinterpret_cast<const float2 *>(r1b + off1);
         asm volatile("" ::"v"(c0.w), "v"(c1.w));  // keep 16-byte reads (ds_read_b96 costs twice the LDS cycles)
-        const float p0 = fminf(0.0f, gauss_power(a0.z, a0.w, b0.x, a0.x - fpx, a0.y - fpy));
-        const float p1 = fminf(0.0f, gauss_power(a1.z, a1.w, b1.x, a1.x - fpx, a1.y - fpy));
-        float al0 = fminf(kAlphaMax, b0.y * __expf(p0));
-        float al1 = fminf(kAlphaMax, b1.y * __expf(p1));
+        float al0 = fminf(kAlphaMax, staged_alpha(a0.z, a0.w, b0.x, b0.y, a0.x - fpx, a0.y - fpy));
+        float al1 = fminf(kAlphaMax, staged_alpha(a1.z, a1.w, b1.x, b1.y, a1.x - fpx, a1.y - fpy));
         al0 = al0 > kAlphaMin ? al0 : 0.0f;
         al1 = al1 > kAlphaMin ? al1 : 0.0f;
         // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T * (1 - alpha) < 1e-4" alone
@@ -229,7 +234,7 @@ __device__ __forceinline__ int row_max_int(int v) {  // max over the 16 lanes of
 }
 
 template <bool kPacked, bool kRows, int kB>
-__global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
                                                               const int *__restrict__ sorted,
                                                               const int *__restrict__ ranges,
                                                               const int *__restrict__ n_px,
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
   constexpr int kAcc = 10;  // doubles per slot (nine used): 80 bytes = 5 x the list entry's byte offset
   __shared__ double s_acc[kB * kAcc];
   __shared__ int s_id[kB];
+  __shared__ float s_res[kB * 9];  // the batch's nine gradient values per gaussian, between the two flush steps
   __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kB];
   __shared__ int s_top;
   const int tile = block_to_tile(blockIdx.x, num_tiles);
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
   const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
   const char *r2b = reinterpret_cast<const char *>(s_r2);
   char *accb = reinterpret_cast<char *>(s_acc);
+  [[maybe_unused]] const unsigned int list_lds = (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)my_list;
 
   int n = 0;
   float Tf = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
@@ -270,7 +277,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
     Tf = T_px[pid];
     g0 = grad_image[3 * pid]; g1 = grad_image[3 * pid + 1]; g2 = grad_image[3 * pid + 2];
   }
-  float T = Tf, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;  // running transmittance, colour behind the current splat
+  typedef float v2f __attribute__((ext_vector_type(2)));  // (c0, c1) as a register pair: one packed add / fma
+  float T = Tf, c2 = 0.0f;  // running transmittance, colour behind the current splat
+  v2f c01 = {0.0f, 0.0f};
   const float tfb = Tf * (bg * g0 + bg * g1 + bg * g2);  // T_final * (background . grad)
   const int row_top_v = row_max_int(n);
   const int rt0 = __builtin_amdgcn_readlane(row_top_v, 0), rt1 = __builtin_amdgcn_readlane(row_top_v, 16);
@@ -278,16 +287,20 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
   const int wave_top = max(max(rt0, rt1), max(rt2, rt3));
   if (tid == 0) {
     s_top = 0;
-    s_r0[kB] = s_r1[kB] = s_r2[kB] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s_r0[kB] = s_r2[kB] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s_r1[kB] = sentinel_r1();
   }
   __syncthreads();
   if (lane == 0) atomicMax(&s_top, wave_top);
   __syncthreads();
   const int top = s_top;  // cuda/render_backward.cu:64,74: start at (max n over the tile) - 1
   if (top <= 0) return;
-  // where this lane's share of the nine row totals goes (see row_sum9)
-  const bool red_lane = row_sum9_active(lane);
-  const int red_idx = row_sum9_index(lane);
+  // where this lane's share of the nine row totals goes (see row_moments9), and the lane constants of the sums:
+  // pixel position relative to the tile centre, pixel gradient
+  const int red_idx = row_moments9_index(lane);
+  const bool red_lane = red_idx >= 0;
+  const RowWeights rw = make_row_weights(lane, (float)((wave & 1) * 8 + (row & 1) * 4 + (j & 3)) - 7.5f,
+                                         (float)((wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2)) - 7.5f, g0, g1, g2);
 
   for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
     const int count = min(kB, top - base);
@@ -295,7 +308,14 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
     if (tid < count) {  // count <= kB
       const int g = sorted[start + base + tid];
       SplatRec s = load_record<kPacked>(g, recs, raw);
+#if GS_ABLATE == 9
+      if constexpr (kPacked) {  // one more dependent global round trip: sensitivity to the staging latency
+        const float4 extra = recs[3 * (g ^ (int)(s.r0.x == 12345.678f)) + 1];
+        if (extra.x == 98765.4f) s.r0.x += 1.0f;
+      }
+#endif
       s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
+      stage_record(s);
       s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
       s_id[tid] = g;
     }
@@ -305,39 +325,70 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
       const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, wave, lane, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
       const int n_rel = (n - base) * 16;  // "base + slot < n" on byte offsets
+#if GS_PIPE
+      // Software pipeline: the list entry two trips ahead and the record of the next trip are fetched while the
+      // current trip computes -- a trip otherwise serialises two LDS round trips before its first multiply.
+      int off = trips > 0 ? my_list[trips - 1] : 0;
+      int off_next = my_list[max(trips - 2, 0)];
+      float4 a = *reinterpret_cast<const float4 *>(r0b + off);
+      float2 b = *reinterpret_cast<const float2 *>(r1b + off);
       for (int i = trips - 1; i >= 0; --i) {
-        const int off = my_list[i];
-        const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
-        const float4 c = *reinterpret_cast<const float4 *>(r2b + off);
+        const int off_cur = off;
+        const float4 a_next = *reinterpret_cast<const float4 *>(r0b + off_next);
+        const float2 b_next = *reinterpret_cast<const float2 *>(r1b + off_next);
+        const int off_nn = my_list[max(i - 2, 0)];
+        __builtin_amdgcn_sched_barrier(0);  // keep the three fetches ahead of this trip's arithmetic
         const float dx = a.x - fpx, dy = a.y - fpy;
-        const float power = fminf(0.0f, gauss_power(a.z, a.w, b.x, dx, dy));
-        float gg = __expf(power);
-        const float opa = b.y;
-        float alpha = fminf(kAlphaMax, opa * gg);
+        float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);
+        a = a_next; b = b_next; off = off_next; off_next = off_nn;
+        float alpha = fminf(kAlphaMax, og);
+        const bool valid = (alpha >= kAlphaMin) && (off_cur < n_rel);
+        if (__ballot(valid) == 0ull) continue;
+        const float4 c = *reinterpret_cast<const float4 *>(r2b + off_cur);
+#define off off_cur
+#else
+      for (int i = trips - 1; i >= 0; --i) {
+        // ds_read_u16 zero-extends; read through asm, the compiler would add an "and 0xffff" to every trip
+        int off;
+        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(list_lds + 2 * i) : "memory");
+        const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
+#if GS_ABLATE == 4
+        const float4 c = make_float4(0.5f, 0.25f, 0.125f, 0.0f);
+#else
+        const float4 c = *reinterpret_cast<const float4 *>(r2b + off);
+#endif
+        const float dx = a.x - fpx, dy = a.y - fpy;
+        // opa * exp(power): d alpha / d gg . gg (the reference differentiates through the 0.99 cap as if absent)
+        float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);
+        float alpha = fminf(kAlphaMax, og);
         // a row past the end of its list reads the sentinel record (alpha 0).  n is 0 for pixels outside the image,
         // so "inside" needs no separate test.
         const bool valid = (alpha >= kAlphaMin) && (off < n_rel);
         if (__ballot(valid) == 0ull) continue;
+#endif
+#if GS_ABLATE == 8
+        asm volatile("" ::"v"(og));
+        continue;
+#endif
         alpha = valid ? alpha : 0.0f;
-        gg = valid ? gg : 0.0f;
+        og = valid ? og : 0.0f;
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T *= inv;                                           // transmittance in front of this splat
         const float aT = alpha * T;
-        const float v0 = aT * g0, v1 = aT * g1, v2 = aT * g2;  // d/d rgb
-        const float d0 = c.x - c0, d1 = c.y - c1, d2 = c.z - c2;
-        float ga = __builtin_fmaf(d0, g0, __builtin_fmaf(d1, g1, d2 * g2));
+        const v2f d01 = v2f{c.x, c.y} - c01;
+        const float d2 = c.z - c2;
+        float ga = __builtin_fmaf(d01.x, g0, __builtin_fmaf(d01.y, g1, d2 * g2));
         ga = __builtin_fmaf(ga, T, -(tfb * inv));           // d/d alpha (cuda/render_backward.cu:139-151)
-        c0 = __builtin_fmaf(alpha, d0, c0);                 // colour behind the next (nearer) splat
-        c1 = __builtin_fmaf(alpha, d1, c1);
+        c01 = __builtin_elementwise_fma(v2f{alpha, alpha}, d01, c01);  // colour behind the next (nearer) splat
         c2 = __builtin_fmaf(alpha, d2, c2);
-        const float gp = gg * (ga * opa);                   // d/d power
-        const float gpx = gp * dx, gpy = gp * dy;
-        // nine raw sums; signs, the -1/2 factors, (1 - opa) and the 0.5*W / 0.5*H are applied once per gaussian
-        // at flush time:  S0 = sum gp, Sx, Sy, Sxx, Sxy, Syy
+        const float gp = og * ga;                           // d/d power
+        // nine raw sums: aT x pixel gradient (d/d rgb) and the six moments of gp about the tile centre; signs, the
+        // -1/2 factors, (1 - opa), the shift to the gaussian's centre and 0.5*W / 0.5*H are applied once per gaussian
+        // at flush time
 #if GS_ABLATE == 2
-        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(gp), "v"(gpx), "v"(gpy), "v"(gpx * dx), "v"(gpx * dy), "v"(gpy * dy));
+        asm volatile("" ::"v"(aT), "v"(gp));
 #else
-        const float red = row_sum9(v0, v1, v2, gp, gpx, gpy, gpx * dx, gpx * dy, gpy * dy);
+        const float red = row_moments9(aT, gp, rw);
         // all-zero sums (rows past their list, blocks without a valid pixel) add nothing: skip their atomics
 #if GS_ABLATE == 1
         asm volatile("" ::"v"(red));
@@ -345,38 +396,50 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4 *__restric
         if (red_lane && red != 0.0f) atomicAdd(reinterpret_cast<double *>(accb + off * 5 + red_idx * 8), (double)red);
 #endif
 #endif
+#if GS_PIPE
+#undef off
+#endif
       }
     }
     __syncthreads();
-    // flush: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows.
+    // flush, step 1: one thread per gaussian turns its nine raw sums into the nine gradient values (uniform control
+    // flow, the double arithmetic once per gaussian instead of once per lane of a 16-lane group)
+    if (tid < count) {
+      const double *acc = &s_acc[tid * kAcc];  // rgb3, S_1, S_cx, S_cy, S_cx2, S_cxcy, S_cy2
+      const float4 a = s_r0[tid], b = s_r1[tid];  // staged conic: see stage_record
+      const float opa = b.z;
+      // moments of gp about the gaussian's centre from those about the tile centre: d = (X, Y) - (cx, cy)
+      const double X = (double)a.x - ((double)tx0 + 7.5), Y = (double)a.y - ((double)ty0 + 7.5);
+      const double S1 = acc[3], Sx = acc[4], Sy = acc[5];
+      const float sx = (float)(X * S1 - Sx), sy = (float)(Y * S1 - Sy);              // sum gp dx, sum gp dy
+      const float sxx = (float)(X * (X * S1 - 2.0 * Sx) + acc[6]);                   // sum gp dx^2
+      const float sxy = (float)(X * (Y * S1 - Sy) - Y * Sx + acc[7]);                // sum gp dx dy
+      const float syy = (float)(Y * (Y * S1 - 2.0 * Sy) + acc[8]);                   // sum gp dy^2
+      const float ca = a.z * kConicDiag, cb = a.w * kConicOff, cc = b.x * kConicDiag;
+      // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
+      // gaussian (sigmoid(opacity) == 1) gets no gradient at all
+      const float keep = opa == 1.0f ? 0.0f : 1.0f;
+      float *res = &s_res[tid * 9];
+      res[0] = keep * (float)acc[0];
+      res[1] = keep * (float)acc[1];
+      res[2] = keep * (float)acc[2];
+      res[3] = keep * ((float)S1 * (1.0f - opa));                                    // d/d logit (render_backward.cu:154)
+      res[4] = keep * (-0.5f * sxx);                                                 // conic00
+      res[5] = keep * -sxy;                                                          // conic01
+      res[6] = keep * (-0.5f * syy);                                                 // conic11
+      res[7] = keep * (-(ca * sx + cb * sy) * (0.5f * (float)width));                // u (render_backward.cu:180-186)
+      res[8] = keep * (-(cc * sy + cb * sx) * (0.5f * (float)height));               // v (:181-187)
+    }
+    __syncthreads();
+    // step 2: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows
     const int k = tid & 15;
     if (k < 9) {
 #pragma unroll 4
       for (int r = 0; r < kB / 16; ++r) {
         const int slot = r * 16 + (tid >> 4);
         if (slot >= count) continue;
-        // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
-        // gaussian (sigmoid(opacity) == 1) gets no gradient at all
-        if (s_r1[slot].y == 1.0f) continue;
-        const double *acc = &s_acc[slot * kAcc];
-        float val;
-        if (k < 3) {
-          val = (float)acc[k];
-        } else if (k == 3) {
-          val = (float)acc[3] * (1.0f - s_r1[slot].y);        // d/d logit (render_backward.cu:154)
-        } else if (k == 4) {
-          val = -0.5f * (float)acc[6];                        // conic00
-        } else if (k == 5) {
-          val = -(float)acc[7];                               // conic01
-        } else if (k == 6) {
-          val = -0.5f * (float)acc[8];                        // conic11
-        } else {
-          const float sx = (float)acc[4], sy = (float)acc[5];
-          const float4 a = s_r0[slot];
-          val = (k == 7) ? -(a.z * sx + a.w * sy) * (0.5f * (float)width)       // u (render_backward.cu:180-186)
-                         : -(s_r1[slot].x * sy + a.w * sx) * (0.5f * (float)height);  // v (:181-187)
-        }
-        if (val == 0.0f) continue;
+        const float val = s_res[slot * 9 + k];
+        if (!(val != 0.0f)) continue;  // zero (nothing to add) -- NaN still goes out
 #if GS_ABLATE == 3
         asm volatile("" ::"v"(val));
         continue;

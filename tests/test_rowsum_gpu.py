@@ -1,4 +1,5 @@
-"""The row-level nine-value reduction of the backward (gs::row_sum9, masked DPP adds in inline assembly) checked
+"""The row-level nine-value reductions of the backward (gs::row_sum9 and gs::row_moments9, masked DPP in inline
+assembly) checked
 lane by lane on the GPU: tools/dpp_rowsum_test.hip compares every row total with a host sum."""
 import os
 import subprocess
@@ -25,4 +26,5 @@ def test_rowsum_program_builds():
 @pytest.mark.gpu
 def test_row_sum9_on_gpu():
     out = subprocess.run([_build()], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0 and "row_sum9: ok" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 0 and "row_sum9: ok" in out.stdout and "row_moments9: ok" in out.stdout, \
+        out.stdout + out.stderr

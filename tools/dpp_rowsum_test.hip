@@ -11,6 +11,42 @@ __global__ void k(const float *in, float *out) {
   out[lane] = gs::row_sum9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
 }
 
+// row_moments9: aT and gp per lane, weights = arbitrary lane "constants"; every active lane against a host sum
+__global__ void km(const float *in, float *out) {
+  const int lane = threadIdx.x;
+  const float aT = in[lane], gp = in[64 + lane], cx = in[128 + lane], cy = in[192 + lane];
+  const float g0 = in[256 + lane], g1 = in[320 + lane], g2 = in[384 + lane];
+  const gs::RowWeights w = gs::make_row_weights(lane, cx, cy, g0, g1, g2);
+  out[lane] = gs::row_moments9(aT, gp, w);
+}
+
+static int test_moments(const float *h, float *d_in, float *d_out) {
+  float o[64];
+  km<<<1, 64>>>(d_in, d_out);
+  hipMemcpy(o, d_out, sizeof(o), hipMemcpyDeviceToHost);
+  int bad = 0, active = 0;
+  for (int lane = 0; lane < 64; ++lane) {
+    const int row = lane >> 4, idx = gs::row_moments9_index(lane);
+    if (idx < 0) continue;
+    ++active;
+    double ref = 0.0;
+    for (int j = 0; j < 16; ++j) {
+      const int l = row * 16 + j;
+      const double aT = h[l], gp = h[64 + l], cx = h[128 + l], cy = h[192 + l];
+      const double term[9] = {aT * h[256 + l], aT * h[320 + l], aT * h[384 + l], gp, gp * cx, gp * cy, gp * cx * cx,
+                              gp * cx * cy, gp * cy * cy};
+      ref += term[idx];
+    }
+    if (std::fabs(ref - o[lane]) > 1e-3 * (1.0 + std::fabs(ref))) {
+      std::printf("moments lane %d idx %d got %g want %g\n", lane, idx, o[lane], ref);
+      ++bad;
+    }
+  }
+  if (active != 36) { std::printf("row_moments9: %d active lanes, want 36\n", active); ++bad; }
+  std::printf(bad ? "row_moments9: %d mismatches\n" : "row_moments9: ok\n", bad);
+  return bad;
+}
+
 int main() {
   float h[9 * 64], *d_in, *d_out, o[64];
   for (int i = 0; i < 9 * 64; ++i) h[i] = (float)((i * 37) % 101) * 0.25f - 7.0f;
@@ -29,5 +65,6 @@ int main() {
     }
   }
   std::printf(bad ? "row_sum9: %d mismatches\n" : "row_sum9: ok\n", bad);
+  bad += test_moments(h, d_in, d_out);
   return bad != 0;
 }
