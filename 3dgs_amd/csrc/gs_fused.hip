@@ -125,6 +125,40 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// ---- staging of array-of-rows data through LDS.  A lane reading ITS row of kRest floats (180 B at SH degree 3)
+// touches 64 different cache lines per wave instruction and runs at the cache's tag rate, not at HBM rate; the
+// wave's 64 rows as one linear span touch 8 lines per instruction.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at 4-byte alignment
+
+// A wave's `rows` (<= 64) consecutive rows of kRest floats between global memory and its LDS staging area, as one
+// linear span of 16-byte accesses.  A full wave issues all its loads before the first LDS store (11.25 per lane at
+// degree 3), so the whole 11.5 KB is in flight at once.
+template <int kRest>
+__device__ __forceinline__ void rows_to_lds(const float *__restrict__ src, float *wsh, int rows, int lane) {
+  constexpr int kVec = 16 * kRest, kFull = kVec / 64, kTail = kVec % 64;  // float4s of a full wave's span
+  if (rows == 64) {
+    float4 v[kFull + 1];
+#pragma unroll
+    for (int t = 0; t < kFull; ++t) v[t] = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src + 4 * (lane + 64 * t)));
+    if (kTail > 0 && lane < kTail) v[kFull] = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src + 4 * (lane + 64 * kFull)));
+#pragma unroll
+    for (int t = 0; t < kFull; ++t) *reinterpret_cast<float4 *>(wsh + 4 * (lane + 64 * t)) = v[t];
+    if (kTail > 0 && lane < kTail) *reinterpret_cast<float4 *>(wsh + 4 * (lane + 64 * kFull)) = v[kFull];
+  } else {
+    const int total = rows * kRest;
+    for (int e = lane * 4; e + 3 < total; e += 256)
+      *reinterpret_cast<float4 *>(wsh + e) = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src + e));
+    for (int e = (total & ~3) + lane; e < total; e += 64) wsh[e] = src[e];
+  }
+}
+template <int kRest>
+__device__ __forceinline__ void rows_from_lds(float *__restrict__ dst, const float *wsh, int rows, int lane) {
+  const int total = rows * kRest;
+  for (int e = lane * 4; e + 3 < total; e += 256)
+    *reinterpret_cast<f4u *>(dst + e) = __builtin_bit_cast(f4u, *reinterpret_cast<const float4 *>(wsh + e));
+  for (int e = (total & ~3) + lane; e < total; e += 64) dst[e] = wsh[e];
+}
+
 // ---- A: world -> camera -> pixel -> keep-mask, for all N
 __global__ __launch_bounds__(kBlock) void project_cull_kernel(const float *__restrict__ xyz,
                                                               const float *__restrict__ view,
@@ -283,25 +317,55 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
                                                                 const float *__restrict__ sigma,
                                                                 const float *__restrict__ Jm,
                                                                 const float *__restrict__ conic,
-                                                                const float4 *__restrict__ rows, float fx, float fy,
+                                                                const float4 *__restrict__ rows_in, float fx, float fy,
                                                                 float tan_fovx, float tan_fovy, float cx, float cy,
                                                                 float cz, int width, int height, BwdOut o) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= M) return;
-  constexpr int n = (L + 1) * (L + 1);
-  const int i = c2g[j];
+  constexpr int n = (L + 1) * (L + 1), kRest = (n - 1) * 3;
+  // The SH rows (kRest floats per gaussian, 180 B at degree 3) go through LDS: a lane reading ITS row touches 64
+  // different cache lines per wave instruction; the wave's 64 rows as one linear span touch 8.  Same for the
+  // gradient rows on the way out.  Each wave stages only its own rows (no workgroup barrier).
+  __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 ? kBlock * kRest : 4];
+  const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
+  const int jw = blockIdx.x * kBlock + wave_first;  // first compacted slot of this wave
+  if (jw >= M) return;
+  const int rows = min(64, M - jw);
+  const bool live = j < M;
+  const int i = c2g[live ? j : jw];
+  float *wsh = s_sh + wave_first * kRest;
+  if constexpr (kRest > 0) {
+    const int i0 = __builtin_amdgcn_readfirstlane(i);
+    if (__all(!live || i == i0 + lane)) {  // consecutive gaussians (no culling in between): one linear span
+      rows_to_lds<kRest>(g.sh + (size_t)i0 * kRest, wsh, rows, lane);
+    } else {
+      for (int r = 0; r < rows; ++r) {
+        const int ir = __shfl(i, r, 64);
+        if (lane < kRest) wsh[r * kRest + lane] = g.sh[(size_t)ir * kRest + lane];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f, b0g[3] = {0.0f, 0.0f, 0.0f};
   const gs::Mat34 vw = gs::load_view(view);
   const gs::Mat44 pr = gs::load_proj(proj);
-  const float4 a = rows[4 * j], b = rows[4 * j + 1], c = rows[4 * j + 2];
+  const int jr = live ? j : jw;  // dead lanes of the last wave recompute row jw and store nothing
+  const float4 a = rows_in[4 * jr], b = rows_in[4 * jr + 1], c = rows_in[4 * jr + 2];
   const float g_rgb[3] = {a.x, a.y, a.z};
   const float g_op = a.w;
   const float g_con[3] = {b.x, b.y, b.z};
   const float g_u = b.w, g_v = c.x;
-  // SH chain: sh_grad (=), band0_grad (=), xyz_grad starts with the view-direction term
-  float gx, gy, gz, b0g[3];
-  float *shg = o.sh + (size_t)j * (n - 1) * 3;
-  gs::sh_bwd<L>(g.sh + (size_t)i * (n - 1) * 3, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy,
-                cz, g_rgb, shg, b0g, gx, gy, gz);
+  {
+    float *row = wsh + lane * kRest;  // read as coefficients, overwritten with their gradients
+    gs::sh_bwd<L>(row, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, g_rgb, row, b0g, gx,
+                  gy, gz);
+  }
+  if constexpr (kRest > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
+  }
+  if (!live) return;
   gx = 0.0f + gx; gy = 0.0f + gy; gz = 0.0f + gz;
   // conic -> (J, Sigma)
   float Jv[6], sg[6], con[3], dJ[6], dS[6];

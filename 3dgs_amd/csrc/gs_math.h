@@ -487,9 +487,10 @@ __device__ __forceinline__ void sigma_bwd(const RotScale &rs, const float *g /*6
 // ---- S2 (reference: compute_sh_gradients_kernel, cuda/spherical_harmonics_backward.cu:28-166)
 // Writes sh_grad (n-1)*3 and band0_grad 3 (overwrite), returns the xyz increment.
 template <int L>
-__device__ __forceinline__ void sh_bwd(const float *__restrict__ sh, const float *__restrict__ band0, float px,
+// sh_grad may be the same row as sh (coefficient k is read before its gradient is written).
+__device__ __forceinline__ void sh_bwd(const float *sh, const float *__restrict__ band0, float px,
                                        float py, float pz, float cx, float cy, float cz, const float *gr,
-                                       float *__restrict__ sh_grad, float *__restrict__ band0_grad, float &ox,
+                                       float *sh_grad, float *__restrict__ band0_grad, float &ox,
                                        float &oy, float &oz) {
   constexpr int n = (L + 1) * (L + 1);
   float ux, uy, uz, len;
@@ -509,9 +510,9 @@ __device__ __forceinline__ void sh_bwd(const float *__restrict__ sh, const float
 #pragma unroll
   for (int k = 0; k < n - 1; ++k) {
     const float yv = Y[k + 1];
+    const float Ri = sh[3 * k], Gi = sh[3 * k + 1], Bi = sh[3 * k + 2];
     sh_grad[3 * k] = gr[0] * yv; sh_grad[3 * k + 1] = gr[1] * yv; sh_grad[3 * k + 2] = gr[2] * yv;
     const float ddx = dY[k + 1][0], ddy = dY[k + 1][1], ddz = dY[k + 1][2];
-    const float Ri = sh[3 * k], Gi = sh[3 * k + 1], Bi = sh[3 * k + 2];
     dRx += ddx * Ri; dGx += ddx * Gi; dBx += ddx * Bi;
     dRy += ddy * Ri; dGy += ddy * Gi; dBy += ddy * Bi;
     dRz += ddz * Ri; dGz += ddz * Gi; dBz += ddz * Bi;
