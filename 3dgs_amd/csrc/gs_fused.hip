@@ -513,21 +513,23 @@ __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char 
                                                             const int *__restrict__ rank_of, int N,
                                                             gsplat_gradients gr, float *__restrict__ common,
                                                             float *__restrict__ rgb) {
-  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= (long long)N * 15) return;
-  const int i = (int)(e / 15), k = (int)(e % 15);
-  float val = 0.0f;
+  const int i = blockIdx.x * kBlock + threadIdx.x;  // one gaussian per thread: three 16-byte stores per row
+  if (i >= N) return;
+  f4u r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = r0, r2 = r0;
+  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   if (mask[i]) {
     const size_t j = (size_t)rank_of[i];
-    if (k < 3) val = gr.grad_xyz[3 * j + k];
-    else if (k == 3) val = gr.grad_opacity[j];
-    else if (k < 7) val = gr.grad_scale[3 * j + (k - 4)];
-    else if (k < 11) val = gr.grad_quaternion[4 * j + (k - 7)];
-    else if (k == 11) val = 1.0f;
-    else if (rgb) val = gr.grad_precompute_rgb[3 * j + (k - 12)];
+    const float *gq = gr.grad_quaternion + 4 * j;
+    r0 = f4u{gr.grad_xyz[3 * j], gr.grad_xyz[3 * j + 1], gr.grad_xyz[3 * j + 2], gr.grad_opacity[j]};
+    r1 = f4u{gr.grad_scale[3 * j], gr.grad_scale[3 * j + 1], gr.grad_scale[3 * j + 2], gq[0]};
+    r2 = f4u{gq[1], gq[2], gq[3], 1.0f};
+    if (rgb) {
+      c0 = gr.grad_precompute_rgb[3 * j]; c1 = gr.grad_precompute_rgb[3 * j + 1]; c2 = gr.grad_precompute_rgb[3 * j + 2];
+    }
   }
-  if (k < 12) common[(size_t)i * 12 + k] = val;
-  else if (rgb) rgb[(size_t)i * 3 + (k - 12)] = val;
+  f4u *row = reinterpret_cast<f4u *>(common + (size_t)i * 12);
+  row[0] = r0; row[1] = r1; row[2] = r2;
+  if (rgb) { rgb[(size_t)i * 3] = c0; rgb[(size_t)i * 3 + 1] = c1; rgb[(size_t)i * 3 + 2] = c2; }
 }
 
 // rgb_all: world blocks of `stride` floats; block r = [N,3] g_rgb of rank r followed by that rank's campos[3].
@@ -539,36 +541,67 @@ __global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__res
                                                               const float *__restrict__ rgb_all, size_t stride,
                                                               float *__restrict__ full) {
   constexpr int n = (L + 1) * (L + 1);
+  constexpr int wo = 12 + 3 * n;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  const int wo = 12 + 3 * n;
-  float *out = full + (size_t)i * wo;
-  if constexpr (kSh) {
-    float acc[n][3];
-#pragma unroll
-    for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
-    const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
-    for (int r = 0; r < world; ++r) {
-      const float *blk = rgb_all + (size_t)r * stride;
-      const float g0 = blk[3 * (size_t)i], g1 = blk[3 * (size_t)i + 1], g2 = blk[3 * (size_t)i + 2];
-      if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
-      const float *cp = blk + 3 * (size_t)N;
-      float dx, dy, dz, len, Y[n];
-      gs::view_dir(px, py, pz, cp[0], cp[1], cp[2], dx, dy, dz, len);
-      gs::sh_basis<L>(dx, dy, dz, Y);
-#pragma unroll
-      for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
-    }
-#pragma unroll
-    for (int k = 0; k < n; ++k) { out[3 + 3 * k] = acc[k][0]; out[4 + 3 * k] = acc[k][1]; out[5 + 3 * k] = acc[k][2]; }
-  }
-  if constexpr (kCommon) {
+  if constexpr (!kSh) {  // the twelve all-reduced columns only: two short pieces per row
+    if (i >= N) return;
+    float *out = full + (size_t)i * wo;
     const float *row = common + (size_t)i * 12;
     out[0] = row[0]; out[1] = row[1]; out[2] = row[2];                          // xyz
     out[3 + 3 * n] = row[3];                                                    // opacity
     out[4 + 3 * n] = row[4]; out[5 + 3 * n] = row[5]; out[6 + 3 * n] = row[6];  // scale
     out[7 + 3 * n] = row[7]; out[8 + 3 * n] = row[8]; out[9 + 3 * n] = row[9]; out[10 + 3 * n] = row[10];  // quaternion
     out[11 + 3 * n] = row[11];                                                  // visibility count
+  } else {
+    // The rebuilt rows leave through LDS, one row per wave instruction (a lane storing ITS 240-byte row touches 64
+    // cache lines per instruction).  kCols floats of every row are written, starting at column kFirst.
+    constexpr int kCols = kCommon ? wo : 3 * n, kFirst = kCommon ? 0 : 3, kPitch = kCols | 1;  // odd pitch: no bank conflicts
+    __shared__ float s_rows[kBlock * kPitch];
+    const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
+    const int iw = blockIdx.x * kBlock + wave_first;
+    if (iw >= N) return;
+    float *mine = s_rows + (wave_first + lane) * kPitch;
+    if (i < N) {
+      float acc[n][3];
+#pragma unroll
+      for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+      const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+      for (int r = 0; r < world; ++r) {
+        const float *blk = rgb_all + (size_t)r * stride;
+        const float g0 = blk[3 * (size_t)i], g1 = blk[3 * (size_t)i + 1], g2 = blk[3 * (size_t)i + 2];
+        if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+        const float *cp = blk + 3 * (size_t)N;
+        float dx, dy, dz, len, Y[n];
+        gs::view_dir(px, py, pz, cp[0], cp[1], cp[2], dx, dy, dz, len);
+        gs::sh_basis<L>(dx, dy, dz, Y);
+#pragma unroll
+        for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
+      }
+      constexpr int o = 3 - kFirst;  // where the SH block starts inside the staged row
+#pragma unroll
+      for (int k = 0; k < n; ++k) { mine[o + 3 * k] = acc[k][0]; mine[o + 3 * k + 1] = acc[k][1]; mine[o + 3 * k + 2] = acc[k][2]; }
+      if constexpr (kCommon) {
+        const float *row = common + (size_t)i * 12;
+        mine[0] = row[0]; mine[1] = row[1]; mine[2] = row[2];
+#pragma unroll
+        for (int k = 3; k < 12; ++k) mine[3 * n + k] = row[k];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int rows = min(64, N - iw);
+    const float *wrows = s_rows + wave_first * kPitch;
+    float *dst = full + (size_t)iw * wo + kFirst;
+    if constexpr (kCols <= 64) {
+      for (int r = 0; r < rows; ++r)
+        if (lane < kCols) dst[(size_t)r * wo + lane] = wrows[r * kPitch + lane];
+    } else {
+      static_assert(kCols <= 128, "row wider than two wave instructions");
+      for (int r = 0; r < rows; ++r) {
+        dst[(size_t)r * wo + lane] = wrows[r * kPitch + lane];
+        if (lane + 64 < kCols) dst[(size_t)r * wo + lane + 64] = wrows[r * kPitch + lane + 64];
+      }
+    }
   }
 }
 
@@ -630,8 +663,7 @@ int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads
     GS_REQUIRE_DEV(rgb);
     GS_REQUIRE_DEV(grads->grad_precompute_rgb);  // backward must have been asked for this intermediate
   }
-  const long long total = (long long)num_gaussians * 15;
-  pack_split_kernel<<<gs::div_up(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+  pack_split_kernel<<<gs::div_up((long long)num_gaussians, kBlock), kBlock, 0, (hipStream_t)stream>>>(
       c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, *grads, common, rgb);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
