@@ -299,14 +299,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   // pixel position relative to the tile centre, pixel gradient
   const int red_idx = row_moments9_index(lane);
   const bool red_lane = red_idx >= 0;
-  const RowWeights rw = make_row_weights(lane, (float)((wave & 1) * 8 + (row & 1) * 4 + (j & 3)) - 7.5f,
-                                         (float)((wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2)) - 7.5f, g0, g1, g2);
 
   for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
     const int count = min(kB, top - base);
+    // an opaque per-batch copy of the thread index: the LDS addresses of staging and flush derive from it and are
+    // recomputed per batch (a few integer operations) instead of being hoisted out of the batch loop, where they
+    // would sit in registers across the compositing loop and end up spilled to scratch
+    int t = tid;
+    asm volatile("" : "+v"(t));
     __syncthreads();
-    if (tid < count) {  // count <= kB
-      const int g = sorted[start + base + tid];
+    if (t < count) {  // count <= kB
+      const int g = sorted[start + base + t];
       SplatRec s = load_record<kPacked>(g, recs, raw);
 #if GS_ABLATE == 9
       if constexpr (kPacked) {  // one more dependent global round trip: sensitivity to the staging latency
@@ -316,15 +319,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #endif
       s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
       stage_record(s);
-      s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
-      s_id[tid] = g;
+      s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
+      s_id[t] = g;
     }
-    for (int k = tid; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
+    for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
     __syncthreads();
     if (base < wave_top) {
       const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, wave, lane, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
       const int n_rel = (n - base) * 16;  // "base + slot < n" on byte offsets
+      // The lane constants of the nine sums (pixel position relative to the tile centre, pixel gradient) are rebuilt
+      // per batch behind an opaque copy, so that they are not live across staging and flush: held for the whole
+      // kernel they push it past the 80-register step and the compiler spills them to scratch (+0.2 GB of traffic).
+      float g0b = g0, g1b = g1, g2b = g2;
+      asm volatile("" : "+v"(g0b), "+v"(g1b), "+v"(g2b));
+      const RowWeights rw = make_row_weights(lane, (float)((wave & 1) * 8 + (row & 1) * 4 + (j & 3)) - 7.5f,
+                                             (float)((wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2)) - 7.5f, g0b, g1b, g2b);
 #if GS_PIPE
       // Software pipeline: the list entry two trips ahead and the record of the next trip are fetched while the
       // current trip computes -- a trip otherwise serialises two LDS round trips before its first multiply.
@@ -404,12 +414,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __syncthreads();
     // flush, step 1: one thread per gaussian turns its nine raw sums into the nine gradient values (uniform control
     // flow, the double arithmetic once per gaussian instead of once per lane of a 16-lane group)
-    if (tid < count) {
-      const double *acc = &s_acc[tid * kAcc];  // rgb3, S_1, S_cx, S_cy, S_cx2, S_cxcy, S_cy2
-      const float4 a = s_r0[tid], b = s_r1[tid];  // staged conic: see stage_record
+    if (t < count) {
+      const double *acc = &s_acc[t * kAcc];  // rgb3, S_1, S_cx, S_cy, S_cx2, S_cxcy, S_cy2
+      const float4 a = s_r0[t], b = s_r1[t];  // staged conic: see stage_record
       const float opa = b.z;
       // moments of gp about the gaussian's centre from those about the tile centre: d = (X, Y) - (cx, cy)
-      const double X = (double)a.x - ((double)tx0 + 7.5), Y = (double)a.y - ((double)ty0 + 7.5);
+      const double X = (double)(a.x - (tx0 + 7.5f)), Y = (double)(a.y - (ty0 + 7.5f));
       const double S1 = acc[3], Sx = acc[4], Sy = acc[5];
       const float sx = (float)(X * S1 - Sx), sy = (float)(Y * S1 - Sy);              // sum gp dx, sum gp dy
       const float sxx = (float)(X * (X * S1 - 2.0 * Sx) + acc[6]);                   // sum gp dx^2
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
       // gaussian (sigmoid(opacity) == 1) gets no gradient at all
       const float keep = opa == 1.0f ? 0.0f : 1.0f;
-      float *res = &s_res[tid * 9];
+      float *res = &s_res[t * 9];
       res[0] = keep * (float)acc[0];
       res[1] = keep * (float)acc[1];
       res[2] = keep * (float)acc[2];
@@ -432,11 +442,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     __syncthreads();
     // step 2: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows
-    const int k = tid & 15;
+    const int k = t & 15;
     if (k < 9) {
 #pragma unroll 4
       for (int r = 0; r < kB / 16; ++r) {
-        const int slot = r * 16 + (tid >> 4);
+        const int slot = r * 16 + (t >> 4);
         if (slot >= count) continue;
         const float val = s_res[slot * 9 + k];
         if (!(val != 0.0f)) continue;  // zero (nothing to add) -- NaN still goes out
