@@ -124,6 +124,7 @@ SIGNATURES = {
     "gsplat_backward_pass": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera), _P, _F, _I,
                                   ctypes.POINTER(Gradients), _P]),
     "gsplat_context_set_timing": (_I, [_P, _I]),
+    "gsplat_context_set_timing_stages": (_I, [_P, ctypes.c_uint]),
     "gsplat_context_get_timing": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), _I]),
     "gsplat_pack_gradients_global": (_I, [_P, ctypes.POINTER(Gradients), _I, _I, _P, _P]),
     "gsplat_packed_gradient_width": (_I, [_I]),

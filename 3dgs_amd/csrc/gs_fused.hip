@@ -75,7 +75,7 @@ struct gsplat_context {
   }
   // optional per-stage HIP-event timing (gsplat_context_set_timing)
   static constexpr int kStages = 8, kSlots = 32;
-  bool timing = false;
+  unsigned int timing = 0;  // bit k: stage k is timed
   hipEvent_t ev[kSlots][2 * kStages] = {};
   unsigned char pending[kSlots][kStages] = {};
   double stage_ms[kStages] = {};
@@ -83,7 +83,7 @@ struct gsplat_context {
   long long fwd_calls = 0;
   int slot = 0;
   void mark(int stage, bool stop, hipStream_t st) {
-    if (!timing) return;
+    if (!((timing >> stage) & 1u)) return;
     (void)hipEventRecord(ev[slot][2 * stage + (stop ? 1 : 0)], st);
     if (stop) pending[slot][stage] = 1;
   }
@@ -1009,17 +1009,21 @@ int gsplat_context_set_binning_route(gsplat_context *c, int route) {
   return GSPLAT_OK;
 }
 
-int gsplat_context_set_timing(gsplat_context *c, int enabled) {
+int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask) {
   GS_REQUIRE(c != nullptr, "null context");
-  if (enabled && !c->ev[0][0]) {
+  if (stage_mask && !c->ev[0][0]) {
     for (int a = 0; a < gsplat_context::kSlots; ++a)
       for (int b = 0; b < 2 * gsplat_context::kStages; ++b) GS_HIP(hipEventCreate(&c->ev[a][b]));
   }
   GS_HIP(hipDeviceSynchronize());
   for (int a = 0; a < gsplat_context::kSlots; ++a) c->harvest(a);
   for (int k = 0; k < gsplat_context::kStages; ++k) { c->stage_ms[k] = 0; c->stage_n[k] = 0; }
-  c->timing = enabled != 0;
+  c->timing = stage_mask & ((1u << gsplat_context::kStages) - 1u);
   return GSPLAT_OK;
+}
+
+int gsplat_context_set_timing(gsplat_context *c, int enabled) {
+  return gsplat_context_set_timing_stages(c, enabled ? ~0u : 0u);
 }
 
 int gsplat_context_get_timing(gsplat_context *c, double *stage_ms_sum, long long *stage_count, int max_stages) {

@@ -82,8 +82,16 @@ class RasterContext:
         """0 automatic, 1 LDS counting sort + per-tile depth sort, 2 stable radix sorts (identical results)."""
         check(self._lib.gsplat_context_set_binning_route(self._h, int(route)))
 
-    def set_timing(self, enabled):
-        check(self._lib.gsplat_context_set_timing(self._h, int(bool(enabled))))
+    def set_timing(self, enabled, stages=None):
+        """Per-stage HIP-event timing on / off; `stages`: names from STAGES to time only those (each timed stage costs
+        two event records per call)."""
+        if enabled and stages is not None:
+            mask = 0
+            for name in stages:
+                mask |= 1 << self.STAGES.index(name)
+            check(self._lib.gsplat_context_set_timing_stages(self._h, mask))
+        else:
+            check(self._lib.gsplat_context_set_timing(self._h, int(bool(enabled))))
 
     def get_timing(self):
         """{stage: (mean ms per launch, launches)} since timing was enabled (HIP events on the launch stream)."""
