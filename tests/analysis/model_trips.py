@@ -95,3 +95,32 @@ for wy in range(2):
         trips_e += np.max(np.stack(cnts), axis=0).sum()
 print("exact: quadrant visits", visits_e, "sub-block pairs", pairs_e, "row-queue trips", trips_e,
       "ratio visits/trips", visits / trips_e, "row occupancy", pairs_e / (4 * trips_e))
+
+
+# ---- lane utilisation of the (instance, block) pairs the AABB test admits: pixels with alpha >= 1/255 (no saturation)
+def lane_utilisation(sample=400000, seed=1):
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(len(g), size=min(sample, len(g)), replace=False)
+    gi = g[idx]
+    ox, oy = tx0[idx], ty0[idx]
+    px = np.arange(16, dtype=np.float32)
+    X = ox[:, None] + px[None, :]            # [n,16] pixel x
+    Y = oy[:, None] + px[None, :]
+    dx = uv[gi, 0][:, None] - X               # [n,16]
+    dy = uv[gi, 1][:, None] - Y
+    A, B, C = a[gi][:, None, None], b[gi][:, None, None], cc[gi][:, None, None]
+    power = -0.5 * (A * dx[:, None, :] ** 2 + C * dy[:, :, None] ** 2) - B * dx[:, None, :] * dy[:, :, None]  # [n,y,x]
+    alpha = np.minimum(0.99, opa[gi][:, None, None] * np.exp(np.minimum(power, 0)))
+    valid = alpha >= 1.0 / 255.0              # [n,16,16]
+    blk = valid.reshape(-1, 4, 4, 4, 4).sum(axis=(2, 4))  # [n, by, bx] valid pixels per 4x4 block
+    hitx = np.stack([(~(hix[idx] < ox + k * 4)) & (~(lox[idx] > ox + k * 4 + 3)) for k in range(4)], 1)  # [n,bx]
+    hity = np.stack([(~(hiy[idx] < oy + k * 4)) & (~(loy[idx] > oy + k * 4 + 3)) for k in range(4)], 1)
+    admitted = hity[:, :, None] & hitx[:, None, :]
+    assert (blk[~admitted] == 0).all(), "AABB test must be conservative"
+    v = blk[admitted]
+    print("admitted (instance, block) pairs per instance", admitted.sum() / len(idx), "with no valid pixel", (v == 0).mean(),
+          "mean valid lanes of 16", v.mean(), "histogram", np.bincount(v, minlength=17) / len(v))
+
+
+if os.environ.get("GS_MODEL_LANES"):
+    lane_utilisation()
