@@ -254,21 +254,97 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[E], in
   }
 }
 
+// The same network on keys held as DOUBLES: a compare-exchange is v_min_f64 + v_max_f64 instead of a 64-bit integer
+// compare and four selects (the kernel is bound by exactly these instructions).  A payload (order-preserving depth
+// bits << 32 | id) with its top bit flipped is, for a positive depth, the bit pattern of a positive normal double
+// whose order is the payload's order; tiles holding a key for which that is not true (negative, denormal-range or
+// non-finite depth) take the integer workgroup kernel instead.  Padding: +infinity.
+__device__ __forceinline__ double key_min(double a, double b) {
+  double r;  // through asm: fmin() would first canonicalise both operands
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double key_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int E>
-__device__ __forceinline__ void sort_tile_in_registers(const unsigned long long *__restrict__ payload, int start, int len,
+__device__ __forceinline__ void wave_bitonic_sort_f64(double (&v)[E], int lane) {
+  constexpr int kTotal = 64 * E;
+#pragma unroll
+  for (int k = 2; k <= kTotal; k <<= 1) {
+    if (k <= E) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int o = e ^ (k - 1);
+        if (e < o) {
+          const double a = v[e], b = v[o];
+          v[e] = key_min(a, b);
+          v[o] = key_max(a, b);
+        }
+      }
+    } else {
+      const int partner = lane ^ (k / E - 1);
+      const bool lower = (lane & (k / E / 2)) == 0;
+      double got[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) got[e] = __shfl(v[E - 1 - e], partner, 64);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const double lo = key_min(got[e], v[e]), hi = key_max(got[e], v[e]);
+        v[e] = lower ? lo : hi;
+      }
+    }
+#pragma unroll
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      if (j < E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if ((e & j) == 0) {
+            const double a = v[e], b = v[e | j];
+            v[e] = key_min(a, b);
+            v[e | j] = key_max(a, b);
+          }
+      } else {
+        const int d = j / E;
+        const bool lower = (lane & d) == 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double got = __shfl_xor(v[e], d, 64);
+          const double lo = key_min(got, v[e]), hi = key_max(got, v[e]);
+          v[e] = lower ? lo : hi;
+        }
+      }
+    }
+  }
+}
+
+// false: the tile holds a key that has no order-preserving double (the caller hands the tile to the integer kernel)
+template <int E>
+__device__ __forceinline__ bool sort_tile_in_registers(const unsigned long long *__restrict__ payload, int start, int len,
                                                        int lane, int *__restrict__ sorted) {
-  unsigned long long v[E];
+  double v[E];
+  bool ok = true;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int p = lane * E + e;
-    v[e] = p < len ? payload[start + p] : ~0ull;
+    unsigned long long bits = 0x7FF0000000000000ull;  // +infinity
+    if (p < len) {
+      bits = payload[start + p] ^ 0x8000000000000000ull;
+      ok = ok && ((bits >> 52) - 1ull) < 0x7FEull;  // sign clear, exponent field neither 0 nor 0x7FF
+    }
+    v[e] = __longlong_as_double((long long)bits);
   }
-  wave_bitonic_sort<E>(v, lane);
+  if (!__all(ok)) return false;
+  wave_bitonic_sort_f64<E>(v, lane);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int p = lane * E + e;
-    if (p < len) sorted[start + p] = (int)(unsigned int)(v[e] & 0xFFFFFFFFull);
+    if (p < len) sorted[start + p] = (int)(unsigned int)((unsigned long long)__double_as_longlong(v[e]) & 0xFFFFFFFFull);
   }
+  return true;
 }
 
 constexpr int kWaveSortMax = 1024;  // 16 entries per lane; longer lists take the workgroup kernel below
@@ -284,11 +360,13 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const unsigne
     if (lane == 0) long_tiles[1 + atomicAdd(&long_tiles[0], 1)] = tile;
     return;
   }
-  if (len <= 64) sort_tile_in_registers<1>(payload, start, len, lane, sorted);
-  else if (len <= 128) sort_tile_in_registers<2>(payload, start, len, lane, sorted);
-  else if (len <= 256) sort_tile_in_registers<4>(payload, start, len, lane, sorted);
-  else if (len <= 512) sort_tile_in_registers<8>(payload, start, len, lane, sorted);
-  else sort_tile_in_registers<16>(payload, start, len, lane, sorted);
+  bool done;
+  if (len <= 64) done = sort_tile_in_registers<1>(payload, start, len, lane, sorted);
+  else if (len <= 128) done = sort_tile_in_registers<2>(payload, start, len, lane, sorted);
+  else if (len <= 256) done = sort_tile_in_registers<4>(payload, start, len, lane, sorted);
+  else if (len <= 512) done = sort_tile_in_registers<8>(payload, start, len, lane, sorted);
+  else done = sort_tile_in_registers<16>(payload, start, len, lane, sorted);
+  if (!done && lane == 0) long_tiles[1 + atomicAdd(&long_tiles[0], 1)] = tile;
 }
 
 // Lists longer than kWaveSortMax (listed by the wave kernel): one workgroup each, LDS up to kLdsSort entries, in place
@@ -323,7 +401,8 @@ __global__ __launch_bounds__(kBlock) void tile_depth_sort_kernel(unsigned long l
 // `long_tiles` (long_tiles[0] must be 0 on entry) and finished by workgroups of the second kernel
 static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, int num_tiles, size_t S, int *long_tiles,
                                int *sorted_out, hipStream_t st) {
-  const int max_long = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)kWaveSortMax);  // cannot be more
+  // tiles the wave kernel may hand over: the long lists and any list with a key that has no double form
+  const int max_long = (int)std::min<size_t>((size_t)num_tiles, S);
   tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
   GS_LAUNCH_CHECK();
   if (max_long > 0) {
