@@ -132,6 +132,31 @@ def test_binning_is_bit_exact(gpu, case):
     assert (srt.cpu().numpy()[:S] == f["sorted"]).all()
 
 
+def test_binning_with_depths_outside_the_register_sorts_range(gpu, orc, case):
+    """The per-tile register sort holds its keys as positive normal doubles; a list with a key that has no such form
+    (negative, zero, denormal-range or infinite depth) is handed to the integer workgroup kernel.  The operator takes
+    whatever depths the caller passes, so both paths must give the reference's order."""
+    torch, ops = gpu, pkg("ops")
+    f, W, H = case["fwd"], case["W"], case["H"]
+    M = f["num_culled"]
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    xyz = np.array(f["xyz_c"], np.float32).reshape(-1, 3).copy()
+    rng = np.random.default_rng(5)
+    odd = np.array([-3.5, 0.0, 1e-41, np.inf, -np.inf, 3e38, 1e-30], np.float32)  # not -0.0: the oracle ties it with +0.0
+    pick = rng.random(M) < 0.3
+    xyz[pick, 2] = odd[rng.integers(0, len(odd), pick.sum())]
+    xyz[~pick, 2] *= np.where(rng.random((~pick).sum()) < 0.5, -1.0, 1.0).astype(np.float32)
+    want_sorted, want_ranges, cap = orc.get_sorted_gaussian_list(f["uv"], xyz, f["radius"], ntx, nty)
+    uv, xyz_d, radius = _dev(torch, f["uv"]), _dev(torch, xyz), _dev(torch, f["radius"])
+    count = ops.get_sorted_gaussian_list(uv, xyz_d, radius, ntx, nty, M, 0, None, None)
+    assert count == cap
+    srt = torch.full((count,), -1, dtype=torch.int32, device="cuda")
+    ranges = torch.full((ntx * nty + 1,), -1, dtype=torch.int32, device="cuda")
+    ops.get_sorted_gaussian_list(uv, xyz_d, radius, ntx, nty, M, count, srt, ranges)
+    assert (ranges.cpu().numpy() == want_ranges).all()
+    assert (srt.cpu().numpy()[:len(want_sorted)] == want_sorted).all()
+
+
 def test_known_answer_binning(gpu):  # reference tests/cuda_forward_test.cpp:422-538
     torch, ops = gpu, pkg("ops")
     uv = _dev(torch, np.array([24, 24, 32, 24, 40, 40], np.float32))
