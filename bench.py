@@ -156,13 +156,15 @@ def main():
                          f"compositing on {cores} OpenMP threads, per-gaussian operators and sort single-threaded"}
 
     ms = elapsed / args.steps * 1e3
+    origin = {"config2": "BASELINE configs[1]", "config3": "BASELINE configs[2]"}.get(args.workload,
+                                                                                     f"'{args.workload}' (not a BASELINE config)")
     line = {
-        "metric": "fwd+bwd iterations/s (one view per GPU), 1e6 gaussians @1920x1080, SH deg 3" if do_bwd
-        else "forward renders/s",
+        "metric": (f"fwd+bwd iterations/s (one view per GPU), {N:.0e} gaussians @{W}x{H}, SH deg {L}".replace("e+0", "e")
+                   if do_bwd else f"forward renders/s, {N:.0e} gaussians @{W}x{H}, SH deg {L}".replace("e+0", "e")),
         "value": world * args.steps / elapsed, "unit": "it/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: synthetic {N} gaussians, {W}x{H}, SH deg {L}, "
+        "config": {"workload": f"{origin}: synthetic {N} gaussians, {W}x{H}, SH deg {L}, "
                                f"{'forward+backward' if do_bwd else 'forward'}",
                    "views_per_step": world, "parallelism": f"view-sharded dp{world}" if world > 1 else "single GPU",
                    "exchange": step.describe_exchange() if world > 1 else "none",
