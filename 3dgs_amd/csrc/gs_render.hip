@@ -27,9 +27,6 @@
 
 #include <cstdlib>
 
-#ifndef GS_PIPE
-#define GS_PIPE 0
-#endif
 #ifndef GS_ABLATE
 #define GS_ABLATE 0
 #endif
@@ -234,7 +231,7 @@ __device__ __forceinline__ int row_max_int(int v) {  // max over the 16 lanes of
 }
 
 template <bool kPacked, bool kRows, int kB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
                                                               const int *__restrict__ sorted,
                                                               const int *__restrict__ ranges,
                                                               const int *__restrict__ n_px,
@@ -242,15 +239,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                               const float *__restrict__ grad_image, int width,
                                                               int height, int ntx, int num_tiles, float bg,
                                                               GradOut out) {
-  __shared__ float4 s_r0[kB + 1], s_r1[kB + 1], s_r2[kB + 1];  // [kB]: the all-zero sentinel record
+  __shared__ float4 s_r0[kB + 1], s_r1[kB + 1];  // [kB]: the all-zero sentinel record
   // [slot][9]: rgb, S0, Sx, Sy, Sxx, Sxy, Syy.  Doubles on purpose: on gfx950 ds_add_f32 retires about one LANE
   // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
   // a 36-lane instruction), and the merge across the tile's 16 blocks needs one atomic per trip.
   constexpr int kAcc = 10;  // doubles per slot (nine used): 80 bytes = 5 x the list entry's byte offset
   __shared__ double s_acc[kB * kAcc];
   __shared__ int s_id[kB];
-  __shared__ float s_res[kB * 9];  // the batch's nine gradient values per gaussian, between the two flush steps
-  __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kB];
+  // row lists | third record array; both are dead once the batch's trips are done, and the flush parks the nine
+  // gradient values per gaussian on top of them (kB*36 bytes: the lists and the first slots of s_r2, not the sentinel)
+  __shared__ __attribute__((aligned(16))) unsigned char s_mix[16 * kB * 2 + (kB + 1) * 16];
+  unsigned short *s_list = reinterpret_cast<unsigned short *>(s_mix);
+  float4 *s_r2 = reinterpret_cast<float4 *>(s_mix + 16 * kB * 2);
+  float *s_res = reinterpret_cast<float *>(s_mix);
+  static_assert(kB * 9 * 4 <= 16 * kB * 2 + kB * 16, "the flush values must not reach the sentinel record");
   __shared__ int s_top;
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
@@ -262,12 +264,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const float fpx = (float)px, fpy = (float)py;
   const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
   const int start = ranges[tile];
-  unsigned short *lists = s_list + wave * 4 * kB;
-  const unsigned short *my_list = lists + row * kB;
   const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
   const char *r2b = reinterpret_cast<const char *>(s_r2);
   char *accb = reinterpret_cast<char *>(s_acc);
-  [[maybe_unused]] const unsigned int list_lds = (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)my_list;
 
   int n = 0;
   float Tf = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
@@ -325,7 +324,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
     __syncthreads();
     if (base < wave_top) {
-      const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, wave, lane, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1);
+      // (list addresses from the opaque index too)
+      unsigned short *lists = s_list + (t >> 6) * 4 * kB;
+      const unsigned int list_lds =
+          (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + ((t >> 4) & 3) * kB);
+      const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, t >> 6, t & 63, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
       const int n_rel = (n - base) * 16;  // "base + slot < n" on byte offsets
       // The lane constants of the nine sums (pixel position relative to the tile centre, pixel gradient) are rebuilt
@@ -335,28 +338,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       asm volatile("" : "+v"(g0b), "+v"(g1b), "+v"(g2b));
       const RowWeights rw = make_row_weights(lane, (float)((wave & 1) * 8 + (row & 1) * 4 + (j & 3)) - 7.5f,
                                              (float)((wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2)) - 7.5f, g0b, g1b, g2b);
-#if GS_PIPE
-      // Software pipeline: the list entry two trips ahead and the record of the next trip are fetched while the
-      // current trip computes -- a trip otherwise serialises two LDS round trips before its first multiply.
-      int off = trips > 0 ? my_list[trips - 1] : 0;
-      int off_next = my_list[max(trips - 2, 0)];
-      float4 a = *reinterpret_cast<const float4 *>(r0b + off);
-      float2 b = *reinterpret_cast<const float2 *>(r1b + off);
-      for (int i = trips - 1; i >= 0; --i) {
-        const int off_cur = off;
-        const float4 a_next = *reinterpret_cast<const float4 *>(r0b + off_next);
-        const float2 b_next = *reinterpret_cast<const float2 *>(r1b + off_next);
-        const int off_nn = my_list[max(i - 2, 0)];
-        __builtin_amdgcn_sched_barrier(0);  // keep the three fetches ahead of this trip's arithmetic
-        const float dx = a.x - fpx, dy = a.y - fpy;
-        float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);
-        a = a_next; b = b_next; off = off_next; off_next = off_nn;
-        float alpha = fminf(kAlphaMax, og);
-        const bool valid = (alpha >= kAlphaMin) && (off_cur < n_rel);
-        if (__ballot(valid) == 0ull) continue;
-        const float4 c = *reinterpret_cast<const float4 *>(r2b + off_cur);
-#define off off_cur
-#else
       for (int i = trips - 1; i >= 0; --i) {
         // ds_read_u16 zero-extends; read through asm, the compiler would add an "and 0xffff" to every trip
         int off;
@@ -375,7 +356,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // so "inside" needs no separate test.
         const bool valid = (alpha >= kAlphaMin) && (off < n_rel);
         if (__ballot(valid) == 0ull) continue;
-#endif
 #if GS_ABLATE == 8
         asm volatile("" ::"v"(og));
         continue;
@@ -405,9 +385,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #else
         if (red_lane && red != 0.0f) atomicAdd(reinterpret_cast<double *>(accb + off * 5 + red_idx * 8), (double)red);
 #endif
-#endif
-#if GS_PIPE
-#undef off
 #endif
       }
     }
