@@ -107,7 +107,8 @@ __device__ __forceinline__ float4 sentinel_r1() { return make_float4(0.0f, GS_NA
 __device__ __forceinline__ float log2_alpha(float a2, float b2, float c2, float lopa, float dx, float dy) {
   float t = a2 * dx;
   t = __builtin_fmaf(b2, dy, t);
-  float q = __builtin_fmaf(t, dx, lopa);
+  float q;  // three-operand form on purpose: as v_fmac the compiler first copies lopa (still needed for the min)
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(t), "v"(dx), "v"(lopa));
   q = __builtin_fmaf(c2 * dy, dy, q);
   float r;  // fminf() would first canonicalise the loaded lopa (one more VALU instruction per evaluation)
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(lopa));
