@@ -46,7 +46,7 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
                      unsigned long long *payload, hipStream_t st);
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
-                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st);
+                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero, long long zero_vec);
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st);
@@ -66,6 +66,7 @@ struct gsplat_context {
   bool dense_route = false;  // binning route of the next forward (follows the last one's density)
   int forced_route = 0;      // gsplat_context_set_binning_route: 0 auto, 1 counting sort, 2 radix sorts
   bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
+  bool backward_seen = false, rows_zeroed = false;  // training use: the forward clears grad_rows for the backward
   // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
@@ -900,8 +901,12 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   if (rc) return rc;
   c->mark(2, true, st);
   c->mark(4, false, st);
+  // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
+  if (c->rows_zeroed) c->backward_seen = false;  // the last forward's cleared rows were never used: rendering only
+  c->rows_zeroed = c->backward_seen;
   rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
-                             c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st);
+                             c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
+                             c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4);
   if (rc) return rc;
   c->mark(4, true, st);
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
@@ -930,9 +935,13 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
   hipStream_t st = (hipStream_t)stream;
   const int M = c->M, W = c->width, H = c->height;
   c->rows_ready = false;
-  c->mark(5, false, st);
-  GS_HIP(hipMemsetAsync(c->grad_rows.ptr, 0, (size_t)M * 64, st));
-  c->mark(5, true, st);
+  c->backward_seen = true;
+  if (!c->rows_zeroed) {  // first backward of the context, or a second backward of the same forward
+    c->mark(5, false, st);
+    GS_HIP(hipMemsetAsync(c->grad_rows.ptr, 0, (size_t)M * 64, st));
+    c->mark(5, true, st);
+  }
+  c->rows_zeroed = false;
   c->mark(6, false, st);
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,

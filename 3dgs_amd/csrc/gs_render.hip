@@ -118,9 +118,17 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
                                                               const int *__restrict__ ranges, int width, int height,
                                                               int ntx, int num_tiles, float bg,
                                                               int *__restrict__ n_out, float *__restrict__ T_out,
-                                                              float *__restrict__ image) {
+                                                              float *__restrict__ image, float4 *__restrict__ zero,
+                                                              long long zero_vec) {
   __shared__ float4 s_r0[kBatch + 1], s_r1[kBatch + 1], s_r2[kBatch + 1];  // [kBatch]: the all-zero sentinel record
   __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride + 2];
+  // Optional side job: every workgroup clears its share of `zero` (the gradient rows the backward accumulates into).
+  // This kernel leaves most of the HBM bandwidth unused, so the 64 bytes per gaussian ride along for free instead of
+  // costing a memset between forward and backward.
+  if (zero) {
+    const long long per = (zero_vec + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = min(lo + per, zero_vec);
+    for (long long k = lo + threadIdx.x; k < hi; k += 256) zero[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
@@ -447,14 +455,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
 // host-side launchers shared with gs_fused.hip ------------------------------------------
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
-                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st) {
+                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero,
+                      long long zero_vec) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   if (recs) {
-    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);
+    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec);
   } else {
-    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image);
+    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -492,7 +501,8 @@ int gsplat_render_image(const float *uv, const float *opacity, const float *coni
   GS_REQUIRE(image_width > 0 && image_height > 0, "image size must be positive");
   gs::RawSplats raw = {uv, opacity, conic, rgb};
   return gs::launch_render_fwd(nullptr, &raw, sorted_splats, splat_range_by_tile, image_width, image_height,
-                               background_opacity, splats_per_pixel, weight_per_pixel, image, (hipStream_t)stream);
+                               background_opacity, splats_per_pixel, weight_per_pixel, image, (hipStream_t)stream, nullptr,
+                               0);
 }
 
 int gsplat_render_image_backward(const float *uvs, const float *opacity, const float *conic, const float *rgb,
