@@ -6,4 +6,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_
 cd $GRAFT_REPO_ROOT
 bash profiles/run_pmc.sh gpurun_out/pmc_final > gpurun_out/pmc_final.log 2>&1
 python3 profiles/summarize_pmc.py gpurun_out/pmc_final > gpurun_out/r01_pmc_summary.json
-find gpurun_out/stats -name "*kernel_stats.csv" | head
+ls -t gpurun_out/stats/runc/*kernel_stats.csv | head -1
