@@ -67,15 +67,6 @@ __device__ __forceinline__ unsigned int subblock_hits(const SplatRec &s, float x
   return ys * xm;
 }
 
-// exponent of the gaussian at offset (dx, dy) = (u - px, v - py); 2 FMAs on purpose
-__device__ __forceinline__ float gauss_power(float a, float b, float c, float dx, float dy) {
-  const float ax = a * dx;
-  const float bx = b * dx;
-  float t = ax * dx;
-  t = __builtin_fmaf(c * dy, dy, t);
-  return __builtin_fmaf(-bx, dy, -0.5f * t);
-}
-
 // ---- staged (LDS) form of a record.  The compositing loops evaluate opa * exp(min(0, power)) as one base-2
 // exponential with the opacity folded into the exponent,
 //   log2(opa * exp(power)) = a2 dx^2 + b2 dx dy + c2 dy^2 + log2(opa),   (a2, b2, c2) = -log2(e) * (a/2, b, c/2),
@@ -84,15 +75,8 @@ __device__ __forceinline__ float gauss_power(float a, float b, float c, float dx
 // the backward recomputes the forward's alpha bit for bit.
 constexpr float kLog2e = 1.44269504088896340736f;
 
-#ifndef GS_NATURAL_POWER
-#define GS_NATURAL_POWER 0
-#endif
 __device__ __forceinline__ void stage_record(SplatRec &s) {
   const float opa = s.r1.y;
-#if GS_NATURAL_POWER
-  s.r1.z = opa;
-  return;
-#endif
   s.r0.z *= -0.5f * kLog2e;
   s.r0.w *= -kLog2e;
   s.r1.x *= -0.5f * kLog2e;
@@ -101,7 +85,7 @@ __device__ __forceinline__ void stage_record(SplatRec &s) {
 }
 
 // the all-zero sentinel record a list is padded with: alpha = 2^-inf = 0 at every pixel
-__device__ __forceinline__ float4 sentinel_r1() { return make_float4(0.0f, GS_NATURAL_POWER ? 0.0f : -INFINITY, 0.0f, 0.0f); }
+__device__ __forceinline__ float4 sentinel_r1() { return make_float4(0.0f, -INFINITY, 0.0f, 0.0f); }
 
 // log2 of the unclamped alpha; min(.., log2 opa) is the reference's min(0, power)
 __device__ __forceinline__ float log2_alpha(float a2, float b2, float c2, float lopa, float dx, float dy) {
@@ -116,19 +100,11 @@ __device__ __forceinline__ float log2_alpha(float a2, float b2, float c2, float 
 }
 
 // the conic entries back from their staged form (flush of the backward): a = a2 * kConicDiag, b = b2 * kConicOff
-#if GS_NATURAL_POWER
-constexpr float kConicDiag = 1.0f, kConicOff = 1.0f;
-#else
 constexpr float kConicDiag = -2.0f / kLog2e, kConicOff = -1.0f / kLog2e;
-#endif
 
 // opa * exp(min(0, power)) from a staged record
 __device__ __forceinline__ float staged_alpha(float a2, float b2, float c2, float lopa, float dx, float dy) {
-#if GS_NATURAL_POWER
-  return lopa * __expf(fminf(0.0f, gauss_power(a2, b2, c2, dx, dy)));
-#else
   return __builtin_amdgcn_exp2f(log2_alpha(a2, b2, c2, lopa, dx, dy));
-#endif
 }
 
 // ---- DPP helpers
