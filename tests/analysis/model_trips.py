@@ -124,3 +124,42 @@ def lane_utilisation(sample=400000, seed=1):
 
 if os.environ.get("GS_MODEL_LANES"):
     lane_utilisation()
+
+
+# ---- candidate block tests between the footprint box and the exact one: + the two principal axes of the ellipse
+def obb_trips():
+    ag, bg2, cg, tg = a[g], b[g], cc[g], tau2[g]
+    ug, vg = uv[g, 0], uv[g, 1]
+    ok = opa[g] * 255 >= 0.999
+    # eigen-decomposition of [[a, b], [b, c]]: q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2
+    mean = 0.5 * (ag + cg)
+    diff = 0.5 * (ag - cg)
+    rad = np.sqrt(diff * diff + bg2 * bg2)
+    l1, l2 = mean + rad, mean - rad            # l1 >= l2 > 0
+    th = 0.5 * np.arctan2(2 * bg2, ag - cg)    # direction of the l1 axis
+    e1x, e1y = np.cos(th), np.sin(th)
+    r1 = np.sqrt(tg / l1)                      # semi-axis along e1 (short), along e2: sqrt(tau2 / l2) (long)
+    r2 = np.sqrt(tg / np.maximum(l2, 1e-30))
+    trips = 0
+    pairs = 0
+    for wy in range(2):
+        for wx in range(2):
+            cnts = []
+            for ry in range(2):
+                for rx in range(2):
+                    bx_, by_ = wx * 2 + rx, wy * 2 + ry
+                    xs, ys = tx0 + bx_ * 4, ty0 + by_ * 4
+                    hit = bx[bx_] & by[by_]
+                    cxb, cyb = xs + 1.5 - ug, ys + 1.5 - vg          # block centre relative to the gaussian
+                    p1 = cxb * e1x + cyb * e1y
+                    p2 = -cxb * e1y + cyb * e1x
+                    h = 1.5 * (np.abs(e1x) + np.abs(e1y))
+                    hit = hit & (np.abs(p1) - h <= r1) & (np.abs(p2) - h <= r2) & ok
+                    cnts.append(np.bincount(tile_of[hit], minlength=T))
+                    pairs += hit.sum()
+            trips += np.max(np.stack(cnts), axis=0).sum()
+    print("box + principal axes: sub-block pairs", pairs, "row-queue trips", trips)
+
+
+if os.environ.get("GS_MODEL_OBB"):
+    obb_trips()
