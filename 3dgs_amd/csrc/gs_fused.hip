@@ -46,10 +46,12 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
                      unsigned long long *payload, hipStream_t st);
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
-                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero, long long zero_vec);
+                      int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero, long long zero_vec,
+                      unsigned short *masks_out);
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
-                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st);
+                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st,
+                      const unsigned short *masks_in);
 }  // namespace gs
 
 struct gsplat_context {
@@ -60,6 +62,7 @@ struct gsplat_context {
   gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows, hitmask;
   // instances
   gs::DeviceBuffer keys_a, keys_b, pay_a, pay_b, sorted, temp, bin_table;
+  gs::DeviceBuffer blockmasks;  // per instance: the 16 block bits of the compositing kernels (forward -> backward)
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
   int *h_words = nullptr;  // pinned
@@ -103,7 +106,7 @@ struct gsplat_context {
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px};
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -111,7 +114,7 @@ struct gsplat_context {
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px};
+                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks};
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
@@ -613,6 +616,7 @@ int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   if ((rc = c->pay_a.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
   if ((rc = c->pay_b.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
   if ((rc = c->sorted.reserve((S + 1) * sizeof(int)))) return rc;
+  if ((rc = c->blockmasks.reserve((S + 1) * sizeof(unsigned short)))) return rc;
   if ((rc = c->temp.reserve(gs::binning_temp_bytes((size_t)c->max_gaussians, S ? S : 1, num_tiles)))) return rc;
   return GSPLAT_OK;
 }
@@ -906,7 +910,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->rows_zeroed = c->backward_seen;
   rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                              c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
-                             c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4);
+                             c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
+                             c->blockmasks.as<unsigned short>());
   if (rc) return rc;
   c->mark(4, true, st);
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
@@ -945,7 +950,8 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
   c->mark(6, false, st);
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
-                                 c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st);
+                                 c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,
+                                 c->blockmasks.as<unsigned short>());
   if (rc) return rc;
   c->mark(6, true, st);
   if (rgb_global) {

@@ -23,20 +23,22 @@ __device__ __forceinline__ float sigmoid_fast(float logit) { return 1.0f / (1.0f
 // p >= -tau, tau = ln(255*opa), i.e. inside the ellipse 0.5 d^T C d <= tau, whose bounding
 // box has half widths sqrt(2 tau C^-1_xx), sqrt(2 tau C^-1_yy).  Degenerate / NaN conics
 // get an infinite box (always visited), opacities that can never reach 1/255 an empty one.
-__device__ __forceinline__ void footprint(float a, float b, float c, float opa, float &hx, float &hy) {
+// Returns tau2 = 2 tau (+ margin), the level of the quadratic form a dx^2 + 2 b dx dy + c dy^2 at that ellipse.
+__device__ __forceinline__ float footprint(float a, float b, float c, float opa, float &hx, float &hy) {
   const float det = a * c - b * b;
   if (!(opa * 255.0f >= 0.999f)) {
     hx = hy = -INFINITY;
     if (opa != opa) hx = hy = INFINITY;
-    return;
+    return 0.0f;
   }
   if (!(det > 0.0f) || !(a > 0.0f) || !(c > 0.0f) || !(det < INFINITY)) {
     hx = hy = INFINITY;
-    return;
+    return INFINITY;
   }
   const float tau2 = 2.0f * fmaxf(0.0f, logf(255.0f * opa)) + 1e-3f;
   hx = sqrtf(tau2 * c / det) * 1.0005f + 0.01f;
   hy = sqrtf(tau2 * a / det) * 1.0005f + 0.01f;
+  return tau2;
 }
 
 __device__ __forceinline__ SplatRec make_record(float u, float v, float a, float b, float c, float logit, float r,
@@ -44,27 +46,47 @@ __device__ __forceinline__ SplatRec make_record(float u, float v, float a, float
   SplatRec s;
   const float opa = sigmoid_fast(logit);
   float hx, hy;
-  footprint(a, b, c, opa, hx, hy);
+  const float tau2 = footprint(a, b, c, opa, hx, hy);
   s.r0 = make_float4(u, v, a, b);
   s.r1 = make_float4(c, opa, hx, hy);
-  s.r2 = make_float4(r, g, bl, 0.0f);
+  s.r2 = make_float4(r, g, bl, tau2);
   return s;
 }
 
-// 16-bit mask: bit (4*by + bx) set when the footprint box may touch the 4x4 pixel block (bx, by) of the tile whose
-// first pixel is (x0, y0).  Written so that any NaN makes the test pass.
-__device__ __forceinline__ unsigned int subblock_hits(const SplatRec &s, float x0, float y0) {
-  const float u = s.r0.x, v = s.r0.y, hx = s.r1.z, hy = s.r1.w;
-  const float lo_x = u - hx, hi_x = u + hx, lo_y = v - hy, hi_y = v + hy;
-  unsigned int xm = 0u, ym = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float o = 4.0f * (float)k;
-    xm |= (!(hi_x < x0 + o) && !(lo_x > x0 + o + 3.0f)) ? (1u << k) : 0u;
-    ym |= (!(hi_y < y0 + o) && !(lo_y > y0 + o + 3.0f)) ? (1u << k) : 0u;
+// 16-bit mask: bit (4*by + bx) set when the ellipse alpha >= 1/255 may touch the 4x4 pixel block (bx, by) of the tile
+// whose first pixel is (x0, y0) -- the ellipse itself, not its bounding box.  For each of the tile's four strips of pixel rows (dy in [Y0, Y0+3]
+// about the centre) the ellipse q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 <= tau2 covers the dx-interval
+// [min_y L(y), max_y R(y)], L/R(y) = -(b/a) y -/+ sqrt((tau2 - (det/a) y^2) / a); R is concave with its maximum at the
+// dy of the ellipse's rightmost point, -(b/c) hx, L convex with its minimum at +(b/c) hx, so each bound is one
+// evaluation at that dy clamped into the strip: two square roots per strip, about 200 instructions per (gaussian,
+// tile) -- once, the forward hands the masks to the backward.  On the benchmark scene the box admits 17.4 M
+// (gaussian, block) pairs, the ellipse 14.3 M: 17 % fewer loop trips in both compositing kernels.  Degenerate conics
+// (infinite box) visit every block; what a NaN centre visits does not matter (its alpha is NaN on every pixel: no splat).
+__device__ __forceinline__ unsigned int block_hits(const SplatRec &s, float x0, float y0) {
+  const float a = s.r0.z, b = s.r0.w, c = s.r1.x, hx = s.r1.z, hy = s.r1.w, tau2 = s.r2.w;
+  if (!(hx < INFINITY) || !(hy < INFINITY)) return 0xFFFFu;  // degenerate conic or NaN: always visited
+  if (!(hx > 0.0f)) return 0u;                                // opacity can never reach 1/255
+  const float inv_a = 1.0f / a, boa = b * inv_a;
+  const float kappa = c - b * boa;    // det / a
+  const float ystar = -(b / c) * hx;  // dy of the rightmost point; the leftmost one sits at -ystar
+  const float U = s.r0.x - x0, V = s.r0.y - y0;  // centre relative to the tile's first pixel
+  unsigned int out = 0u;
+#pragma unroll 1  // one strip at a time: unrolled, the four strips' temporaries push the callers past their VGPR step
+  for (int l = 0; l < 4; ++l) {
+    const float Y0 = 4.0f * (float)l - V, Y1 = Y0 + 3.0f;
+    const float ylo = fmaxf(Y0, -hy), yhi = fminf(Y1, hy);
+    const float yr = __builtin_amdgcn_fmed3f(ystar, ylo, yhi), yl = __builtin_amdgcn_fmed3f(-ystar, ylo, yhi);
+    const float wr = __builtin_sqrtf(fmaxf(0.0f, (tau2 - kappa * yr * yr) * inv_a));
+    const float wl = __builtin_sqrtf(fmaxf(0.0f, (tau2 - kappa * yl * yl) * inv_a));
+    const float R = wr - boa * yr, L = -wl - boa * yl;
+    const float Rm = R + (0.01f + 5e-4f * fabsf(R)), Lm = L - (0.01f + 5e-4f * fabsf(L));
+    // blocks k with 4k - U <= Rm and 4k + 3 - U >= Lm: k in [ceil((Lm + U - 3) / 4), floor((Rm + U) / 4)]
+    const int k_hi = min(3, (int)floorf((Rm + U) * 0.25f)), k_lo = max(0, (int)ceilf((Lm + U - 3.0f) * 0.25f));
+    unsigned int row = k_hi >= k_lo ? ((2u << k_hi) - (1u << k_lo)) : 0u;
+    if (ylo > yhi) row = 0u;  // the strip lies above or below the ellipse
+    out |= row << (4 * l);
   }
-  const unsigned int ys = (ym | (ym << 3) | (ym << 6) | (ym << 9)) & 0x1111u;  // bit k -> bit 4k
-  return ys * xm;
+  return out;
 }
 
 // ---- staged (LDS) form of a record.  The compositing loops evaluate opa * exp(min(0, power)) as one base-2

@@ -113,13 +113,13 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
 }
 
 template <bool kPacked>
-__global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void render_fwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
                                                               const int *__restrict__ sorted,
                                                               const int *__restrict__ ranges, int width, int height,
                                                               int ntx, int num_tiles, float bg,
                                                               int *__restrict__ n_out, float *__restrict__ T_out,
                                                               float *__restrict__ image, float4 *__restrict__ zero,
-                                                              long long zero_vec) {
+                                                              long long zero_vec, unsigned short *__restrict__ masks_out) {
   __shared__ float4 s_r0[kBatch + 1], s_r1[kBatch + 1], s_r2[kBatch + 1];  // [kBatch]: the all-zero sentinel record
   __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride + 2];
   // Optional side job: every workgroup clears its share of `zero` (the gradient rows the backward accumulates into).
@@ -142,8 +142,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
   const bool inside = px < width && py < height;
   const float fpx = (float)px, fpy = (float)py;
   const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
-  unsigned short *lists = s_list + wave * 4 * kListStride;
-  const unsigned short *my_list = lists + row * kListStride;
   const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
   const char *r2b = reinterpret_cast<const char *>(s_r2);
 
@@ -157,19 +155,27 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4 *__restric
 
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
+    // an opaque per-batch copy of the thread index (see render_bwd_kernel): staging and list-building addresses are
+    // rebuilt per batch instead of living in registers across the compositing loop
+    int t = tid;
+    asm volatile("" : "+v"(t));
     __syncthreads();
-    if (tid < count) {
-      const int g = sorted[start + base + tid];
+    if (t < count) {
+      const int g = sorted[start + base + t];
       SplatRec s = load_record<kPacked>(g, recs, raw);
-      s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
+      const unsigned int hits = block_hits(s, tx0, ty0);
+      if (masks_out) masks_out[start + base + t] = (unsigned short)hits;  // the backward stages the same instances
+      s.r2.w = __uint_as_float(hits);
       stage_record(s);
-      s_r0[tid] = s.r0; s_r1[tid] = s.r1; s_r2[tid] = s.r2;
+      s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
     }
     __syncthreads();
     if (live > 0) {
       // rows whose 16 pixels are all saturated (or outside) need no list
       const int big = kBatch;
-      const RowCounts rc = build_row_lists<kListStride>(s_r2, lists, count, wave, lane,
+      unsigned short *lists = s_list + (t >> 6) * 4 * kListStride;
+      const unsigned short *my_list = lists + ((t >> 4) & 3) * kListStride;
+      const RowCounts rc = build_row_lists<kListStride>(s_r2, lists, count, t >> 6, t & 63,
                                            (unsigned int)(satmask & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 16) & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 32) & 0xFFFFull) == 0xFFFFu ? 0 : big,
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                                                               const float *__restrict__ T_px,
                                                               const float *__restrict__ grad_image, int width,
                                                               int height, int ntx, int num_tiles, float bg,
-                                                              GradOut out) {
+                                                              GradOut out, const unsigned short *__restrict__ masks_in) {
   __shared__ float4 s_r0[kB + 1], s_r1[kB + 1];  // [kB]: the all-zero sentinel record
   // [slot][9]: rgb, S0, Sx, Sy, Sxx, Sxy, Syy.  Doubles on purpose: on gfx950 ds_add_f32 retires about one LANE
   // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
@@ -324,7 +330,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         if (extra.x == 98765.4f) s.r0.x += 1.0f;
       }
 #endif
-      s.r2.w = __uint_as_float(subblock_hits(s, tx0, ty0));
+      // the fused path hands over the forward's block masks; the raw-array operator computes them here
+      if constexpr (kPacked) s.r2.w = __uint_as_float((unsigned int)masks_in[start + base + t]);
+      else s.r2.w = __uint_as_float(block_hits(s, tx0, ty0));
       stage_record(s);
       s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
       s_id[t] = g;
@@ -456,14 +464,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 // host-side launchers shared with gs_fused.hip ------------------------------------------
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero,
-                      long long zero_vec) {
+                      long long zero_vec, unsigned short *masks_out) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   if (recs) {
-    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec);
+    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out);
   } else {
-    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec);
+    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -471,17 +479,17 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
 
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
-                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st) {
+                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   GradOut out = {rows, g_rgb, g_opacity, g_uv, g_conic};
   if (recs && rows) {
-    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   } else if (recs) {
-    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   } else {
-    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out);
+    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -502,7 +510,7 @@ int gsplat_render_image(const float *uv, const float *opacity, const float *coni
   gs::RawSplats raw = {uv, opacity, conic, rgb};
   return gs::launch_render_fwd(nullptr, &raw, sorted_splats, splat_range_by_tile, image_width, image_height,
                                background_opacity, splats_per_pixel, weight_per_pixel, image, (hipStream_t)stream, nullptr,
-                               0);
+                               0, nullptr);
 }
 
 int gsplat_render_image_backward(const float *uvs, const float *opacity, const float *conic, const float *rgb,
@@ -519,7 +527,7 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
   gs::RawSplats raw = {uvs, opacity, conic, rgb};
   return gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, (hipStream_t)stream);
+                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"
