@@ -28,3 +28,26 @@ def test_row_sum9_on_gpu():
     out = subprocess.run([_build()], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "row_sum9: ok" in out.stdout and "row_moments9: ok" in out.stdout, \
         out.stdout + out.stderr
+
+
+BH_SRC = os.path.join(ROOT, "tools", "block_hits_test.hip")
+BH_EXE = os.path.join(ROOT, "tools", "block_hits_test")
+
+
+def _build_block_hits():
+    hdr = os.path.join(ROOT, "3dgs_amd", "csrc", "gs_render.h")
+    if not os.path.exists(BH_EXE) or os.path.getmtime(BH_EXE) < max(os.path.getmtime(BH_SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", BH_SRC, "-o", BH_EXE])
+    return BH_EXE
+
+
+def test_block_hits_program_builds():
+    assert os.path.exists(_build_block_hits())
+
+
+@pytest.mark.gpu
+def test_block_hits_is_conservative_on_gpu():
+    """gs::block_hits (the ellipse-vs-block test of the compositing kernels) never drops a block that holds a pixel with
+    alpha >= 1/255: 262144 random gaussians against a per-pixel evaluation."""
+    out = subprocess.run([_build_block_hits()], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "block_hits: ok" in out.stdout, out.stdout + out.stderr
