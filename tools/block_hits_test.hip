@@ -32,13 +32,13 @@ int main() {
   std::vector<float> h(6 * (size_t)n);
   for (int i = 0; i < n; ++i) {
     const float th = 3.14159265f * U(rng);
-    const float s1 = std::exp(std::log(0.3f) + U(rng) * std::log(200.0f)), s2 = s1 * std::exp(-U(rng) * std::log(40.0f));
+    const float s1 = std::exp(std::log(0.05f) + U(rng) * std::log(40000.0f)), s2 = s1 * std::exp(-U(rng) * std::log(1000.0f));  // 0.05 .. 2000 px, up to 1000:1
     const float cs = std::cos(th), sn = std::sin(th);
     // covariance R diag(s1^2, s2^2) R^T; conic = inverse
     const float A = cs * cs * s1 * s1 + sn * sn * s2 * s2, B = cs * sn * (s1 * s1 - s2 * s2), C = sn * sn * s1 * s1 + cs * cs * s2 * s2;
     const float det = A * C - B * B;
-    h[6 * i + 0] = 32.0f + (U(rng) * 3.0f - 1.0f) * 16.0f;  // centre from one tile left/above to one right/below
-    h[6 * i + 1] = 48.0f + (U(rng) * 3.0f - 1.0f) * 16.0f;
+    h[6 * i + 0] = 32.0f + (U(rng) * 3.0f - 1.0f) * 16.0f * (i % 8 == 0 ? 20.0f : 1.0f);  // centre near the tile, some far away
+    h[6 * i + 1] = 48.0f + (U(rng) * 3.0f - 1.0f) * 16.0f * (i % 8 == 0 ? 20.0f : 1.0f);
     h[6 * i + 2] = C / det; h[6 * i + 3] = -B / det; h[6 * i + 4] = A / det;
     h[6 * i + 5] = -6.0f + 14.0f * U(rng);  // logit of the opacity
   }
