@@ -8,20 +8,23 @@
 // Design (not the reference's one-warp-per-tile, 8-pixels-per-lane layout):
 //   * one 256-thread workgroup per tile = four wave64s; every 16-lane ROW of a wave owns one 4x4 pixel block,
 //     one pixel per lane;
-//   * the tile's list is consumed in batches of 256 entries: every thread gathers ONE gaussian (three 16-byte
-//     loads of a 48-byte record, or the reference's four arrays), evaluates sigmoid(opacity) and a conservative
-//     footprint box once, computes which of the tile's 16 blocks the box reaches, and parks it in LDS;
+//   * the tile's list is consumed in batches (256 entries forward, 128 backward): every thread gathers ONE gaussian
+//     (three 16-byte loads of a 48-byte record, or the reference's four arrays), works out which of the tile's 16
+//     blocks the ellipse alpha >= 1/255 can reach (gs::block_hits; the forward hands these masks to the backward),
+//     and parks the record in LDS in the form the loops evaluate (gs::stage_record);
 //   * each wave compacts, per row, the batch's slots that hit the row's block into a byte list in LDS, and every
 //     row walks ITS OWN list: in one loop trip the four rows of a wave work on four different (gaussian, block)
-//     pairs and a wave's trip count is the longest of its four lists -- on the benchmark scene 1.37x fewer trips
-//     than visiting (gaussian, 8x8 quadrant) pairs (tests/analysis/model_trips.py).  Skipping is exact: a skipped gaussian
-//     has alpha < 1/255 on every pixel of the block;
-//   * forward: a row whose 16 pixels are saturated gets no list, a wave stops when its 64 pixels are saturated, the
-//     workgroup when all four waves have;
+//     pairs and a wave's trip count is the longest of its four lists -- on the benchmark scene 1.65x fewer trips
+//     than visiting (gaussian, 8x8 quadrant) pairs (tests/analysis/model_trips.py).  Skipping is exact: a skipped
+//     gaussian has alpha < 1/255 on every pixel of the block;
+//   * forward: two list entries per trip; a row whose 16 pixels are saturated gets no list, a wave stops when its 64
+//     pixels are saturated, the workgroup when all four waves have; on the side it clears the gradient rows the
+//     backward accumulates into (the kernel leaves most of the HBM bandwidth unused);
 //   * backward: the nine partial sums of a (gaussian, block) pair are reduced across the row's 16 lanes only
-//     (gs::row_sum9: 21 full-rate VALU, the nine totals land in nine lanes of one register), merged across the
-//     tile's blocks with ONE ds_add_f64 per trip, and flushed once per batch to HBM as whole 64-byte gradient rows
-//     (or into the reference's four gradient arrays).
+//     (gs::row_moments9: 22 VALU with the products folded into the first butterfly stage, the nine totals land in
+//     nine lanes of one register), merged across the tile's blocks with ONE ds_add_f64 per trip, converted once per
+//     gaussian and flushed per batch to HBM as whole 64-byte gradient rows (or into the reference's four gradient
+//     arrays).
 #include "gs_common.h"
 #include "gs_render.h"
 
@@ -30,9 +33,9 @@
 #ifndef GS_ABLATE
 #define GS_ABLATE 0
 #endif
-// Backward batch size: 128 slots keep the block at ~21 KB of LDS (records 6 KB, f64 accumulators 10 KB, lists 4 KB),
-// so the kernel stays VGPR-limited at 6 waves/SIMD; 256 slots (41 KB, 3 blocks/CU) measured 0.76 ms vs 0.57 ms,
-// 64 slots 0.63 ms (twice the barriers).
+// Backward batch size: 128 slots keep the block at 21 KB of LDS (records 4 KB, f64 accumulators 10 KB, lists + third
+// record array 6 KB), i.e. 7 workgroups per CU, matching the 72 VGPRs; 256 slots (41 KB, 3 blocks/CU) measured 0.76 ms
+// vs 0.57 ms when tried, 64 slots 0.63 ms (twice the barriers and per-batch work).
 #ifndef GS_BWD_BATCH
 #define GS_BWD_BATCH 128
 #endif
