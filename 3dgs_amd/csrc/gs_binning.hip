@@ -145,13 +145,15 @@ __global__ __launch_bounds__(kBlock) void tile_ranges32_kernel(const unsigned in
 // index, the first step of each merge pairs i with its mirror image), so virtual +infinity padding above `len`
 // never moves and comparators that touch it can simply be skipped: any list length works without padding stores.
 // Lists up to kLdsSort entries are sorted in LDS, longer ones in place in global memory by the same workgroup.
-constexpr int kLdsSort = 2048;
+constexpr int kLdsSort = 4096;
 
 // kWaveLocal: the buffer is LDS.  Thread t of a wave owns comparators whose operands lie in that wave's own
 // 128-element span whenever the comparator distance is <= 64, and a wave executes its LDS operations in order, so
 // those steps need no workgroup barrier (only a compiler fence); for n2 = 512 that removes 42 of 45 barriers.
-template <bool kWaveLocal, typename Buf>
-__device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int tid) {
+// k_first > 2: the caller has already sorted every aligned run of k_first / 2 entries (the merge levels below k_first
+// are skipped).
+template <bool kWaveLocal, int kThreads = kBlock, typename Buf>
+__device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int tid, int k_first = 2) {
   // a step whose comparators stay inside one wave's span only needs that wave's own earlier LDS writes; a
   // workgroup barrier is required whenever the previous OR the next step crosses waves
   int prev = 1 << 30;  // the loads before the first step were followed by __syncthreads()
@@ -167,11 +169,12 @@ __device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int t
   };
   prev = 0;  // nothing to order before the very first step
   int lh = 0;  // log2(k / 2)
-  for (int k = 2; k <= n2; k <<= 1, ++lh) {
+  while ((2 << lh) < k_first) ++lh;
+  for (int k = k_first; k <= n2; k <<= 1, ++lh) {
     {  // mirror step: comparator distance up to k - 1
       sync(k >> 1);
       const int half = k >> 1;
-      for (int t = tid; t < (n2 >> 1); t += kBlock) {
+      for (int t = tid; t < (n2 >> 1); t += kThreads) {
         const int base = (t >> lh) << (lh + 1), il = t & (half - 1);
         const int lo = base + il, hi = base + k - 1 - il;
         if (hi < len) {
@@ -182,7 +185,7 @@ __device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int t
     }
     for (int j = k >> 2; j > 0; j >>= 1) {
       sync(j);
-      for (int t = tid; t < (n2 >> 1); t += kBlock) {
+      for (int t = tid; t < (n2 >> 1); t += kThreads) {
         const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
         if (hi < len) {
           const unsigned long long a = p[lo], b = p[hi];
@@ -321,11 +324,11 @@ __device__ __forceinline__ void wave_bitonic_sort_f64(double (&v)[E], int lane) 
   }
 }
 
-// false: the tile holds a key that has no order-preserving double (the caller hands the tile to the integer kernel)
+// Loads `len` (<= 64 E) payloads starting at `start` as doubles (padding: +infinity) and sorts them; lane L ends with
+// the entries L*E .. L*E+E-1 of the sorted run.  false: a key has no order-preserving double, nothing was sorted.
 template <int E>
-__device__ __forceinline__ bool sort_tile_in_registers(const unsigned long long *__restrict__ payload, int start, int len,
-                                                       int lane, int *__restrict__ sorted) {
-  double v[E];
+__device__ __forceinline__ bool sort_run_in_registers(const unsigned long long *__restrict__ payload, int start, int len,
+                                                      int lane, double (&v)[E]) {
   bool ok = true;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -339,6 +342,15 @@ __device__ __forceinline__ bool sort_tile_in_registers(const unsigned long long 
   }
   if (!__all(ok)) return false;
   wave_bitonic_sort_f64<E>(v, lane);
+  return true;
+}
+
+// false: the tile holds a key that has no order-preserving double (the caller hands the tile to the integer kernel)
+template <int E>
+__device__ __forceinline__ bool sort_tile_in_registers(const unsigned long long *__restrict__ payload, int start, int len,
+                                                       int lane, int *__restrict__ sorted) {
+  double v[E];
+  if (!sort_run_in_registers<E>(payload, start, len, lane, v)) return false;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int p = lane * E + e;
@@ -352,47 +364,92 @@ constexpr int kWaveSortMax = 1024;  // 16 entries per lane; longer lists take th
 __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const unsigned long long *__restrict__ payload,
                                                                    const int *__restrict__ ranges, int num_tiles,
                                                                    int *__restrict__ sorted, int *__restrict__ long_tiles) {
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (tile >= num_tiles) return;
-  const int start = ranges[tile], len = ranges[tile + 1] - start;
-  if (len <= 0) return;
-  if (len > kWaveSortMax) {
-    if (lane == 0) long_tiles[1 + atomicAdd(&long_tiles[0], 1)] = tile;
-    return;
+  __shared__ int s_handed[4], s_base;
+  const int wave = threadIdx.x >> 6, tile = blockIdx.x * 4 + wave, lane = threadIdx.x & 63;
+  bool done = true;
+  if (tile < num_tiles) {
+    const int start = ranges[tile], len = ranges[tile + 1] - start;
+    if (len > kWaveSortMax) done = false;
+    else if (len <= 0) done = true;
+    else if (len <= 64) done = sort_tile_in_registers<1>(payload, start, len, lane, sorted);
+    else if (len <= 128) done = sort_tile_in_registers<2>(payload, start, len, lane, sorted);
+    else if (len <= 256) done = sort_tile_in_registers<4>(payload, start, len, lane, sorted);
+    else if (len <= 512) done = sort_tile_in_registers<8>(payload, start, len, lane, sorted);
+    else done = sort_tile_in_registers<16>(payload, start, len, lane, sorted);
   }
-  bool done;
-  if (len <= 64) done = sort_tile_in_registers<1>(payload, start, len, lane, sorted);
-  else if (len <= 128) done = sort_tile_in_registers<2>(payload, start, len, lane, sorted);
-  else if (len <= 256) done = sort_tile_in_registers<4>(payload, start, len, lane, sorted);
-  else if (len <= 512) done = sort_tile_in_registers<8>(payload, start, len, lane, sorted);
-  else done = sort_tile_in_registers<16>(payload, start, len, lane, sorted);
-  if (!done && lane == 0) long_tiles[1 + atomicAdd(&long_tiles[0], 1)] = tile;
+  // tiles handed to the workgroup kernels: one atomic per workgroup (a dense scene hands over every tile, and
+  // thousands of atomics on one address cost more than the sort)
+  if (lane == 0) s_handed[wave] = done ? -1 : tile;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int q = 0; q < 4; ++q) n += s_handed[q] >= 0;
+    s_base = n ? atomicAdd(&long_tiles[0], n) : 0;
+  }
+  __syncthreads();
+  if (lane == 0 && !done) {
+    int slot = s_base;
+    for (int q = 0; q < wave; ++q) slot += s_handed[q] >= 0;
+    long_tiles[1 + slot] = tile;
+  }
 }
 
-// Lists longer than kWaveSortMax (listed by the wave kernel): one workgroup each, LDS up to kLdsSort entries, in place
-// in global memory beyond that.
-__global__ __launch_bounds__(kBlock) void tile_depth_sort_kernel(unsigned long long *__restrict__ payload,
-                                                                 const int *__restrict__ ranges, int num_tiles,
-                                                                 int *__restrict__ sorted,
-                                                                 const int *__restrict__ long_tiles) {
-  __shared__ unsigned long long buf[kLdsSort];
+// Lists the wave kernel handed over: one workgroup each.  Up to kLdsSort entries: every wave first sorts one run of
+// kWaveSortMax entries in registers (as the wave kernel does) and parks it in LDS, and only the last one or two merge
+// levels of the network run in LDS (11 or 23 steps instead of 66 or 78) -- unless a key has no double form, then the
+// whole network runs in LDS on the integer keys.  Longer lists: in place in global memory.
+// kWaves = 2: the lists of up to 2 kWaveSortMax entries (128 threads, 16 KB of LDS: ten workgroups per CU -- the
+// register sorts are latency bound, so residency is what counts); kWaves = 4: everything longer.
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned long long *__restrict__ payload,
+                                                                      const int *__restrict__ ranges, int num_tiles,
+                                                                      int *__restrict__ sorted,
+                                                                      const int *__restrict__ long_tiles) {
+  constexpr int kThreads = kWaves * 64, kLds = kWaves * kWaveSortMax;
+  static_assert(kLds <= kLdsSort, "LDS buffer");
+  __shared__ unsigned long long buf[kLds];
+  __shared__ int s_runs_ok;
   const int count = long_tiles[0];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
     const int tile = long_tiles[1 + t];
     const int start = ranges[tile], len = ranges[tile + 1] - start;
+    if (kWaves == 2 ? len > 2 * kWaveSortMax : len <= 2 * kWaveSortMax) continue;  // the other instantiation's tile
     int n2 = 1;
     while (n2 < len) n2 <<= 1;
     __syncthreads();  // buf is reused across iterations
-    if (len <= kLdsSort) {
-      for (int i = tid; i < len; i += kBlock) buf[i] = payload[start + i];
+    if (len <= kLds) {
+      if (tid == 0) s_runs_ok = 1;
       __syncthreads();
-      bitonic_sort_block<true>(buf, len, n2, tid);
-      for (int i = tid; i < len; i += kBlock) sorted[start + i] = (int)(unsigned int)(buf[i] & 0xFFFFFFFFull);
+      const int run_len = min(kWaveSortMax, len - wave * kWaveSortMax);
+      if (len > kWaveSortMax && run_len > 0) {
+        constexpr int E = kWaveSortMax / 64;
+        double v[E];
+        if (sort_run_in_registers<E>(payload, start + wave * kWaveSortMax, run_len, lane, v)) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int p = lane * E + e;
+            if (p < run_len)
+              buf[wave * kWaveSortMax + p] = (unsigned long long)__double_as_longlong(v[e]) ^ 0x8000000000000000ull;
+          }
+        } else if (lane == 0) {
+          s_runs_ok = 0;
+        }
+      }
+      __syncthreads();
+      if (len > kWaveSortMax && s_runs_ok) {
+        bitonic_sort_block<true, kThreads>(buf, len, n2, tid, 2 * kWaveSortMax);
+      } else {
+        __syncthreads();
+        for (int i = tid; i < len; i += kThreads) buf[i] = payload[start + i];
+        __syncthreads();
+        bitonic_sort_block<true, kThreads>(buf, len, n2, tid);
+      }
+      for (int i = tid; i < len; i += kThreads) sorted[start + i] = (int)(unsigned int)(buf[i] & 0xFFFFFFFFull);
     } else {
       unsigned long long *p = payload + start;
-      bitonic_sort_block<false>(p, len, n2, tid);
-      for (int i = tid; i < len; i += kBlock) sorted[start + i] = (int)(unsigned int)(p[i] & 0xFFFFFFFFull);
+      bitonic_sort_block<false, kThreads>(p, len, n2, tid);
+      for (int i = tid; i < len; i += kThreads) sorted[start + i] = (int)(unsigned int)(p[i] & 0xFFFFFFFFull);
     }
   }
 }
@@ -406,8 +463,14 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
   tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
   GS_LAUNCH_CHECK();
   if (max_long > 0) {
-    tile_depth_sort_kernel<<<std::min(max_long, 512), kBlock, 0, st>>>(payload, ranges, num_tiles, sorted_out,
-                                                                       long_tiles);
+    // workgroups beyond the list's length leave at once; ten (16 KB of LDS) resp. five (32 KB) fit on a CU
+    tile_depth_sort_kernel<2><<<std::min(max_long, 10 * 256), 128, 0, st>>>(payload, ranges, num_tiles, sorted_out,
+                                                                            long_tiles);
+    GS_LAUNCH_CHECK();
+    const int max_longer = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(2 * kWaveSortMax));  // cannot be more
+    if (max_longer > 0)
+      tile_depth_sort_kernel<4><<<std::min(max_longer, 5 * 256), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out,
+                                                                                long_tiles);
     GS_LAUNCH_CHECK();
   }
   return GSPLAT_OK;
@@ -456,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void low_words_kernel(const unsigned long l
 // leaves the register kernel above 1024 entries; dense real scenes (thousands per tile) take the global route.
 static long long dense_tile_threshold() {
   static const long long v = [] {
-    const char *e = getenv("GSPLAT_DENSE_TILE_AVG");
+    const char *e = getenv("GSPLAT_DENSE_TILE_AVG");  // average list length above which a radix forward stays radix
     return e ? atoll(e) : 768ll;
   }();
   return v;
@@ -557,11 +620,14 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
                                                           const unsigned long long *__restrict__ pair_counters,
                                                           volatile unsigned long long *pub, unsigned long long ticket) {
   __shared__ int s_part[1024];
+  __shared__ int s_longest;  // the longest tile list: the host picks the next forward's binning route by it
+  if (threadIdx.x == 0) s_longest = 0;
   const int per = (T + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, T);
-  int sum = 0;
-  for (int t = lo; t < hi; ++t) sum += totals[t];
+  int sum = 0, longest = 0;
+  for (int t = lo; t < hi; ++t) { const int v = totals[t]; sum += v; longest = max(longest, v); }
   s_part[threadIdx.x] = sum;
   __syncthreads();
+  if (longest > 0) atomicMax(&s_longest, longest);
   for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
     const int v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
     __syncthreads();
@@ -575,6 +641,7 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
     if (threadIdx.x == 0) {
       pub[0] = ((unsigned long long)(unsigned int)s_part[1023] << 32) | (unsigned long long)(unsigned int)*m_total;
       pub[1] = v;
+      pub[3] = (unsigned long long)s_longest;
       __threadfence_system();
       pub[2] = ticket;
       __threadfence_system();
@@ -587,6 +654,16 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
 
 bool binning_supports_counting_sort(int num_tiles) { return num_tiles <= kBinMaxTiles; }
 bool binning_prefers_radix(size_t S, int num_tiles) { return (long long)S > dense_tile_threshold() * (long long)num_tiles; }
+// Route of the NEXT forward.  Up to dense_tile_threshold() entries per tile on average: counting sort + per-tile
+// sorts, whatever the longest list (a few long lists in a sparse scene are cheaper than two more radix passes over
+// everything).  Denser: still the counting sort as long as every list fits the LDS merge (kLdsSort entries: register-
+// sorted runs + one or two merge levels -- 0.64 ms against 1.06 ms on the 4 M-gaussian scene); one longer list means
+// an in-place global-memory network, and the radix route (depth pre-sort + stable tile sort) is the safer choice.
+// After a radix forward the longest list is not known: stay.
+bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles, long long longest) {
+  if (!binning_prefers_radix(S, num_tiles)) return false;
+  return was_counting_sort ? longest > kLdsSort : true;
+}
 size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 2) * sizeof(int); }
 
 // Phase 1 (needs nothing from the host): per-workgroup offsets and ranges from the histogram rows preprocess_kernel

@@ -27,6 +27,7 @@ size_t binning_temp_bytes(size_t N, size_t S, int num_tiles);
 int scan_counts(int N, const int *counts, int *offsets, void *temp, size_t temp_bytes, hipStream_t st);
 bool binning_supports_counting_sort(int num_tiles);
 bool binning_prefers_radix(size_t S, int num_tiles);
+bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles, long long longest);
 size_t binning_table_bytes(int num_tiles);
 int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
                     const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
@@ -882,7 +883,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;
   }
-  c->dense_route = gs::binning_prefers_radix(S, num_tiles);
+  c->dense_route = gs::binning_next_route_is_radix(sparse, S, num_tiles, (long long)c->h_pub[3]);
   const bool emitted = S <= inst_cap;  // dense route: else grow the instance buffers (synchronises) and emit again
   const void *keys_before = c->keys_a.ptr;
   rc = reserve_instances(c, S, num_tiles);

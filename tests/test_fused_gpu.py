@@ -263,10 +263,10 @@ def test_pack_gradients_global_layout(gpu, scene):
 
 
 def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
-    """More than 768 list entries per tile on average.  The binning route follows the previous forward's density: the
-    first call on a context bins with the counting sort + per-tile kernels (lists > 2048 entries: in-place global
-    network), the second takes the dense route (global stable depth pre-sort + stable tile sort).  Both must match the
-    oracle exactly (lists) / within tolerance (image)."""
+    """More than 768 list entries per tile on average and lists beyond the LDS merge's 4096 entries.  The binning route
+    follows the previous forward: the first call on a context bins with the counting sort + per-tile kernels (lists >
+    4096 entries: in-place global network), the second takes the dense route (global stable depth pre-sort + stable tile
+    sort).  Both must match the oracle exactly (lists) / within tolerance (image)."""
     raster = pkg("raster")
     N, W, H, L = 40000, 64, 48, 0
     params = scene.make_gaussians(N, W, H, L)
@@ -276,7 +276,7 @@ def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
     ctx = raster.RasterContext(N, W, H)
     dp, dc = raster.device_params(params), raster.device_camera(cam)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
-    assert np.diff(ref["ranges"]).max() > 2048 and len(ref["sorted"]) > 768 * (len(ref["ranges"]) - 1)
+    assert np.diff(ref["ranges"]).max() > 4096 and len(ref["sorted"]) > 768 * (len(ref["ranges"]) - 1)
     for route in (0, 0, 1, 2):  # automatic (counting sort first, then radix), then each forced
         ctx.set_binning_route(route)
         fwd = ctx.rasterize_image(dp, dc, c, 0.5, L)
@@ -284,15 +284,16 @@ def test_dense_scene_takes_the_global_depth_presort(gpu, scene, orc):
 
 
 def test_few_long_tile_lists_in_a_sparse_scene(gpu, scene, orc):
-    """Low average list length (per-tile sort kernels) but two hot spots: one tile list above 2048 entries (in-place
-    global-memory network) and one between 1025 and 2048 (LDS workgroup network); the rest sorts in registers."""
+    """Low average list length (per-tile sort kernels) but three hot spots: one tile list above 4096 entries (in-place
+    global-memory network), one between 2049 and 4096 and one between 1025 and 2048 (register-sorted runs merged in
+    LDS by four resp. two waves); the rest sorts in registers."""
     raster = pkg("raster")
-    N, W, H, L = 9500, 256, 144, 0
+    N, W, H, L = 14500, 256, 144, 0
     params = scene.make_gaussians(N, W, H, L)
     params["opacity"][:] = -4.0
     cam = scene.make_camera(W, H)
     rng = np.random.default_rng(4)
-    for lo, hi, (cu, cv) in ((5000, 8000, (40.0, 40.0)), (8000, 9500, (200.0, 100.0))):
+    for lo, hi, (cu, cv) in ((5000, 9600, (40.0, 40.0)), (9600, 11100, (200.0, 100.0)), (11100, 14500, (120.0, 60.0))):
         k = hi - lo
         z = rng.uniform(3.0, 9.0, k)
         u, v = cu + rng.uniform(-2, 2, k), cv + rng.uniform(-2, 2, k)
@@ -305,7 +306,8 @@ def test_few_long_tile_lists_in_a_sparse_scene(gpu, scene, orc):
     fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
     lens = np.diff(ref["ranges"])
-    assert lens.max() > 2048 and ((lens > 1024) & (lens <= 2048)).any() and lens.mean() < 768
+    assert lens.max() > 4096 and ((lens > 1024) & (lens <= 2048)).any() and ((lens > 2048) & (lens <= 4096)).any()
+    assert lens.mean() < 768
     _check_forward(fwd, ref)
 
 
