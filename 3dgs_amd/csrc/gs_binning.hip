@@ -456,8 +456,9 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
 
 // per-tile depth order: one wave per tile in registers; the few lists above kWaveSortMax entries are listed in
 // `long_tiles` (long_tiles[0] must be 0 on entry) and finished by workgroups of the second kernel
+// `longest`: the longest list when the caller knows it (the fused forward reads it with the counts), else < 0
 static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, int num_tiles, size_t S, int *long_tiles,
-                               int *sorted_out, hipStream_t st) {
+                               int *sorted_out, hipStream_t st, long long longest = -1) {
   // tiles the wave kernel may hand over: the long lists and any list with a key that has no double form
   const int max_long = (int)std::min<size_t>((size_t)num_tiles, S);
   tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
@@ -468,7 +469,7 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
                                                                             long_tiles);
     GS_LAUNCH_CHECK();
     const int max_longer = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(2 * kWaveSortMax));  // cannot be more
-    if (max_longer > 0)
+    if (max_longer > 0 && (longest < 0 || longest > 2 * kWaveSortMax))
       tile_depth_sort_kernel<4><<<std::min(max_longer, 5 * 256), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out,
                                                                                 long_tiles);
     GS_LAUNCH_CHECK();
@@ -684,12 +685,12 @@ int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, 
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
                              const int *table, const int *ranges, size_t S, unsigned long long *payload,
-                             int *long_tiles, int *sorted_out, hipStream_t st) {
+                             int *long_tiles, int *sorted_out, long long longest, hipStream_t st) {
   const int T = ntx * nty;
   bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
                                                                              nty, table, ranges, (long long)S, payload);
   GS_LAUNCH_CHECK();
-  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st);
+  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest);
 }
 
 // The emit step on its own: the fused forward launches it with the buffers' capacity BEFORE it waits for the

@@ -35,7 +35,7 @@ int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, 
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
                              const int *table, const int *ranges, size_t S, unsigned long long *payload,
-                             int *long_tiles, int *sorted_out, hipStream_t st);
+                             int *long_tiles, int *sorted_out, long long longest, hipStream_t st);
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
@@ -894,7 +894,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     rc = gs::binning_scatter_and_sort(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(),
                                       c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
                                       c->bin_table.as<int>(), c->ranges.as<int>(), S, c->pay_a.as<unsigned long long>(),
-                                      c->keys_a.as<int>(), c->sorted.as<int>(), st);
+                                      c->keys_a.as<int>(), c->sorted.as<int>(), (long long)c->h_pub[3], st);
   } else {
     rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                               c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
