@@ -550,10 +550,12 @@ __device__ __forceinline__ void for_each_hit_tile(int j, const float *__restrict
   if (r.x1 <= r.x0 || rh <= 0) return;
   if ((r.x1 - r.x0) * rh <= 64) {
     unsigned long long m = hitmask[j];
+    const float inv_rh = 1.0f / (float)rh;  // b / rh for b < 64, rh <= 64: exact through the float reciprocal
     while (m != 0ull) {
       const int b = __builtin_ctzll(m);
       m &= m - 1ull;
-      f((r.y0 + b % rh) * ntx + r.x0 + b / rh);
+      const int col = (int)(((float)b + 0.5f) * inv_rh), row = b - col * rh;
+      f((r.y0 + row) * ntx + r.x0 + col);
     }
   } else {
     const Obb o = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
@@ -599,7 +601,21 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
                                                                   unsigned long long *__restrict__ payload) {
   extern __shared__ int s_cur[];
   const int T = ntx * nty;
-  for (int t = threadIdx.x; t < T; t += kBinThreads) s_cur[t] = ranges[t] + table[(size_t)blockIdx.x * T + t];
+  {  // cursors = tile starts + this workgroup's offsets: all loads of a thread in flight before the first LDS store
+    constexpr int kPer = kBinMaxTiles / kBinThreads;  // 16
+    int start_t[kPer], off_t[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int t = threadIdx.x + k * kBinThreads;
+      start_t[k] = t < T ? ranges[t] : 0;
+      off_t[k] = t < T ? table[(size_t)blockIdx.x * T + t] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int t = threadIdx.x + k * kBinThreads;
+      if (t < T) s_cur[t] = start_t[k] + off_t[k];
+    }
+  }
   __syncthreads();
   // the compacted gaussians of this workgroup's slice of global indices (rank = exclusive scan of the cull mask)
   const int lo = rank[(long long)N * blockIdx.x / kBinBlocks], hi = rank[(long long)N * (blockIdx.x + 1) / kBinBlocks];
