@@ -62,3 +62,16 @@ def test_view_sharded_step_two_ranks_one_gpu(tmp_path):
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()  # views that saw each gaussian
     assert (full[:, -1] == 2).any() and (full[:, -1] == 0).any()
+
+
+def test_split_exchange_on_rccl_one_rank():
+    """The same overlapped exchange on the real backend (nccl = RCCL), one rank: the collectives degenerate to copies
+    but shapes, contiguity and async handles go through the calls of the multi-GPU run (tools/nccl_one_rank.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_one_rank.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "nccl one-rank rehearsal: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
