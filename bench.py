@@ -174,6 +174,13 @@ def main():
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                      "avg_launch_ms": dom_ms},
+        # the HBM-bound kernels either side of the compositing, from the per-stage pass (algorithmic bytes per
+        # gaussian: SURVEY.md 8d / DESIGN.md section 4); not the dominant kernel, reported for completeness
+        "roofline_per_gaussian_kernels": [
+            {"kernel": k, "bound": "hbm", "algorithmic_bytes": int(bpg * M), "avg_launch_ms": round(stages[k][0], 4),
+             "achieved": (bpg * M / (stages[k][0] * 1e-3) / 1e9) if stages[k][0] > 0 else 0.0, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": (bpg * M / (stages[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if stages[k][0] > 0 else 0.0}
+            for k, bpg in (("preprocess", 301), ("preprocess_backward", 560)) if (do_bwd or k == "preprocess")],
         "cpu_baseline": cpu,
         "setup_s": round(gen_s, 1),
     }
