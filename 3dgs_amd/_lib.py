@@ -123,6 +123,7 @@ SIGNATURES = {
                                     ctypes.POINTER(RasterConfig), _F, _I, ctypes.POINTER(ForwardView), _P]),
     "gsplat_backward_pass": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera), _P, _F, _I,
                                   ctypes.POINTER(Gradients), _P]),
+    "gsplat_context_set_render_only": (_I, [_P, _I]),
     "gsplat_context_set_timing": (_I, [_P, _I]),
     "gsplat_context_set_timing_stages": (_I, [_P, ctypes.c_uint]),
     "gsplat_context_get_timing": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), _I]),

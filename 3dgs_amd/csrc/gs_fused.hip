@@ -71,6 +71,7 @@ struct gsplat_context {
   int forced_route = 0;      // gsplat_context_set_binning_route: 0 auto, 1 counting sort, 2 radix sorts
   bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
   bool backward_seen = false, rows_zeroed = false;  // training use: the forward clears grad_rows for the backward
+  bool render_only = false;  // gsplat_context_set_render_only: forwards skip what only a backward would read
   // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
@@ -268,10 +269,12 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   o.hitmask[j] = hm;
   o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
   o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
+  if (o.sigma) {  // null in a render-only context: only the backward and the caller read these four
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { o.sigma[6 * j + k] = sg[k]; o.J[6 * j + k] = J[k]; }
-  o.conic[3 * j] = con[0]; o.conic[3 * j + 1] = con[1]; o.conic[3 * j + 2] = con[2];
-  o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
+    for (int k = 0; k < 6; ++k) { o.sigma[6 * j + k] = sg[k]; o.J[6 * j + k] = J[k]; }
+    o.conic[3 * j] = con[0]; o.conic[3 * j + 1] = con[1]; o.conic[3 * j + 2] = con[2];
+    o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
+  }
   reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
   const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
   o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
@@ -801,8 +804,10 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   int rc = GSPLAT_OK;
   c->mark(0, true, st);
   c->mark(1, false, st);
-  PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), c->sigma.as<float>(), c->conic.as<float>(),
-               c->J.as<float>(), c->rgb.as<float>(), c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
+  const bool ro = c->render_only;
+  PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), ro ? nullptr : c->sigma.as<float>(),
+               ro ? nullptr : c->conic.as<float>(), ro ? nullptr : c->J.as<float>(), ro ? nullptr : c->rgb.as<float>(),
+               c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
                c->hitmask.as<unsigned long long>(), c->pair_counters()};
   // Two binning routes, both exact for any scene; the choice only affects speed, so it follows the LAST forward's
   // density (the first call starts sparse): sparse = LDS counting sort + per-tile depth sort, dense (more than
@@ -908,21 +913,22 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->mark(4, false, st);
   // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
   if (c->rows_zeroed) c->backward_seen = false;  // the last forward's cleared rows were never used: rendering only
-  c->rows_zeroed = c->backward_seen;
+  c->rows_zeroed = c->backward_seen && !ro;
   rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                              c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                              c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
-                             c->blockmasks.as<unsigned short>());
+                             ro ? nullptr : c->blockmasks.as<unsigned short>());
   if (rc) return rc;
   c->mark(4, true, st);
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
-  c->have_forward = true;
+  c->have_forward = !ro;  // a render-only forward leaves nothing for a backward
   if (out) {
     out->num_culled = (size_t)M; out->num_pairs = (size_t)pairs; out->num_splats = S;
     out->mask = c->mask.as<unsigned char>(); out->uv = c->uv_all.as<float>(); out->xyz_c = c->xyz_c_all.as<float>();
     out->compact_to_global = c->c2g.as<int>();
-    out->sigma = c->sigma.as<float>(); out->conic = c->conic.as<float>(); out->J = c->J.as<float>();
-    out->precomputed_rgb = c->rgb.as<float>(); out->radius = c->radius.as<float>();
+    out->sigma = ro ? nullptr : c->sigma.as<float>(); out->conic = ro ? nullptr : c->conic.as<float>();
+    out->J = ro ? nullptr : c->J.as<float>(); out->precomputed_rgb = ro ? nullptr : c->rgb.as<float>();
+    out->radius = c->radius.as<float>();
     out->uv_selected = c->uv.as<float>(); out->xyz_c_selected = c->xyz_c.as<float>();
     out->sorted_gaussians = c->sorted.as<int>();
     out->splat_start_end_idx_by_tile_idx = c->ranges.as<int>();
@@ -1035,6 +1041,13 @@ int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask)
   for (int a = 0; a < gsplat_context::kSlots; ++a) c->harvest(a);
   for (int k = 0; k < gsplat_context::kStages; ++k) { c->stage_ms[k] = 0; c->stage_n[k] = 0; }
   c->timing = stage_mask & ((1u << gsplat_context::kStages) - 1u);
+  return GSPLAT_OK;
+}
+
+int gsplat_context_set_render_only(gsplat_context *c, int enabled) {
+  GS_REQUIRE(c != nullptr, "null context");
+  c->render_only = enabled != 0;
+  if (c->render_only) c->have_forward = false;
   return GSPLAT_OK;
 }
 

@@ -26,6 +26,8 @@ class _DevView:
 
 
 def _view(ptr, shape, typestr, owner):
+    if ptr is None and int(np.prod(shape)) != 0:
+        return None  # an output the library did not produce (render-only context)
     if ptr is None or int(np.prod(shape)) == 0:
         dt = {"<f4": torch.float32, "<i4": torch.int32, "|u1": torch.uint8}[typestr]
         return torch.empty(tuple(shape), dtype=dt, device="cuda")
@@ -81,6 +83,10 @@ class RasterContext:
     def set_binning_route(self, route):
         """0 automatic, 1 LDS counting sort + per-tile depth sort, 2 stable radix sorts (identical results)."""
         check(self._lib.gsplat_context_set_binning_route(self._h, int(route)))
+
+    def set_render_only(self, enabled):
+        """Serving mode: forwards skip the outputs only a backward reads (see gsplat_context_set_render_only)."""
+        check(self._lib.gsplat_context_set_render_only(self._h, int(bool(enabled))))
 
     def set_timing(self, enabled, stages=None):
         """Per-stage HIP-event timing on / off; `stages`: names from STAGES to time only those (each timed stage costs

@@ -134,6 +134,18 @@ def main():
         call_ms.append((time.perf_counter() - ta) * 1e3)
     torch.cuda.synchronize()
     fps = reps / (time.perf_counter() - t1)
+    # the same in a render-only context (serving: nothing kept for a backward)
+    step.ctx.set_render_only(True)
+    reps_ro = max(5, min(args.steps, 100))
+    for _ in range(5):
+        step.ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps_ro):
+        step.ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+    torch.cuda.synchronize()
+    fps_render_only = reps_ro / (time.perf_counter() - t1)
+    step.ctx.set_render_only(False)
     gc.enable()
     if os.environ.get("GSPLAT_BENCH_DEBUG"):
         print("forward-only host ms per call:", " ".join(f"{t:.2f}" for t in call_ms), file=sys.stderr)
@@ -169,7 +181,7 @@ def main():
                    "views_per_step": world, "parallelism": f"view-sharded dp{world}" if world > 1 else "single GPU",
                    "exchange": step.describe_exchange() if world > 1 else "none",
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": fwd["num_pairs"], "scene_seed": scene.SEED},
-        "render_fps_forward_only": fps,
+        "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,

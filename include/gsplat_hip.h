@@ -336,6 +336,11 @@ int gsplat_context_set_binning_route(gsplat_context *ctx, int route);
  * 4 compositing forward, 5 gradient-row memset, 6 compositing backward, 7 per-gaussian backward.
  * gsplat_context_get_timing synchronises the device, writes the per-stage sum of milliseconds and the number
  * of samples since timing was (re)enabled, and returns the number of stages. */
+/* Render-only use (serving): forwards stop writing what only a backward or a training host reads -- Sigma, J, conic,
+ * the evaluated SH colour (those four pointers of gsplat_forward_view come back NULL) and the compositing kernels'
+ * block masks -- and the backward entry points answer "no forward pass recorded" until it is switched off again.
+ * Image, per-pixel counts / transmittance and the sorted lists are unchanged. */
+int gsplat_context_set_render_only(gsplat_context *ctx, int enabled);
 int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
 /* The same for a subset of the stages (bit k of stage_mask = stage k; 0 switches timing off).  Every timed stage
  * costs two event records per call, about 0.7 % of a 1 ms step each: bench.py times only stage 6 inside its timed

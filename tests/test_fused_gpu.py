@@ -400,3 +400,27 @@ def test_config2_forward_only(gpu, scene, orc):
     fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, c["bg"], L)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=16)
     _check_forward(fwd, ref, exact_lists=False)
+
+
+def test_render_only_context(gpu, scene, orc):
+    """gsplat_context_set_render_only: same image, counts and lists; the backward-only outputs come back null and the
+    backward is refused until the mode is switched off."""
+    torch, raster = gpu, pkg("raster")
+    r = _run(torch, scene, "small", 0)
+    ctx, dp, dc, c, L = r["ctx"], r["dp"], r["dc"], scene.CONFIG, r["L"]
+    ref_img, ref_n = r["fwd"]["image"].clone(), r["fwd"]["n"].clone()
+    ref_sorted = r["fwd"]["sorted"].clone()
+    ctx.set_render_only(True)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    assert fwd["sigma"] is None and fwd["J"] is None and fwd["conic"] is None and fwd["rgb"] is None
+    assert torch.equal(fwd["image"], ref_img) and torch.equal(fwd["n"], ref_n) and torch.equal(fwd["sorted"], ref_sorted)
+    W, H = scene.WORKLOADS["small"][1:3]
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    grads = ctx.alloc_gradients(fwd["num_culled"], L)
+    with pytest.raises(Exception):
+        ctx.backward_pass(dp, dc, gi, c["bg"], L, grads)
+    ctx.set_render_only(False)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    assert fwd["sigma"] is not None
+    ctx.backward_pass(dp, dc, gi, c["bg"], L, grads)
+    torch.cuda.synchronize()
