@@ -132,9 +132,13 @@ class Trainer:
         """Mean PSNR over the views at background 0 (TrainerImpl::evaluate, cuda/trainer.cu:263-360)."""
         total, views = 0.0, (views or self.views)
         ctx = self._context_for(self.num_gaussians)
-        for cam, gt in views:
-            fwd = ctx.rasterize_image(dict(self.params), cam, self.cfg, 0.0, self.l_max)
-            total += ops.compute_psnr(fwd["image"], gt, int(cam["height"]), int(cam["width"]))
+        ctx.set_render_only(True)  # nothing here runs a backward
+        try:
+            for cam, gt in views:
+                fwd = ctx.rasterize_image(dict(self.params), cam, self.cfg, 0.0, self.l_max)
+                total += ops.compute_psnr(fwd["image"], gt, int(cam["height"]), int(cam["width"]))
+        finally:
+            ctx.set_render_only(False)
         return total / len(views)
 
     # ------------------------------------------------------------------ policy steps
