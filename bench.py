@@ -146,6 +146,33 @@ def main():
     torch.cuda.synchronize()
     fps_render_only = reps_ro / (time.perf_counter() - t1)
     step.ctx.set_render_only(False)
+
+    # ---- the whole training iteration (SURVEY 8f rows f1 + f2 around the path): rasterize -> fused L1+SSIM loss ->
+    # backward with the uv intermediates -> masked in-place Adam; outside the timed region, last (it moves the parameters)
+    train_ms = None
+    if do_bwd and os.environ.get("GSPLAT_BENCH_TRAIN_STEP", "1") != "0":
+        ops = importlib.import_module("3dgs_amd.ops")
+        opt_mod = importlib.import_module("3dgs_amd.optimizer")
+        target = step.ctx.rasterize_image(dp, dc, cfg, 0.0, L)["image"].clone()
+        opt = opt_mod.AdamOptimizer(dp, L, scene_extent=5.0)
+        tgrads = step.ctx.alloc_gradients(N, L, intermediates=True)
+        loss_grad = torch.empty(H, W, 3, device=dev)
+
+        def train_step(it):
+            f = step.ctx.rasterize_image(dp, dc, cfg, 0.0, L)
+            ops.fused_loss(f["image"], target, H, W, 0.2, loss_grad, blocking=False)
+            step.ctx.backward_pass(dp, dc, loss_grad, 0.0, L, tgrads)
+            opt.step(it, f, tgrads)
+
+        for it in range(10):
+            train_step(it)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps_tr = max(5, min(args.steps, 50))
+        for it in range(reps_tr):
+            train_step(10 + it)
+        torch.cuda.synchronize()
+        train_ms = (time.perf_counter() - t1) / reps_tr * 1e3
     gc.enable()
     if os.environ.get("GSPLAT_BENCH_DEBUG"):
         print("forward-only host ms per call:", " ".join(f"{t:.2f}" for t in call_ms), file=sys.stderr)
@@ -182,6 +209,7 @@ def main():
                    "exchange": step.describe_exchange() if world > 1 else "none",
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": fwd["num_pairs"], "scene_seed": scene.SEED},
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
+        "train_step_ms_with_loss_and_adam": train_ms,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
