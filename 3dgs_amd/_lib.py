@@ -74,6 +74,7 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
+ABI_VERSION = 2  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -140,8 +141,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # cheap when the library is fresh (mtime scan); on a box without hipcc a prebuilt, up-to-date library is used as is
+    try:
         build()
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(LIB_PATH):
+            raise
     # torch owns device memory and ships its own HIP runtime: import it first so that this library binds to the
     # same runtime instance (two runtimes in one process do not see each other's allocations)
     import torch  # noqa: F401
@@ -150,6 +155,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync
         fn.restype = res
         fn.argtypes = args
+    got = lib.gsplat_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libgsplat_hip.so reports ABI {got}, this binding expects {ABI_VERSION}: stale library")
     _lib = lib
     return lib
 

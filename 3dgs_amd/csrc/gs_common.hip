@@ -73,7 +73,7 @@ HostWords &host_words() { return g_words; }
 
 extern "C" {
 const char *gsplat_last_error(void) { return gs::g_err; }
-int gsplat_abi_version(void) { return 1; }
+int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
 int gsplat_release_scratch(void) {
   (void)hipDeviceSynchronize();
   for (int i = 0; i < gs::SCR_NUM; ++i) gs::g_scratch[i].release();

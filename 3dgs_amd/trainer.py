@@ -82,7 +82,8 @@ class Trainer:
     def train_step(self, cam, gt_image):
         c = self.cfg
         it = self.iter
-        bg = (it % 255) / 255.0 if (c["use_background"] and it < c["use_background_end"]) else 0.0
+        # cuda/trainer.cu:1341-1343: the background cycles for the whole run (use_background_end is parsed but never read)
+        bg = (it % 255) / 255.0 if c["use_background"] else 0.0
         if it % c["add_sh_band_interval"] == 0 and it >= c["add_sh_band_interval"]:
             self.add_sh_band()
         ctx = self._context_for(self.num_gaussians)
@@ -252,7 +253,14 @@ class Trainer:
         self.opt.grad_accum_dur = ops.gather_rows(acc[1].view(torch.float32), order).view(torch.int32)
 
     def save_to_ply(self, path):
+        """TrainerImpl::save_to_ply (cuda/trainer.cu:1166-1196): the device quaternion (kernel order w,x,y,z) is
+        memcpy'd into Eigen's (x,y,z,w) storage and normalised, so the file's rot_0..3 are the unit quaternion in
+        DEVICE order.  gsplat_save_ply writes its (w,x,y,z) input as (x,y,z,w) (Gaussians' Eigen convention), so the
+        columns are pre-rotated here to land unchanged."""
         from . import dataset
         p = {k: v.detach().cpu().numpy() for k, v in self.params.items()}
-        dataset.save_ply(path, p["xyz"], p["rgb"], p["opacity"], p["scale"], p["quaternion"],
+        q = p["quaternion"].astype(np.float32)
+        norm = np.sqrt((q.astype(np.float64) ** 2).sum(1, keepdims=True))
+        q = (q / np.where(norm > 0, norm, 1.0)).astype(np.float32)
+        dataset.save_ply(path, p["xyz"], p["rgb"], p["opacity"], p["scale"], np.roll(q, 1, axis=1),
                          p["sh"].reshape(len(p["xyz"]), -1) if self.l_max > 0 else None)

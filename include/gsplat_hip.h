@@ -46,7 +46,9 @@ extern "C" {
 
 /* Human-readable text for the last error raised on the calling thread. */
 const char *gsplat_last_error(void);
-/* Library ABI version (bumped when a signature changes). */
+/* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
+ * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
+#define GSPLAT_ABI_VERSION 2
 int gsplat_abi_version(void);
 /* Frees library-owned scratch memory of the current device. */
 int gsplat_release_scratch(void);

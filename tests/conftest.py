@@ -37,7 +37,7 @@ def gpu():
     import torch
     assert torch.cuda.is_available(), "these tests need a GPU"
     lib = pkg("_lib").load()
-    assert lib.gsplat_abi_version() >= 1
+    assert lib.gsplat_abi_version() == pkg("_lib").ABI_VERSION
     return torch
 
 

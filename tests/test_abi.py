@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gsplat_hip.h but not exported"
     assert set(names) == set(lib_mod.SIGNATURES), "python binding and header disagree"
-    assert lib.gsplat_abi_version() == 1
+    assert lib.gsplat_abi_version() == lib_mod.ABI_VERSION  # checked by load() too: a stale prebuilt library raises
     assert lib.gsplat_packed_gradient_width(3) == 60
     assert lib.gsplat_packed_gradient_width(0) == 15
 

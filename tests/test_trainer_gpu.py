@@ -76,7 +76,7 @@ def test_training_loop_with_density_control(gpu, scene, tmp_path):
     init = ops.initialize_gaussians(pts, col)
     cfg = dict(num_iters=400, add_sh_band_interval=150, max_sh_band=2, adaptive_control_start=50,
                adaptive_control_interval=50, adaptive_control_end=350, reset_opacity_start=10 ** 9,
-               uv_grad_threshold=1e-6, max_gaussians=20000, use_background_end=0)
+               uv_grad_threshold=1e-6, max_gaussians=20000, use_background=False)
     t = trainer_mod.Trainer(init, views, cfg, scene_extent=5.0, seed=3)
     psnr0 = t.evaluate()
     hist = t.train(400)
@@ -93,6 +93,14 @@ def test_training_loop_with_density_control(gpu, scene, tmp_path):
     t.save_to_ply(tmp_path / "trained.ply")
     head = (tmp_path / "trained.ply").read_bytes().split(b"end_header\n", 1)[0].decode()
     assert f"element vertex {t.num_gaussians}" in head and "f_rest_23" in head
+    # rot_0..3 = the unit quaternion in device order (w,x,y,z), as TrainerImpl::save_to_ply writes it
+    # (cuda/trainer.cu:1166-1196: memcpy into Eigen storage, normalise)
+    body = (tmp_path / "trained.ply").read_bytes().split(b"end_header\n", 1)[1]
+    rows = np.frombuffer(body, np.float32).reshape(t.num_gaussians, 17 + 24)
+    q = t.params["quaternion"].cpu().numpy().astype(np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    assert np.allclose(rows[:, -4:], q, atol=1e-6)
+    assert np.allclose(rows[:, :3], t.params["xyz"].cpu().numpy())
 
 
 def test_reset_opacity_and_sort(gpu, scene):

@@ -21,7 +21,7 @@ init = ops.initialize_gaussians(pts, col)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 cfg = dict(num_iters=iters, add_sh_band_interval=500, max_sh_band=2, adaptive_control_start=100,
            adaptive_control_interval=100, adaptive_control_end=iters - 200, reset_opacity_start=10 ** 9,
-           uv_grad_threshold=1e-6, max_gaussians=400_000, use_background_end=0)
+           uv_grad_threshold=1e-6, max_gaussians=400_000, use_background=False)
 t = trainer_mod.Trainer(init, views, cfg, scene_extent=5.0, seed=3)
 p0 = t.evaluate()
 torch.cuda.synchronize(); t0 = time.perf_counter()
