@@ -106,7 +106,8 @@ SIGNATURES = {
     "gsplat_compute_psnr": (_I, [_P, _P, _I, _I, ctypes.POINTER(ctypes.c_float), _P]),
     "gsplat_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P]),
     "gsplat_optimizer_step": (_I, [_P, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
-    "gsplat_optimizer_step_packed": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _P]),
+    "gsplat_optimizer_step_packed": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "gsplat_pack_uv_grad_norm": (_I, [_P, ctypes.POINTER(Gradients), _I, _P, _P]),
     "gsplat_initialize_gaussians": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gsplat_knn_mean_distance": (_I, [_P, _I, _I, _P, _P]),
     "gsplat_compute_morton_codes": (_I, [_I, _P, _F, _F, _F, _F, _F, _F, _P, _P]),

@@ -516,6 +516,21 @@ __global__ __launch_bounds__(kBlock) void scatter_rgb_rows_kernel(const unsigned
   rgb[e] = mask[i] ? rows[(size_t)rank_of[i] * 16 + k] : 0.0f;
 }
 
+// |grad_uv| of this view in global gaussian order (0 where culled): the densification statistic of a view-sharded step
+__global__ __launch_bounds__(kBlock) void pack_uv_norm_kernel(const unsigned char *__restrict__ mask,
+                                                              const int *__restrict__ rank_of, int N,
+                                                              const float *__restrict__ grad_uv,
+                                                              float *__restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  float val = 0.0f;
+  if (mask[i]) {
+    const float2 g = reinterpret_cast<const float2 *>(grad_uv)[rank_of[i]];
+    val = sqrtf(g.x * g.x + g.y * g.y);
+  }
+  out[i] = val;
+}
+
 // Split exchange: the 12 direction-independent columns (SUM all-reduce) and this view's g_rgb (all-gather).
 __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char *__restrict__ mask,
                                                             const int *__restrict__ rank_of, int N,
@@ -674,6 +689,18 @@ int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads
   }
   pack_split_kernel<<<gs::div_up((long long)num_gaussians, kBlock), kBlock, 0, (hipStream_t)stream>>>(
       c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, *grads, common, rgb);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_pack_uv_grad_norm(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians, float *uv_norm,
+                             void *stream) {
+  GS_REQUIRE(c && grads, "null argument struct");
+  GS_REQUIRE(c->have_forward && num_gaussians == c->N, "does not match the recorded forward");
+  GS_REQUIRE_DEV(uv_norm);
+  GS_REQUIRE_DEV(grads->grad_uv);  // backward must have been asked for this intermediate
+  pack_uv_norm_kernel<<<gs::div_up((long long)num_gaussians, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+      c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, grads->grad_uv, uv_norm);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

@@ -247,12 +247,17 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(int rows, GroupTabl
   const float g = kPacked ? packed[(size_t)r * width + G.packed_column + c] : G.grad[i];
   const long long o = row * stride + c;
   adam_update(&G.param[o], &G.exp_avg[o], &G.exp_avg_sq[o], g, G.lr, b1, b2, eps, bias1, bias2);
-  if (!kPacked && k == 0 && c == 0) {  // densification statistics, cuda/trainer.cu:1136-1157
-    if (uv_accum) {
-      const float u = grad_uv[2 * r], v = grad_uv[2 * r + 1];
-      uv_accum[row] += sqrtf(u * u + v * v);
+  if (k == 0 && c == 0) {  // densification statistics, cuda/trainer.cu:1136-1157
+    if (kPacked) {  // grad_uv = the all-reduced sum over the step's views of |grad_uv| [N]; one count per view
+      if (uv_accum) uv_accum[row] += grad_uv[r];
+      if (accum_dur) accum_dur[row] += (int)packed[(size_t)r * width + width - 1];
+    } else {
+      if (uv_accum) {
+        const float u = grad_uv[2 * r], v = grad_uv[2 * r + 1];
+        uv_accum[row] += sqrtf(u * u + v * v);
+      }
+      if (accum_dur) accum_dur[row] += 1;
     }
-    if (accum_dur) accum_dur[row] += 1;
   }
 }
 
@@ -391,7 +396,8 @@ int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gs
 }
 
 int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int width, const gsplat_adam_group *groups,
-                                 int n_groups, float b1, float b2, float eps, float bias1, float bias2, void *stream) {
+                                 int n_groups, float b1, float b2, float eps, float bias1, float bias2,
+                                 const float *uv_norm_sum, float *uv_grad_accum, int *grad_accum_dur, void *stream) {
   GS_REQUIRE(num_gaussians >= 0, "negative gaussian count");
   GroupTable t;
   int rc = build_group_table(groups, n_groups, true, &t, __func__);
@@ -400,10 +406,12 @@ int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int wid
     GS_REQUIRE(groups[k].packed_column + groups[k].stride <= width - 1, "group columns exceed the packed row");
   if (num_gaussians == 0) return GSPLAT_OK;
   GS_REQUIRE_DEV(packed);
+  if (uv_grad_accum) { GS_REQUIRE_DEV(uv_grad_accum); GS_REQUIRE_DEV(uv_norm_sum); }
+  if (grad_accum_dur) GS_REQUIRE_DEV(grad_accum_dur);
   GS_REQUIRE((long long)num_gaussians * t.start[t.n] < (1ll << 31), "too many parameters for one launch");
   const long long blocks = group_blocks(&t, num_gaussians);
   optimizer_step_kernel<true><<<(unsigned int)blocks, 256, 0, (hipStream_t)stream>>>(
-      num_gaussians, t, nullptr, packed, width, b1, b2, eps, bias1, bias2, nullptr, nullptr, nullptr);
+      num_gaussians, t, nullptr, packed, width, b1, b2, eps, bias1, bias2, uv_norm_sum, uv_grad_accum, grad_accum_dur);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

@@ -78,87 +78,155 @@ class ViewShardedStep:
     one 3-float g_rgb slot per rank (12 + 3*world floats instead of 12 + 3*n_coeffs = 60 at SH degree 3), and one
     extra row with every rank's camera position; the SH-coefficient gradients sum_r g_rgb^r x Y(dir^r) are rebuilt
     locally afterwards (gsplat_unpack_gradients_factored).  Still ONE all-reduce per step.
-    exchange="full": all-reduce the complete packed[N, 12+3*n_coeffs] rows.
+    exchange="full": all-reduce the complete packed[N, 12+3*n_coeffs] rows (the north star's single all-reduce).
+
+    with_uv_norm=True (training): the all-reduced buffer carries N more floats, the per-view |grad_uv| in global
+    order (gsplat_pack_uv_grad_norm), so that after the exchange `uv_norm_sum[N]` holds the sum over the step's views:
+    what the densification statistics of cuda/trainer.cu:1136-1157 need on a view-sharded step.  Same collective,
+    no extra launch on the wire.
     """
 
-    def __init__(self, params, l_max, width, height, config, bg, exchange="split"):
+    def __init__(self, params, l_max, width, height, config, bg, exchange="split", with_uv_norm=False, ctx=None):
         from . import raster
         self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
-        self.N = int(params["xyz"].shape[0])
-        self.ctx = raster.RasterContext(self.N, width, height)
-        self.width_cols = raster.packed_gradient_width(l_max)
+        self.N = N = int(params["xyz"].shape[0])
+        self.ctx = ctx if ctx is not None else raster.RasterContext(N, width, height)
+        self.width_cols = wc = raster.packed_gradient_width(l_max)
         dev = params["xyz"].device
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        if exchange not in ("split", "factored", "full"):
+            raise ValueError(f"unknown exchange {exchange!r}")
         self.exchange = exchange
-        self.packed = torch.empty(self.N, self.width_cols, dtype=torch.float32, device=dev)
+        self.with_uv_norm = bool(with_uv_norm)
+        tail = N if with_uv_norm else 0
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.uv_norm_sum = None
+        # the buffer that goes through the all-reduce is flat: rows first, then (training) the N uv norms
+        if exchange == "full":
+            self._reduce_buf = z(N * wc + tail)
+            self.packed = self._reduce_buf[:N * wc].view(N, wc)
+        else:
+            self.packed = torch.empty(N, wc, dtype=torch.float32, device=dev)
         self.fw = raster.factored_gradient_width(self.world)
-        self.factored = torch.zeros(self.N + 1, self.fw, dtype=torch.float32, device=dev) if exchange == "factored" \
-            else None
+        self.factored = None
+        if exchange == "factored":
+            self._reduce_buf = z((N + 1) * self.fw + tail)
+            self.factored = self._reduce_buf[:(N + 1) * self.fw].view(N + 1, self.fw)
         self._rgb_gather = None
         if exchange == "split":
-            self.common = torch.zeros(self.N, 12, dtype=torch.float32, device=dev)
-            self.rgb = torch.zeros(self.N + 1, 3, dtype=torch.float32, device=dev)          # row N: campos
-            self.rgb_all = torch.zeros(self.world, self.N + 1, 3, dtype=torch.float32, device=dev)
+            self._reduce_buf = z(N * 12 + tail)
+            self.common = self._reduce_buf[:N * 12].view(N, 12)
+            self.rgb = z((N + 1) * 3).view(N + 1, 3)          # row N: campos
+            self.rgb_all = z(self.world * (N + 1) * 3).view(self.world, N + 1, 3)
+        if with_uv_norm:
+            self.uv_norm_sum = self._reduce_buf[self._reduce_buf.numel() - N:]
         # capacity N: never reallocated
-        self.grads = self.ctx.alloc_gradients(self.N, l_max)
-        self.grads["precompute_rgb"] = torch.empty(self.N, 3, dtype=torch.float32, device=dev)
+        self.grads = self.ctx.alloc_gradients(N, l_max)
+        self.grads["precompute_rgb"] = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        if with_uv_norm:
+            self.grads["uv"] = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        self._campos_of = None  # the camera whose position is already in the exchange buffers
+        self._blind = False     # this rank's view saw no gaussian in the current step
 
     def describe_exchange(self):
         mb = lambda t: f"{t.numel() * 4 / 1e6:.0f} MB"
         if self.exchange == "split":
-            return f"split: all-reduce of {mb(self.common)} + all-gather of {mb(self.rgb)} per rank"
-        return f"{self.exchange}: one all-reduce of {mb(self.factored if self.exchange == 'factored' else self.packed)}"
+            return f"split: all-reduce of {mb(self._reduce_buf)} + all-gather of {mb(self.rgb)} per rank"
+        return f"{self.exchange}: one all-reduce of {mb(self._reduce_buf)}"
 
     def exchange_gradients(self, cam):
-        """Scatter this rank's compacted gradients to global order, sum over ranks, leave the result in self.packed."""
+        """Scatter this rank's compacted gradients to global order, sum over ranks, leave the result in self.packed
+        (and, with_uv_norm, self.uv_norm_sum)."""
+        N = self.N
+        if self._blind:  # nothing in view on this rank: exact zeros, but every collective is still joined
+            self._reduce_buf.zero_()
+        elif self.with_uv_norm:
+            self.raster.pack_uv_grad_norm(self.ctx, self.grads, N, self.uv_norm_sum)
         if self.exchange == "split":
             gather = self._rgb_gather  # started by step() behind the per-gaussian backward, or None
             self._rgb_gather = None
-            if gather is None:
-                self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, self.rgb)
+            if self._blind:
+                if gather is None:
+                    self.rgb[:N].zero_()
+                    self._set_campos(cam)
+                    gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+            elif gather is None:
+                self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, self.rgb)
                 self._set_campos(cam)
                 gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
             else:
-                self.raster.pack_gradients_split(self.ctx, self.grads, self.N, self.common, None)
-            reduce = dist.all_reduce(self.common, op=dist.ReduceOp.SUM, async_op=True)
+                self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, None)
+            reduce = dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM, async_op=True)
             # the SH columns only need the gathered g_rgb: rebuild them while the all-reduce is in flight
             gather.wait()
-            self.raster.unpack_gradients_split(self.params["xyz"], None, self.rgb_all, 3 * (self.N + 1), self.l_max,
-                                               self.N, self.world, self.packed)
+            self.raster.unpack_gradients_split(self.params["xyz"], None, self.rgb_all, 3 * (N + 1), self.l_max,
+                                               N, self.world, self.packed)
             reduce.wait()
-            self.raster.unpack_gradients_split(None, self.common, None, 0, self.l_max, self.N, self.world, self.packed)
+            self.raster.unpack_gradients_split(None, self.common, None, 0, self.l_max, N, self.world, self.packed)
         elif self.exchange == "factored":
             f = self.factored
-            self.raster.pack_gradients_factored(self.ctx, self.grads, self.N, self.rank, self.world, f)
-            f[self.N].zero_()
-            f[self.N, 12 + 3 * self.rank: 15 + 3 * self.rank] = torch.as_tensor(
-                [float(c) for c in cam["campos"]], dtype=torch.float32, device=f.device)
-            all_reduce_gradients(f)
-            self.raster.unpack_gradients_factored(self.params["xyz"], f[self.N, 12:], f, self.l_max, self.N,
+            if not self._blind:
+                self.raster.pack_gradients_factored(self.ctx, self.grads, N, self.rank, self.world, f)
+            f[N].zero_()
+            f[N, 12 + 3 * self.rank: 15 + 3 * self.rank] = self._campos_tensor(cam)
+            all_reduce_gradients(self._reduce_buf)
+            self.raster.unpack_gradients_factored(self.params["xyz"], f[N, 12:], f, self.l_max, N,
                                                   self.world, self.packed)
         else:
-            self.ctx.pack_gradients_global(self.grads, self.l_max, self.N, self.packed)
-            all_reduce_gradients(self.packed)
+            if not self._blind:
+                self.ctx.pack_gradients_global(self.grads, self.l_max, N, self.packed)
+            all_reduce_gradients(self._reduce_buf)
         return self.packed
 
-    def _set_campos(self, cam):
-        self.rgb[self.N] = torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32,
-                                           device=self.rgb.device)
+    def _campos_tensor(self, cam):
+        dev_pos = cam.get("campos_dev")  # raster.device_camera uploads it once per view
+        if dev_pos is not None:
+            return dev_pos
+        return torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32, device=self.packed.device)
 
-    def step(self, cam, grad_image):
+    def _set_campos(self, cam):
+        if self._campos_of is cam:  # same view as the last step (the benchmark): already in place
+            return
+        self.rgb[self.N] = self._campos_tensor(cam)
+        self._campos_of = cam
+
+    def step(self, cam, grad_image=None, grad_fn=None, bg=None):
+        """One view-sharded step.  grad_image: dL/dimage [H,W,3]; or grad_fn(fwd) -> dL/dimage computed from this
+        rank's rendering (the training loop's loss).  Returns the forward dict (None when nothing was in view)."""
+        bg = self.bg if bg is None else bg
         overlap = self.world > 1 and self.exchange == "split"
         if overlap:
-            self._set_campos(cam)  # a small host-to-device copy: issue it before the GPU has work queued
-        fwd = self.ctx.rasterize_image(self.params, cam, self.config, self.bg, self.l_max)
-        if overlap:
-            # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
-            self.ctx.backward_render(grad_image, self.bg, self.rgb)
-            self._rgb_gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
-            self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
-        else:
-            self.ctx.backward_pass(self.params, cam, grad_image, self.bg, self.l_max, self.grads)
+            self._set_campos(cam)  # device-to-device (or cached): issued before the GPU has work queued
+        self._blind = False
+        try:
+            fwd = self.ctx.rasterize_image(self.params, cam, self.config, bg, self.l_max)
+        except Exception as e:  # no gaussian in view: the reference warns and skips the view (cuda/trainer.cu:1352)
+            if getattr(e, "code", None) != -5:
+                raise
+            self._blind, fwd = True, None
+        if not self._blind:
+            if grad_fn is not None:
+                grad_image = grad_fn(fwd)
+            if overlap:
+                # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
+                self.ctx.backward_render(grad_image, bg, self.rgb)
+                self._rgb_gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+                self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
+            else:
+                self.ctx.backward_pass(self.params, cam, grad_image, bg, self.l_max, self.grads)
         if self.world > 1:
             self.exchange_gradients(cam)
         return fwd
+
+    def local_packed(self, cam):
+        """Single-process use (world 1): this view's gradients in the packed global-order layout, no collective."""
+        if self._blind:
+            self._reduce_buf.zero_()
+            self.packed.zero_()
+            return self.packed
+        if self.with_uv_norm:
+            self.raster.pack_uv_grad_norm(self.ctx, self.grads, self.N, self.uv_norm_sum)
+        self.ctx.pack_gradients_global(self.grads, self.l_max, self.N, self.packed)
+        return self.packed

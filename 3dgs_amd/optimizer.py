@@ -82,10 +82,15 @@ class AdamOptimizer:
             self.uv_grad_accum.data_ptr() if uv is not None else None,
             self.grad_accum_dur.data_ptr() if uv is not None else None, _stream()))
 
-    def step_packed(self, it, packed):
-        """All-reduced packed rows [N, width] (sum over the views of the step)."""
+    def step_packed(self, it, packed, uv_norm_sum=None):
+        """All-reduced packed rows [N, width] (sum over the views of the step).  uv_norm_sum [N]: the all-reduced
+        per-view |grad_uv| (ViewShardedStep(with_uv_norm=True)); when given, the densification statistics are updated
+        once per view that saw the gaussian, as W single-view steps of the reference would."""
         assert packed.shape[1] == self.width and packed.is_contiguous()
         b1c, b2c = self.bias_corrections(it)
         arr = self._groups(it)
-        check(_lib.load().gsplat_optimizer_step_packed(packed.data_ptr(), packed.shape[0], self.width, arr,
-                                                       len(self.names), B1, B2, EPS, b1c, b2c, _stream()))
+        stats = uv_norm_sum is not None
+        check(_lib.load().gsplat_optimizer_step_packed(
+            packed.data_ptr(), packed.shape[0], self.width, arr, len(self.names), B1, B2, EPS, b1c, b2c,
+            uv_norm_sum.data_ptr() if stats else None, self.uv_grad_accum.data_ptr() if stats else None,
+            self.grad_accum_dur.data_ptr() if stats else None, _stream()))

@@ -48,6 +48,7 @@ def device_camera(cam, device="cuda"):
     out = dict(cam)
     out["view"] = torch.as_tensor(np.asarray(cam["view"], np.float32)).to(device)
     out["proj"] = torch.as_tensor(np.asarray(cam["proj"], np.float32)).to(device)
+    out["campos_dev"] = torch.as_tensor(np.asarray(cam["campos"], np.float32)).to(device)  # for the exchange step
     return out
 
 
@@ -219,6 +220,14 @@ def pack_gradients_split(ctx, grads, num_gaussians, common, rgb):
     gs = RasterContext._grad_struct(grads)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     check(_lib.load().gsplat_pack_gradients_split(ctx._h, ctypes.byref(gs), int(num_gaussians), _ptr(common), _ptr(rgb), st))
+
+
+def pack_uv_grad_norm(ctx, grads, num_gaussians, uv_norm):
+    """This view's |grad_uv| in global gaussian order (0 where culled): gsplat_pack_uv_grad_norm."""
+    gs = RasterContext._grad_struct(grads)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_lib.load().gsplat_pack_uv_grad_norm(ctx._h, ctypes.byref(gs), int(num_gaussians), _ptr(uv_norm), st))
+    return uv_norm
 
 
 def unpack_gradients_split(xyz, common, rgb_all, rank_stride, l_max, num_gaussians, world, packed):

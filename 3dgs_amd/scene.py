@@ -99,6 +99,15 @@ def make_gaussians(num, width, height, l_max, seed=SEED):
     return dict(xyz=xyz, rgb=rgb, sh=sh, opacity=opacity, scale=scale, quaternion=quaternion)
 
 
+def cull_half(params, seed=SEED):
+    """About half of the gaussians moved behind the camera (z -> -z), chosen per index by the counter-based generator:
+    culled and visible rows interleave at random, as in a real training view, instead of the benchmark scene's M = N."""
+    out = {k: v.copy() for k, v in params.items()}
+    behind = uniform24(seed, 70, len(out["xyz"])) < 0.5
+    out["xyz"][behind, 2] *= -1.0
+    return out
+
+
 def make_grad_image(width, height, seed=SEED):
     g = (uniform24(seed, 60, 3 * width * height) * 2.0 - 1.0) / (3.0 * width * height)
     return g.reshape(height, width, 3).astype(np.float32)
@@ -115,4 +124,7 @@ WORKLOADS = {
     # not a BASELINE config: 4x the density of config3 (~1700 list entries per tile), exercises the dense-scene
     # binning route and the long-list behaviour of the compositing kernels
     "dense4m": (4_000_000, 1920, 1080, 3, True),
+    # not a BASELINE config: config3 with about half of the gaussians culled, interleaved (cull_half): the
+    # per-gaussian kernels' non-consecutive-row paths, which M = N never takes
+    "config3_halfculled": (1_000_000, 1920, 1080, 3, True),
 }

@@ -13,8 +13,10 @@ import math
 
 import numpy as np
 import torch
+import torch.distributed as tdist
 
 from . import ops, raster
+from .dist import ViewShardedStep
 from .optimizer import AdamOptimizer, DEFAULT_LR
 
 GROUPS = ("xyz", "rgb", "sh", "opacity", "scale", "quaternion")
@@ -32,13 +34,35 @@ def _logit(p):
     return math.log(p) - math.log(1.0 - p)
 
 
+def draw_view_indices(rng, iteration, world, num_views):
+    """View indices of one iteration, one per rank, identical on every rank that shares the generator's seed.  The
+    reference walks the first two images in order and then draws uniformly (cuda/trainer.cu:1438-1444); with W ranks
+    an iteration consumes W consecutive draws of that sequence (rank r trains on the r-th)."""
+    draws = []
+    for k in range(world):
+        g = iteration * world + k
+        draws.append(g if g < 2 else int(rng.integers(0, num_views)))
+    return [d % num_views for d in draws]
+
+
 class Trainer:
     """params: dict of device tensors (xyz rgb opacity scale quaternion, optionally sh) as gsplat_initialize_gaussians
     returns them; views: list of (camera dict for raster.device_camera, ground-truth image tensor [H,W,3] on device)."""
 
-    def __init__(self, params, views, config=None, scene_extent=1.0, seed=0):
+    def __init__(self, params, views, config=None, scene_extent=1.0, seed=0, exchange="split"):
+        """With an initialised torch.distributed group of W > 1 ranks the loop is view-sharded: every
+        rank holds the same parameters and the same seed, one iteration = W training views (rank r takes the r-th of
+        the iteration's W draws), the per-gaussian gradients and |grad_uv| are summed over the ranks
+        (ViewShardedStep) and every rank applies the identical packed optimizer step and density control, so the
+        replicas stay bit-identical without ever exchanging parameters."""
         self.cfg = dict(DEFAULT_CONFIG, **(config or {}))
         self.views = views
+        self.world = tdist.get_world_size() if tdist.is_initialized() else 1
+        self.rank = tdist.get_rank() if tdist.is_initialized() else 0
+        self.exchange = exchange
+        self._sharded = None  # (key, ViewShardedStep) for the current gaussian count / SH degree
+        self._grad_image = {}  # (H, W) -> dL/dimage buffer, allocated once per image size
+        self._grads = None     # (capacity, l_max, dict): per-view gradient arrays, reused across iterations
         self.scene_extent = float(scene_extent)
         self.seed = int(seed)
         self.rng = np.random.default_rng(seed)
@@ -63,6 +87,7 @@ class Trainer:
 
     def _new_optimizer(self, moments):
         """Fresh AdamOptimizer over the current parameter tensors; `moments` = (exp_avg, exp_avg_sq) dicts to adopt."""
+        self._sharded = None  # the parameter tensors were replaced: the exchange step binds to the new ones
         p = dict(self.params)
         if self.l_max == 0:
             p.pop("sh")
@@ -79,7 +104,22 @@ class Trainer:
         return self.ctx
 
     # ------------------------------------------------------------------ one iteration (cuda/trainer.cu:1338-1362)
-    def train_step(self, cam, gt_image):
+    def _grad_image_for(self, H, W, device):
+        buf = self._grad_image.get((H, W))
+        if buf is None:
+            buf = self._grad_image[(H, W)] = torch.empty(H, W, 3, dtype=torch.float32, device=device)
+        return buf
+
+    def _gradients_for(self, ctx, m):
+        """Per-view gradient arrays in compacted order: allocated for the current gaussian count, sliced per view."""
+        n = self.num_gaussians
+        if self._grads is None or self._grads[0] < n or self._grads[1] != self.l_max:
+            self._grads = (n, self.l_max, ctx.alloc_gradients(n, self.l_max, intermediates=True))
+        return {k: v[:m] for k, v in self._grads[2].items()}
+
+    def train_step(self, cam, gt_image, want_loss=True):
+        if self.world > 1:
+            return self._train_step_sharded(cam, gt_image, want_loss)
         c = self.cfg
         it = self.iter
         # cuda/trainer.cu:1341-1343: the background cycles for the whole run (use_background_end is parsed but never read)
@@ -96,13 +136,42 @@ class Trainer:
                 raise
             self.iter += 1
             return None
-        grad_image = torch.empty(H, W, 3, dtype=torch.float32, device=gt_image.device)
-        loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image)
-        grads = ctx.alloc_gradients(fwd["num_culled"], self.l_max, intermediates=True)
+        grad_image = self._grad_image_for(H, W, gt_image.device)
+        # the loss value is a blocking read-back: only fetched when the caller logs it
+        loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image, blocking=want_loss)
+        grads = self._gradients_for(ctx, fwd["num_culled"])
         ctx.backward_pass(p, cam, grad_image, bg, self.l_max, grads)
         self.opt.step(it, fwd, grads)
         self.iter += 1
         return loss
+
+    def _train_step_sharded(self, cam, gt_image, want_loss):
+        """One iteration of a W-rank group: this rank's view -> loss -> backward -> exchange -> the same packed
+        optimizer step on every rank (gsplat_optimizer_step_packed incl. the densification statistics)."""
+        c, it = self.cfg, self.iter
+        bg = (it % 255) / 255.0 if c["use_background"] else 0.0
+        if it % c["add_sh_band_interval"] == 0 and it >= c["add_sh_band_interval"]:
+            self.add_sh_band()
+        n = self.num_gaussians
+        key = (n, self.l_max)
+        if self._sharded is None or self._sharded[0] != key:
+            ctx = self._context_for(n)
+            p = dict(self.params)
+            self._sharded = (key, ViewShardedStep(p, self.l_max, ctx.max_width, ctx.max_height, c, 0.0,
+                                                  exchange=self.exchange, with_uv_norm=True, ctx=ctx))
+        step = self._sharded[1]
+        H, W = int(cam["height"]), int(cam["width"])
+        out = {}
+
+        def grad_fn(fwd):
+            g = self._grad_image_for(H, W, gt_image.device)
+            out["loss"] = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), g, blocking=want_loss)
+            return g
+
+        step.step(cam, grad_fn=grad_fn, bg=bg)
+        self.opt.step_packed(it, step.packed, step.uv_norm_sum)
+        self.iter += 1
+        return out.get("loss")
 
     def maintenance(self):
         """Density control and opacity reset at the reference's cadence (cuda/trainer.cu:1394-1406); call after
@@ -116,17 +185,27 @@ class Trainer:
             self.reset_opacity()
             self.reset_grad_accum()
 
-    def train(self, num_iters, log_every=0):
+    def draw_views(self):
+        return draw_view_indices(self.rng, self.iter, self.world, len(self.views))
+
+    def train(self, num_iters, log_every=0, loss_every=1, eval_every=0, eval_views=None, on_eval=None):
+        """loss_every: read the loss value back every that many iterations (each read blocks the host; 0 = never);
+        eval_every / eval_views / on_eval: `evaluate(eval_views)` at that cadence (the reference: every 3000
+        iterations, cuda/trainer.cu:1388), reported through on_eval(iteration, psnr)."""
         for _ in range(num_iters):
-            # the reference walks the first two images in order and then draws uniformly (cuda/trainer.cu:1438-1444)
-            v = self.iter if self.iter < 2 else int(self.rng.integers(0, len(self.views)))
-            cam, gt = self.views[v % len(self.views)]
-            loss = self.train_step(cam, gt)
+            v = self.draw_views()[self.rank]
+            cam, gt = self.views[v]
+            want = bool(loss_every) and (self.iter % loss_every == 0 or (log_every and (self.iter + 1) % log_every == 0))
+            loss = self.train_step(cam, gt, want_loss=want)
+            if eval_every and (self.iter - 1) % eval_every == 0 and eval_views:
+                psnr = self.evaluate(eval_views)
+                if on_eval:
+                    on_eval(self.iter - 1, psnr)
             self.maintenance()
             if loss is not None:
                 self.history.append((self.iter, loss, self.num_gaussians))
-            if log_every and self.iter % log_every == 0:
-                print(f"iter {self.iter}: loss {loss} gaussians {self.num_gaussians}")
+            if log_every and self.iter % log_every == 0 and self.rank == 0:
+                print(f"iter {self.iter}: loss {loss} gaussians {self.num_gaussians}", flush=True)
         return self.history
 
     def evaluate(self, views=None):

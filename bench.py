@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""Benchmark of the rasterizer hot path on MI355X (contract: see the task description / DESIGN.md).
+"""Benchmark of the rasterizer hot path on MI355X (contract: see the task description / DESIGN.md section 5).
 
 One "step" = one forward + backward pass of one training view per GPU
 (gsplat_rasterize_image + gsplat_backward_pass, i.e. rasterize_image + the 7-operator backward chain of the
 reference) on BASELINE.json configs[2]: 1e6 synthetic gaussians, 1920x1080, SH degree 3, with inputs resident in
-HBM.  With --gpus N > 1 every rank renders its own view and the per-gaussian gradients are summed with one RCCL
-all-reduce per step (weak scaling: value = views/s over all ranks).
+HBM.  With --gpus N > 1 every rank renders its own view and the per-gaussian gradients are summed over the ranks
+once per step (weak scaling: value = views/s over all ranks).
+
+`python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (one child process per GPU, started
+before anything in this process touches the GPU); under `python -m torch.distributed.run` the ranks come from the
+environment.  A mismatch between --gpus and the world size is an error, never a silent single-GPU run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -14,61 +18,255 @@ import gc
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 2 cycles
+# (`v_fma_f32` (wave64): 2 cyc), 2.4 GHz max clock -> 1228.8 G wave-level VALU instructions per second
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the non-headline workloads (half-culled config 3, dense4m) reported as extra keys")
+    return ap.parse_args()
 
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """Parent of a multi-GPU run: never imports torch, never touches a GPU.  Starts one child per rank with the
+    torch.distributed environment, forwards rank 0's JSON line, fails if any rank fails."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
+    out0 = procs[0].communicate()[0] or ""
+    codes = []
+    deadline = time.time() + 120  # the ranks leave together (final barrier); a straggler means a failure
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()  # this exact child
+            codes.append(-9)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(c != 0 for c in codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != n:
+        print(f"bench.py: rank 0 did not report n_gpus={n}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def tile_max_sum(torch, n, W, H):
+    """S_eff = sum over tiles of max_px(splats_per_pixel): list entries any pixel of the tile needs."""
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    npad = torch.zeros(nty * 16, ntx * 16, dtype=n.dtype, device=n.device)
+    npad[:H, :W] = n
+    return int(npad.reshape(nty, 16, ntx, 16).amax(dim=(1, 3)).sum().item())
+
+
+def stage_pass(ctx, dp, dc, dgi, cfg, L, grads, reps, do_bwd=True):
+    ctx.set_timing(True)
+    for _ in range(reps):
+        ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+        if do_bwd:
+            ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
+    st = ctx.get_timing()
+    ctx.set_timing(False)
+    return st
+
+
+def hbm_entry(kernel, nbytes, ms):
+    ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": kernel, "bound": "hbm", "algorithmic_bytes": int(nbytes), "avg_launch_ms": round(ms, 4),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+
+
+def extra_workload(torch, scene, raster, name, dev, reps=20):
+    """A non-headline workload, per-stage times only (outside every timed region)."""
+    N, W, H, L, _ = scene.WORKLOADS[name]
+    cfg = scene.CONFIG
+    params = scene.make_gaussians(N, W, H, L)
+    cam = scene.make_camera(W, H, 0)
+    if name == "config3_halfculled":
+        params = scene.cull_half(params)
+    dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
+    dgi = torch.as_tensor(scene.make_grad_image(W, H)).to(dev)
+    ctx = raster.RasterContext(N, W, H)
+    grads = ctx.alloc_gradients(N, L)
+    for _ in range(5):
+        fwd = ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+        ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
+    M, S = fwd["num_culled"], fwd["num_splats"]
+    st = stage_pass(ctx, dp, dc, dgi, cfg, L, grads, reps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+        ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    out = {"N": N, "M": M, "S": S, "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
+           "preprocess": hbm_entry("preprocess", 288 * M + 13 * N, st["preprocess"][0]),
+           "preprocess_backward": hbm_entry("preprocess_backward", 560 * M, st["preprocess_backward"][0])}
+    ctx.close()
+    del dp, dgi, grads
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(scene, args, params, cam, gi, cfg, N, W, H, L, do_bwd):
+    """The oracle (a CPU restatement of the reference's operators; the reference has no CPU rasterizer) timed on this
+    box's host cores: one iteration at 1 thread, two at all cores; plus the reference's only CPU compute,
+    Gaussians::Initialize (src/gaussian.cpp:38-104), as the oracle's kd-tree restatement on 1e5 / 1e6 points."""
+    import numpy as np
+    from oracle import oracle as orc
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # the GPU box's CPU share for one GPU
+
+    def iteration(threads):
+        orc.set_threads(threads)
+        t = time.perf_counter()
+        f = orc.rasterize(params, cam, cfg["near_thresh"], cfg["mh_dist"], cfg["cull_mask_padding"], cfg["bg"], L,
+                          threads=threads)
+        if do_bwd:
+            orc.backward_pass(f, cam, gi, cfg["bg"], L, threads=threads)
+        return time.perf_counter() - t
+
+    s_all = min(iteration(cores) for _ in range(2))
+    s_one = iteration(1)
+    orc.set_threads(1)
+    init = {}
+    rng = np.random.default_rng(0x3D65)
+    for n in (100_000, 1_000_000):
+        pts = rng.normal(size=(n, 3)) * np.array([4.0, 2.0, 4.0])
+        col = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        for th in (cores, 1):
+            t = time.perf_counter()
+            orc.initialize_gaussians(pts, col, threads=th, kdtree=True)
+            init[f"{n}_points_{th}_threads_s"] = round(time.perf_counter() - t, 4)
+    return {"value": 1.0 / s_all, "unit": "it/s", "cores": cores, "kind": "port",
+            "value_1_thread": 1.0 / s_one, "seconds_per_iteration": {"1_thread": round(s_one, 3),
+                                                                      f"{cores}_threads": round(s_all, 3)},
+            "sample": f"whole iterations of the same workload ({N} gaussians, {W}x{H}, SH {L}): best of 2 on {cores} "
+                      f"OpenMP threads (value), 1 on one thread (value_1_thread); per-gaussian operators and compositing "
+                      f"are threaded, tile binning (candidate scan + qsort) is serial at both settings",
+            "gaussians_initialize": dict(init, what="oracle restatement of Gaussians::Initialize (src/gaussian.cpp:38-104: "
+                                         "kd-tree, leaf 10, 3-NN, OpenMP queries; nanoflann/Eigen are not vendored), "
+                                         "normal point clouds, tree build included")}
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(launch_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}")
+
+    import numpy as np  # noqa: F401
     import torch
     scene = importlib.import_module("3dgs_amd.scene")
     raster = importlib.import_module("3dgs_amd.raster")
     gdist = importlib.import_module("3dgs_amd.dist")
     import torch.distributed as dist
 
-    rank, world, local_rank = gdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device((local_rank % torch.cuda.device_count()) if world > 1 else 0)
+    rank, world, local_rank = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
+    ndev = torch.cuda.device_count()
+    backend = dist.get_backend() if world > 1 else "none"
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {ndev} "
+                         f"(GSPLAT_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
+    torch.cuda.set_device(local_rank % ndev if world > 1 else 0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     N, W, H, L, do_bwd = scene.WORKLOADS[args.workload]
     cfg = scene.CONFIG
     t0 = time.time()
     params = scene.make_gaussians(N, W, H, L)
+    if args.workload == "config3_halfculled":
+        params = scene.cull_half(params)
     cam = scene.make_camera(W, H, view_index=rank)  # every rank its own training view
     gi = scene.make_grad_image(W, H)
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
     dgi = torch.as_tensor(gi).to(dev)
-    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=os.environ.get("GSPLAT_EXCHANGE", "split"))
     gen_s = time.time() - t0
+    gc.collect()
+    gc.disable()  # a generation-2 collection in the middle of a timed loop costs tens of milliseconds
+
+    # ---- exchange payload (multi-GPU): GSPLAT_EXCHANGE = full | factored | split | auto.  "auto" (default) times each
+    # payload for a few steps before the warm-up and keeps the fastest on this node's links; all three end in
+    # the same packed rows (tests/test_dist_gpu.py), "full" is the north star's single all-reduce of whole rows.
+    want = os.environ.get("GSPLAT_EXCHANGE", "auto" if world > 1 else "split")
+    exchange_ms = {}
+    ctx = raster.RasterContext(N, W, H)
+    if world > 1 and do_bwd and want == "auto":
+        for mode in ("full", "factored", "split"):
+            st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode, ctx=ctx)
+            for _ in range(3):
+                st.step(dc, dgi)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ta = time.perf_counter()
+            for _ in range(10):
+                st.step(dc, dgi)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([(time.perf_counter() - ta) / 10 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_ms[mode] = round(float(t.item()), 4)
+            del st
+            torch.cuda.empty_cache()
+        want = min(exchange_ms, key=exchange_ms.get)  # the same on every rank: the times were MAX-reduced
+    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want if want != "auto" else "split", ctx=ctx)
 
     def one_step():
         if do_bwd:
             return step.step(dc, dgi)
         return step.ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
 
+    # ---- reporting passes that need no collective run BEFORE the timed region (they also leave the GPU at its
+    # steady clocks, as inside a training run): workload statistics and per-stage times with every stage bracketed
+    fwd = one_step()
+    P = W * H
+    S_eff = tile_max_sum(torch, fwd["n"], W, H)
+    M, S, num_pairs = fwd["num_culled"], fwd["num_splats"], fwd["num_pairs"]
+    stages = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, max(5, min(args.steps, 50)), do_bwd)
+
     for _ in range(args.warmup):
-        fwd = one_step()
+        one_step()
     torch.cuda.synchronize()
-    gc.collect()
-    gc.disable()  # a generation-2 collection in the middle of a timed loop costs tens of milliseconds
     # Inside the timed region only the dominant kernel is bracketed by HIP events (the roofline's launch duration):
     # every timed stage costs two event records per step, all eight together 5 % of the step.
     dom = "render_backward" if do_bwd else "render_forward"
@@ -78,7 +276,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        fwd = one_step()
+        one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -94,44 +292,40 @@ def main():
         gc.enable()
         if world > 1:
             dist.barrier()
+            dist.destroy_process_group()
         return
 
-    # ---- workload statistics and the roofline of the dominant kernel (compositing backward)
-    n = fwd["n"]
-    P = W * H
-    ntx, nty = (W + 15) // 16, (H + 15) // 16
-    npad = torch.zeros(nty * 16, ntx * 16, dtype=n.dtype, device=dev)
-    npad[:H, :W] = n
-    S_eff = int(npad.reshape(nty, 16, ntx, 16).amax(dim=(1, 3)).sum().item())
-    M, S = fwd["num_culled"], fwd["num_splats"]
+    # ---- roofline of the dominant kernel (compositing backward): HBM on algorithmic bytes, and the bound the kernel
+    # actually runs against, VALU issue (wave-level VALU instructions per launch from the SQ_INSTS_VALU pass kept in
+    # profiles/traffic.json, divided by the launch duration measured live above)
     alg_bytes = (76 * S_eff + 20 * P) if do_bwd else (40 * S_eff + 20 * P)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
+    traffic = valu_insts = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")  # filled from the rocprofv3 --pmc passes (profiles/README.md)
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and args.workload == "config3":
         try:
-            traffic = json.load(open(tfile)).get(dom)
+            tj = json.load(open(tfile))
+            traffic, valu_insts = tj.get(dom), tj.get(dom + "_valu_insts")
         except Exception:
-            traffic = None
-
-    # ---- per-stage times: a separate pass with every stage bracketed by events, outside the timed region
-    step.ctx.set_timing(True)
-    for _ in range(max(5, min(args.steps, 50))):  # rank 0 alone: no exchange here
-        step.ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
-        if do_bwd:
-            step.ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, step.grads)
-    stages = step.ctx.get_timing()
-    step.ctx.set_timing(False)
+            traffic = valu_insts = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                "avg_launch_ms": dom_ms}
+    roofline_valu = None
+    if valu_insts and dom_ms > 0:
+        ginst = valu_insts / (dom_ms * 1e-3) / 1e9
+        roofline_valu = {"kernel": dom, "bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST,
+                         "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST,
+                         "valu_instructions_per_launch": valu_insts,
+                         "note": "SQ_INSTS_VALU per launch (profiles/, same workload) / live launch duration; peak = "
+                                 "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
 
     # ---- forward-only rate (render fps), outside the timed region
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     reps = max(5, min(args.steps, 30))
-    call_ms = []
     for _ in range(reps):
-        ta = time.perf_counter()
         step.ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
-        call_ms.append((time.perf_counter() - ta) * 1e3)
     torch.cuda.synchronize()
     fps = reps / (time.perf_counter() - t1)
     # the same in a render-only context (serving: nothing kept for a backward)
@@ -153,15 +347,16 @@ def main():
     if do_bwd and os.environ.get("GSPLAT_BENCH_TRAIN_STEP", "1") != "0":
         ops = importlib.import_module("3dgs_amd.ops")
         opt_mod = importlib.import_module("3dgs_amd.optimizer")
-        target = step.ctx.rasterize_image(dp, dc, cfg, 0.0, L)["image"].clone()
-        opt = opt_mod.AdamOptimizer(dp, L, scene_extent=5.0)
+        dp_train = {k: v.clone() for k, v in dp.items()}
+        target = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)["image"].clone()
+        opt = opt_mod.AdamOptimizer(dp_train, L, scene_extent=5.0)
         tgrads = step.ctx.alloc_gradients(N, L, intermediates=True)
         loss_grad = torch.empty(H, W, 3, device=dev)
 
         def train_step(it):
-            f = step.ctx.rasterize_image(dp, dc, cfg, 0.0, L)
+            f = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)
             ops.fused_loss(f["image"], target, H, W, 0.2, loss_grad, blocking=False)
-            step.ctx.backward_pass(dp, dc, loss_grad, 0.0, L, tgrads)
+            step.ctx.backward_pass(dp_train, dc, loss_grad, 0.0, L, tgrads)
             opt.step(it, f, tgrads)
 
         for it in range(10):
@@ -173,26 +368,22 @@ def main():
             train_step(10 + it)
         torch.cuda.synchronize()
         train_ms = (time.perf_counter() - t1) / reps_tr * 1e3
-    gc.enable()
-    if os.environ.get("GSPLAT_BENCH_DEBUG"):
-        print("forward-only host ms per call:", " ".join(f"{t:.2f}" for t in call_ms), file=sys.stderr)
+        del dp_train, opt, tgrads, loss_grad, target
 
-    # ---- CPU baseline: the oracle (a CPU restatement of the reference; the reference has no CPU rasterizer)
+    # ---- non-headline workloads (extra keys): what real training views do to the per-gaussian kernels and the binning
+    extra = None
+    if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
+        extra = {}
+        for name in ("config3_halfculled", "dense4m"):
+            try:
+                extra[name] = extra_workload(torch, scene, raster, name, dev)
+            except Exception as e:  # never lose the headline line to a side measurement
+                extra[name] = {"error": repr(e)[:200]}
+    gc.enable()
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
-        reps_cpu = 2
-        t2 = time.perf_counter()
-        for _ in range(reps_cpu):
-            f = orc.rasterize(params, cam, cfg["near_thresh"], cfg["mh_dist"], cfg["cull_mask_padding"], cfg["bg"], L,
-                              threads=cores)
-            if do_bwd:
-                orc.backward_pass(f, cam, gi, cfg["bg"], L, threads=cores)
-        cpu_s = (time.perf_counter() - t2) / reps_cpu
-        cpu = {"value": 1.0 / cpu_s, "unit": "it/s", "cores": cores, "kind": "port",
-               "sample": f"{reps_cpu} full iterations of the same workload ({N} gaussians, {W}x{H}, SH {L}); "
-                         f"compositing on {cores} OpenMP threads, per-gaussian operators and sort single-threaded"}
+        cpu = cpu_baseline(scene, args, params, cam, gi, cfg, N, W, H, L, do_bwd)
 
     ms = elapsed / args.steps * 1e3
     origin = {"config2": "BASELINE configs[1]", "config3": "BASELINE configs[2]"}.get(args.workload,
@@ -206,27 +397,27 @@ def main():
         "config": {"workload": f"{origin}: synthetic {N} gaussians, {W}x{H}, SH deg {L}, "
                                f"{'forward+backward' if do_bwd else 'forward'}",
                    "views_per_step": world, "parallelism": f"view-sharded dp{world}" if world > 1 else "single GPU",
-                   "exchange": step.describe_exchange() if world > 1 else "none",
-                   "M": M, "S": S, "S_eff": S_eff, "num_pairs": fwd["num_pairs"], "scene_seed": scene.SEED},
+                   "exchange": step.describe_exchange() if world > 1 else "none", "backend": backend,
+                   "M": M, "S": S, "S_eff": S_eff, "num_pairs": num_pairs, "scene_seed": scene.SEED},
+        "exchange_ms_per_step": exchange_ms or None,
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
-        "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                     "avg_launch_ms": dom_ms},
+        "roofline": roofline,
+        "roofline_valu_issue": roofline_valu,
         # the HBM-bound kernels either side of the compositing, from the per-stage pass (algorithmic bytes per
         # gaussian: SURVEY.md 8d / DESIGN.md section 4); not the dominant kernel, reported for completeness
-        "roofline_per_gaussian_kernels": [
-            {"kernel": k, "bound": "hbm", "algorithmic_bytes": int(bpg * M), "avg_launch_ms": round(stages[k][0], 4),
-             "achieved": (bpg * M / (stages[k][0] * 1e-3) / 1e9) if stages[k][0] > 0 else 0.0, "peak": HBM_PEAK_GBS,
-             "unit": "GB/s", "frac": (bpg * M / (stages[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if stages[k][0] > 0 else 0.0}
-            for k, bpg in (("preprocess", 301), ("preprocess_backward", 560)) if (do_bwd or k == "preprocess")],
+        "roofline_per_gaussian_kernels": [hbm_entry(k, b, stages[k][0]) for k, b in
+                                          (("preprocess", 288 * M + 13 * N), ("preprocess_backward", 560 * M))
+                                          if (do_bwd or k == "preprocess")],
+        "extra_workloads": extra,
         "cpu_baseline": cpu,
         "setup_s": round(gen_s, 1),
     }
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -184,9 +184,13 @@ int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gs
 
 /* Multi-view variant: gradients are rows of the all-reduced packed layout
  * (gsplat_pack_gradients_global / gsplat_unpack_gradients_factored, row width `width`, last column = number of
- * views that saw the gaussian); rows with a zero count are skipped, which is the union of the per-view masks. */
+ * views that saw the gaussian); rows with a zero count are skipped, which is the union of the per-view masks.
+ * Densification statistics of a W-view step (trainer.cu:1136-1157 once per view): when uv_grad_accum / grad_accum_dur
+ * are non-NULL, uv_grad_accum[i] += uv_norm_sum[i] (the all-reduced gsplat_pack_uv_grad_norm column: the sum over the
+ * step's views of |grad_uv|) and grad_accum_dur[i] += the row's view count. */
 int gsplat_optimizer_step_packed(const float *packed, int num_gaussians, int width, const gsplat_adam_group *groups,
-                                 int n_groups, float b1, float b2, float eps, float bias1, float bias2, void *stream);
+                                 int n_groups, float b1, float b2, float eps, float bias1, float bias2,
+                                 const float *uv_norm_sum, float *uv_grad_accum, int *grad_accum_dur, void *stream);
 
 /* replaces Gaussians::Initialize  (src/gaussian.cpp:38-104; host kd-tree + OpenMP in the reference): the initial
  * gaussians of a sparse point cloud, computed on the GPU.  points_xyz [N,3] doubles and points_rgb [N,3] bytes are
@@ -381,6 +385,13 @@ int gsplat_pack_gradients_split(gsplat_context *ctx, const gsplat_gradients *gra
                                 float *rgb, void *stream);
 int gsplat_unpack_gradients_split(const float *xyz, const float *common, const float *rgb_all, size_t rank_stride,
                                   int l_max, int num_gaussians, int world_size, float *packed, void *stream);
+
+/* The per-view densification statistic in global gaussian order: uv_norm[i] = |grad_uv| of this view's backward
+ * (PositionalGradientNorm, cuda/trainer.cu:1143-1148) or 0 where the view culled the gaussian.  SUM all-reduced next
+ * to the gradients it feeds gsplat_optimizer_step_packed, so that density control runs on a view-sharded step.
+ * grads->grad_uv must have been requested from the backward. */
+int gsplat_pack_uv_grad_norm(gsplat_context *ctx, const gsplat_gradients *grads, int num_gaussians, float *uv_norm,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* OpenMP threads of the per-gaussian operators (P1 P2 K1 G1 G2 S1 and the backward chain): every gaussian is
+ * independent, so the arithmetic is the same at any count.  The compositing functions take their own `threads`
+ * argument; tile binning (the candidate scan and the qsort) is serial at every setting.  Default 1. */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n > 0 ? n : 1; }
+
 #define R float
 #define SUF _f32
 #define SQRT sqrtf
@@ -76,6 +82,96 @@ void orc_knn_mean_distance(const double *pts, long n, int k, float *out, int thr
       if (best[a] < INFINITY) { total += sqrt(best[a]); ++count; }
     out[i] = count > 0 ? (float)(total / count) : 0.01f;
   }
+}
+
+/* The same quantity the way the reference computes it (src/gaussian.cpp:60-91): a kd-tree over the points (nanoflann
+ * KDTreeSingleIndexAdaptor, leaf size 10, L2 in double) and one k+1-nearest query per point under OpenMP.  nanoflann is
+ * not vendored in the reference (empty submodule), so this is a dependency-free restatement of the published
+ * algorithm -- median split on the widest axis, leaves of <= 10 points, depth-first search that visits the near child
+ * first and the far child only if the splitting plane is closer than the current k-th distance -- used as the CPU
+ * baseline of the initialisation (bench.py) and checked against the brute force above. */
+typedef struct { int lo, hi, axis, left, right; double split; } orc_kdnode;
+typedef struct { const double *pts; int *idx; orc_kdnode *nodes; int n_nodes; } orc_kdtree;
+
+static int orc_kd_build(orc_kdtree *t, int lo, int hi) {
+  const int me = t->n_nodes++;
+  orc_kdnode *nd = &t->nodes[me];
+  nd->lo = lo; nd->hi = hi; nd->left = nd->right = -1; nd->axis = 0; nd->split = 0.0;
+  if (hi - lo <= 10) return me;
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = lo; k < hi; ++k)
+    for (int a = 0; a < 3; ++a) {
+      const double v = t->pts[3 * (long)t->idx[k] + a];
+      if (v < mn[a]) mn[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  int ax = 0;
+  for (int a = 1; a < 3; ++a)
+    if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
+  if (!(mx[ax] > mn[ax])) return me;  /* all points identical: one (large) leaf */
+  /* nth_element on the axis (quickselect, median) */
+  int l = lo, r = hi - 1;
+  const int mid = lo + (hi - lo) / 2;
+  while (l < r) {
+    const double pivot = t->pts[3 * (long)t->idx[(l + r) / 2] + ax];
+    int i = l, j = r;
+    while (i <= j) {
+      while (t->pts[3 * (long)t->idx[i] + ax] < pivot) ++i;
+      while (t->pts[3 * (long)t->idx[j] + ax] > pivot) --j;
+      if (i <= j) { const int tmp = t->idx[i]; t->idx[i] = t->idx[j]; t->idx[j] = tmp; ++i; --j; }
+    }
+    if (mid <= j) r = j; else if (mid >= i) l = i; else break;
+  }
+  nd->axis = ax;
+  nd->split = t->pts[3 * (long)t->idx[mid] + ax];
+  const int left = orc_kd_build(t, lo, mid);
+  const int right = orc_kd_build(t, mid, hi);
+  t->nodes[me].left = left; t->nodes[me].right = right;  /* nodes[] does not move: sized up front */
+  return me;
+}
+
+static void orc_kd_query(const orc_kdtree *t, int node, const double *q, double *best, int want) {
+  const orc_kdnode *nd = &t->nodes[node];
+  if (nd->left < 0) {
+    for (int k = nd->lo; k < nd->hi; ++k) {
+      const double *p = &t->pts[3 * (long)t->idx[k]];
+      const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2], d = dx * dx + dy * dy + dz * dz;
+      if (!(d < best[want - 1])) continue;
+      int a = want - 1;
+      while (a > 0 && best[a - 1] > d) { best[a] = best[a - 1]; --a; }
+      best[a] = d;
+    }
+    return;
+  }
+  const double diff = q[nd->axis] - nd->split;
+  const int near = diff < 0.0 ? nd->left : nd->right, far = diff < 0.0 ? nd->right : nd->left;
+  orc_kd_query(t, near, q, best, want);
+  if (diff * diff < best[want - 1]) orc_kd_query(t, far, q, best, want);
+}
+
+void orc_knn_mean_distance_kdtree(const double *pts, long n, int k, float *out, int threads) {
+  if (n <= 0) return;
+  orc_kdtree t;
+  t.pts = pts;
+  t.idx = (int *)malloc((size_t)n * sizeof(int));
+  t.nodes = (orc_kdnode *)malloc((size_t)(2 * n + 1) * sizeof(orc_kdnode));
+  t.n_nodes = 0;
+  for (long i = 0; i < n; ++i) t.idx[i] = (int)i;
+  orc_kd_build(&t, 0, (int)n);
+  const int want = k + 1;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 256)
+  for (long i = 0; i < n; ++i) {
+    double best[9];
+    for (int a = 0; a < want; ++a) best[a] = INFINITY;
+    orc_kd_query(&t, 0, &pts[3 * i], best, want);
+    double total = 0.0;
+    int count = 0;
+    for (int a = 1; a < want; ++a)
+      if (best[a] < INFINITY) { total += sqrt(best[a]); ++count; }
+    out[i] = count > 0 ? (float)(total / count) : 0.01f;
+  }
+  free(t.idx);
+  free(t.nodes);
 }
 
 /* attribute part of Gaussians::Initialize (src/gaussian.cpp:93-101) */

@@ -42,6 +42,7 @@ static inline int FN(f2i_sat)(R v) {
 /* P1  compute_camera_space_points   cuda/projection.cu:6-45                             */
 /* ------------------------------------------------------------------------------------ */
 void FN(orc_camera_space_points)(const R *xyz_w, const R *view, int N, R *xyz_c) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R wx = xyz_w[i * 3 + 0], wy = xyz_w[i * 3 + 1], wz = xyz_w[i * 3 + 2];
     xyz_c[i * 3 + 0] = view[0] * wx + view[1] * wy + view[2] * wz + view[3];
@@ -54,6 +55,7 @@ void FN(orc_camera_space_points)(const R *xyz_w, const R *view, int N, R *xyz_c)
 /* P2  project_to_screen   cuda/projection.cu:47-98  (row 2 of proj is never read)       */
 /* ------------------------------------------------------------------------------------ */
 void FN(orc_project_to_screen)(const R *xyz, const R *proj, int N, int width, int height, R *uv) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R x = xyz[i * 3 + 0], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
     const R x_clip = proj[0] * x + proj[1] * y + proj[2] * z + proj[3];
@@ -71,6 +73,7 @@ void FN(orc_project_to_screen)(const R *xyz, const R *proj, int N, int width, in
 /* ------------------------------------------------------------------------------------ */
 void FN(orc_cull_gaussians)(const R *uv, const R *xyz, int N, R near_thresh, int padding, int width, int height,
                             unsigned char *mask) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R u = uv[i * 2 + 0], v = uv[i * 2 + 1], z = xyz[i * 3 + 2];
     const int zok = z >= near_thresh;
@@ -84,6 +87,7 @@ void FN(orc_cull_gaussians)(const R *uv, const R *xyz, int N, R near_thresh, int
 /* G1  compute_sigma   cuda/gaussian.cu:6-75   quaternion order (w,x,y,z)               */
 /* ------------------------------------------------------------------------------------ */
 void FN(orc_compute_sigma)(const R *quaternion, const R *scale, int N, R *sigma) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     R w = quaternion[4 * i + 0], x = quaternion[4 * i + 1], y = quaternion[4 * i + 2], z = quaternion[4 * i + 3];
     const R norm = SQRT(w * w + x * x + y * y + z * z);
@@ -112,6 +116,7 @@ void FN(orc_compute_sigma)(const R *quaternion, const R *scale, int N, R *sigma)
 /* radius is float4 {r_major, r_minor, sin_theta, cos_theta} stored as 4 consecutive R.    */
 /* ------------------------------------------------------------------------------------ */
 void FN(orc_projection_jacobian)(const R *xyz, R focal_x, R focal_y, R tan_fovx, R tan_fovy, int N, R *J) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     R x = xyz[i * 3 + 0], y = xyz[i * 3 + 1];
     const R z = xyz[i * 3 + 2];
@@ -136,6 +141,7 @@ void FN(orc_projection_jacobian)(const R *xyz, R focal_x, R focal_y, R tan_fovx,
 void FN(orc_conic_from_J)(const R *sigma, const R *view, const R *J, int N, R mh_dist, R *conic, R *radius) {
   const R w00 = view[0], w01 = view[1], w02 = view[2], w10 = view[4], w11 = view[5], w12 = view[6], w20 = view[8],
           w21 = view[9], w22 = view[10];
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R *s = sigma + 6 * i, *j = J + 6 * i;
     const R s00 = s[0], s01 = s[1], s02 = s[2], s11 = s[3], s12 = s[4], s22 = s[5];
@@ -363,6 +369,7 @@ static inline void FN(sh_basis_grad)(int l_max, R x, R y, R z, R (*dY)[3]) {
 
 void FN(orc_sh_forward)(const R *xyz, const R *sh, const R *band0, const R *campos, int l_max, int N, R *rgb) {
   const int n = (l_max + 1) * (l_max + 1);
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     /* compute_dir_kernel :8-26 */
     const R dx = xyz[3 * i] - campos[0], dy = xyz[3 * i + 1] - campos[1], dz = xyz[3 * i + 2] - campos[2];
@@ -576,6 +583,7 @@ void FN(orc_render_image_backward)(const R *uv, const R *opacity, const R *conic
 /* ------------------------------------------------------------------------------------ */
 void FN(orc_project_to_screen_backward)(const R *xyz_c, const R *proj, const R *uv_grad, int N, int width, int height,
                                         R *xyz_c_grad) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R x = xyz_c[3 * i], y = xyz_c[3 * i + 1], z = xyz_c[3 * i + 2];
     const R x_clip = proj[0] * x + proj[1] * y + proj[2] * z + proj[3];
@@ -596,6 +604,7 @@ void FN(orc_project_to_screen_backward)(const R *xyz_c, const R *proj, const R *
 /* Q2  compute_camera_space_points_backward   cuda/projection_backward.cu:95-137   (+=) */
 void FN(orc_camera_space_points_backward)(const R *xyz_w, const R *view, const R *xyz_c_grad, int N, R *xyz_w_grad) {
   (void)xyz_w;
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R gx = xyz_c_grad[3 * i], gy = xyz_c_grad[3 * i + 1], gz = xyz_c_grad[3 * i + 2];
     xyz_w_grad[3 * i + 0] += view[0] * gx + view[4] * gy + view[8] * gz;
@@ -607,6 +616,7 @@ void FN(orc_camera_space_points_backward)(const R *xyz_w, const R *view, const R
 /* H1  compute_projection_jacobian_backward   cuda/gaussian_backward.cu:6-78   (+=) */
 void FN(orc_projection_jacobian_backward)(const R *xyz, R focal_x, R focal_y, R tan_fovx, R tan_fovy, const R *J_grad,
                                           int N, R *xyz_grad) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     if (FABS(z) < (R)1e-6f) continue;
@@ -640,6 +650,7 @@ void FN(orc_conic_backward)(const R *J, const R *sigma, const R *view, const R *
                             R *J_grad, R *sigma_grad) {
   const R w00 = view[0], w01 = view[1], w02 = view[2], w10 = view[4], w11 = view[5], w12 = view[6], w20 = view[8],
           w21 = view[9], w22 = view[10];
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R *j = J + 6 * i, *s = sigma + 6 * i;
     const R j00 = j[0], j01 = j[1], j02 = j[2], j10 = j[3], j11 = j[4], j12 = j[5];
@@ -743,6 +754,7 @@ void FN(orc_sigma_backward)(const R *q, const R *s, const R *dSigma_in, int N, R
 void FN(orc_sh_backward)(const R *xyz, const R *band0, const R *sh, const R *campos, const R *rgb_grad, int l_max, int N,
                          R *sh_grad, R *band0_grad, R *xyz_grad) {
   const int n = (l_max + 1) * (l_max + 1);
+#pragma omp parallel for schedule(static) num_threads(orc_threads)  /* independent per gaussian: same arithmetic at any thread count */
   for (int i = 0; i < N; ++i) {
     const R fx = xyz[3 * i] - campos[0], fy = xyz[3 * i + 1] - campos[1], fz = xyz[3 * i + 2] - campos[2];
     const R len = SQRT(fx * fx + fy * fy + fz * fz) + (R)1e-9f;

@@ -284,19 +284,27 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, b1, b2, eps, bias1, bias2,
     return p, m, v
 
 
-def knn_mean_distance(points, k=3, threads=1):
-    """mean distance to the k nearest other points, brute force in double (src/gaussian.cpp:66-91)."""
+def set_threads(n):
+    """OpenMP threads of the per-gaussian operators (independent per gaussian: same arithmetic at any count).  The
+    compositing functions take their own `threads` argument; tile binning is serial at every setting."""
+    lib().orc_set_threads(int(n))
+
+
+def knn_mean_distance(points, k=3, threads=1, kdtree=False):
+    """mean distance to the k nearest other points in double (src/gaussian.cpp:66-91): brute force, or (kdtree=True)
+    through a kd-tree with leaf size 10 as the reference's nanoflann index does."""
     pts = _a(points, np.float64).reshape(-1, 3)
     out = np.empty(len(pts), np.float32)
-    lib().orc_knn_mean_distance(_p(pts), ctypes.c_long(len(pts)), int(k), _p(out), int(threads))
+    fn = lib().orc_knn_mean_distance_kdtree if kdtree else lib().orc_knn_mean_distance
+    fn(_p(pts), ctypes.c_long(len(pts)), int(k), _p(out), int(threads))
     return out
 
 
-def initialize_gaussians(points, colors, threads=1):
+def initialize_gaussians(points, colors, threads=1, kdtree=False):
     """Gaussians::Initialize (src/gaussian.cpp:38-104): dict xyz rgb opacity scale quaternion(w,x,y,z)."""
     pts, col = _a(points, np.float64).reshape(-1, 3), _a(colors, np.uint8).reshape(-1, 3)
     n = len(pts)
-    md = knn_mean_distance(pts, 3, threads)
+    md = knn_mean_distance(pts, 3, threads, kdtree)
     z = lambda *s: np.empty(s, np.float32)
     out = dict(xyz=z(n, 3), rgb=z(n, 3), opacity=z(n), scale=z(n, 3), quaternion=z(n, 4))
     lib().orc_init_attributes(_p(pts), _p(col), _p(md), ctypes.c_long(n), _p(out["xyz"]), _p(out["rgb"]),

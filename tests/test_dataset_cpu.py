@@ -247,3 +247,38 @@ def test_oracle_initialize_attributes(orc):  # src/gaussian.cpp:93-101
     assert (g["quaternion"] == [1, 0, 0, 0]).all() and (g["xyz"] == pts.astype(np.float32)).all()
     np.testing.assert_allclose(g["scale"][0], np.log((1 + 2 + 5) / 3), rtol=1e-6)
     assert (g["scale"][:, 0] == g["scale"][:, 1]).all() and (g["scale"][:, 1] == g["scale"][:, 2]).all()
+
+
+def test_kdtree_knn_equals_brute_force(orc):
+    """The CPU baseline of Gaussians::Initialize (kd-tree, leaf size 10, as the reference's nanoflann index) must
+    return the brute-force answer on clustered, planar, duplicated and tiny clouds."""
+    rng = np.random.default_rng(5)
+    clouds = [rng.normal(size=(3000, 3)), np.concatenate([rng.normal(size=(500, 3)) * 0.01, rng.uniform(-5, 5, (700, 3))]),
+              np.c_[rng.uniform(0, 1, (800, 2)), np.zeros(800)], np.repeat(rng.normal(size=(40, 3)), 9, axis=0),
+              rng.normal(size=(1, 3)), rng.normal(size=(2, 3)), rng.normal(size=(11, 3)), np.zeros((30, 3))]
+    for pts in clouds:
+        for k in (1, 3, 8):
+            a = orc.knn_mean_distance(pts, k)
+            b = orc.knn_mean_distance(pts, k, threads=3, kdtree=True)
+            assert np.array_equal(a, b), (len(pts), k, np.abs(a - b).max())
+
+
+def test_oracle_threads_do_not_change_results(orc, scene):
+    """orc.set_threads parallelises the per-gaussian operators only (independent per gaussian): bit-identical."""
+    N, W, H, L = 3000, 128, 96, 3
+    params, cam, c = scene.make_gaussians(N, W, H, L), scene.make_camera(W, H, 2), scene.CONFIG
+    gi = scene.make_grad_image(W, H)
+
+    def run(threads):
+        orc.set_threads(threads)
+        try:
+            f = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=threads)
+            return f, orc.backward_pass(f, cam, gi, c["bg"], L, threads=threads)
+        finally:
+            orc.set_threads(1)
+
+    (f1, b1), (f4, b4) = run(1), run(4)
+    for k in ("image", "sorted", "ranges", "conic", "rgb", "radius", "sigma", "J"):
+        assert np.array_equal(f1[k], f4[k]), k
+    for k in ("xyz", "sh", "band0", "scale", "quaternion", "xyz_c", "J", "sigma"):
+        assert np.array_equal(b1[k], b4[k]), k

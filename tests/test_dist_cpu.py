@@ -104,3 +104,39 @@ def test_single_process_all_reduce_is_identity():
     gdist = pkg("dist")
     t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
     assert gdist.all_reduce_gradients(t.clone()).equal(t)
+
+
+def _draw_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import importlib
+    gdist = importlib.import_module("3dgs_amd.dist")
+    trainer_mod = importlib.import_module("3dgs_amd.trainer")
+    gdist.init_from_env(backend="gloo")
+    rng = np.random.default_rng(11)  # every rank: the same seed
+    mine, everyone = [], []
+    for it in range(25):
+        draws = trainer_mod.draw_view_indices(rng, it, world, 7)
+        everyone.append(draws)
+        mine.append(draws[rank])
+    got = [torch.zeros(25, dtype=torch.int64) for _ in range(world)]
+    torch.distributed.all_gather(got, torch.tensor(mine))
+    np.save(os.path.join(out_dir, f"draws{rank}.npy"), np.array(everyone))
+    np.save(os.path.join(out_dir, f"picked{rank}.npy"), torch.stack(got).numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_view_schedule_is_shared_and_sharded(tmp_path):
+    """The view-sharded trainer's schedule: every rank draws the SAME W views per iteration from the shared seed and
+    trains on its own one; the first two samples are views 0 and 1 as in the reference (cuda/trainer.cu:1438-1444)."""
+    world = 2
+    mp.spawn(_draw_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d = [np.load(tmp_path / f"draws{r}.npy") for r in range(world)]
+    p = [np.load(tmp_path / f"picked{r}.npy") for r in range(world)]
+    assert (d[0] == d[1]).all() and (p[0] == p[1]).all()
+    assert d[0].shape == (25, world) and list(d[0][0]) == [0, 1]
+    for r in range(world):
+        assert (p[0][r] == d[0][:, r]).all()
+    assert d[0].min() >= 0 and d[0].max() <= 6 and len(np.unique(d[0])) > 3

@@ -64,6 +64,71 @@ def test_view_sharded_step_two_ranks_one_gpu(tmp_path):
     assert (full[:, -1] == 2).any() and (full[:, -1] == 0).any()
 
 
+def _train_worker(rank, world, port, out_dir, exchange):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch
+    scene = importlib.import_module("3dgs_amd.scene")
+    raster = importlib.import_module("3dgs_amd.raster")
+    ops = importlib.import_module("3dgs_amd.ops")
+    gdist = importlib.import_module("3dgs_amd.dist")
+    trainer_mod = importlib.import_module("3dgs_amd.trainer")
+    gdist.init_from_env()
+    N, W, H = 3000, 160, 96
+    truth = scene.make_gaussians(N, W, H, 0)
+    truth["scale"] += 0.9
+    dp = raster.device_params(truth)
+    ctx = raster.RasterContext(N, W, H)
+    views = []
+    for v in range(6):
+        cam = raster.device_camera(scene.make_camera(W, H, v))
+        views.append((cam, ctx.rasterize_image(dp, cam, scene.CONFIG, 0.0, 0)["image"].clone()))
+    idx = np.random.default_rng(2).choice(N, N // 3, replace=False)
+    pts = torch.from_numpy(truth["xyz"][idx].astype(np.float64)).cuda()
+    col = torch.from_numpy(np.clip((truth["rgb"][idx] * 0.28209479 + 0.5) * 255, 0, 255).astype(np.uint8)).cuda()
+    init = ops.initialize_gaussians(pts, col)
+    cfg = dict(num_iters=80, add_sh_band_interval=25, max_sh_band=2, adaptive_control_start=20,
+               adaptive_control_interval=20, adaptive_control_end=70, reset_opacity_start=10 ** 9,
+               uv_grad_threshold=1e-6, max_gaussians=20000, use_background=False)
+    t = trainer_mod.Trainer(init, views, cfg, scene_extent=5.0, seed=3, exchange=exchange)
+    assert t.world == world and t.rank == rank
+    psnr0 = t.evaluate()
+    hist = t.train(80)
+    psnr1 = t.evaluate()
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in t.params.items()}
+    out["uv_grad_accum"] = t.opt.uv_grad_accum.cpu().numpy()
+    out["grad_accum_dur"] = t.opt.grad_accum_dur.cpu().numpy()
+    out["exp_avg_xyz"] = t.opt.exp_avg["xyz"].cpu().numpy()
+    out["meta"] = np.array([psnr0, psnr1, t.num_gaussians, t.l_max, N // 3, np.mean([h[1] for h in hist[:10]]),
+                            np.mean([h[1] for h in hist[-10:]]), len({h[2] for h in hist})])
+    np.savez(os.path.join(out_dir, f"train_{exchange}_{rank}.npz"), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["split", "full"])
+def test_view_sharded_training_two_ranks_one_gpu(tmp_path, exchange):
+    """80 view-sharded training iterations (two views per iteration) with SH growth at 25/50 and density control at
+    40/60: both replicas must end with BIT-IDENTICAL parameters, moments and densification statistics without ever
+    exchanging parameters, the loss must fall and the gaussian count change."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"train_{exchange}_{k}.npz") for k in range(world)]
+    for k in r[0].files:
+        assert r[0][k].shape == r[1][k].shape and (r[0][k] == r[1][k]).all(), f"{k}: replicas diverged"
+    psnr0, psnr1, n_end, l_max, n_start, loss_head, loss_tail, n_counts = r[0]["meta"]
+    assert np.isfinite(r[0]["xyz"]).all() and loss_tail < 0.85 * loss_head, (loss_head, loss_tail)
+    assert psnr1 > psnr0 + 1.0, (psnr0, psnr1)
+    assert n_counts > 1 and n_end != n_start, "density control never changed the gaussian count"
+    assert l_max == 2 and r[0]["sh"].shape[1:] == (8, 3)
+    dur = r[0]["grad_accum_dur"]
+    assert dur.max() <= 2 * 20 and dur.max() > 1, dur.max()  # two views per iteration since the last reset
+
+
 def test_split_exchange_on_rccl_one_rank():
     """The same overlapped exchange on the real backend (nccl = RCCL), one rank: the collectives degenerate to copies
     but shapes, contiguity and async handles go through the calls of the multi-GPU run (tools/nccl_one_rank.py)."""
@@ -75,3 +140,20 @@ def test_split_exchange_on_rccl_one_rank():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_one_rank.py")], env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0 and "nccl one-rank rehearsal: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself (gloo lets both share this GPU; the
+    RCCL run needs one device per rank) and rank 0 reports n_gpus 2 with the times of all three exchange payloads."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSPLAT_EXCHANGE")}
+    env.update(GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "4",
+                          "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["views_per_step"] == 2 and line["scaling"] == "weak"
+    assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split"}
+    assert line["config"]["exchange"].split(":")[0] in ("full", "factored", "split")
+    assert line["value"] > 0 and line["steps"] == 4
