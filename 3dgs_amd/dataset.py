@@ -151,6 +151,23 @@ def ReadPoints3DBinary(path):
     return out
 
 
+def ReadPoints3DArrays(path):
+    """The same file as flat arrays -- (ids uint64[N], xyz float64[N,3], rgb uint8[N,3]) in file order -- without one
+    Python dict per point: what Gaussians::Initialize consumes (src/gaussian.cpp:54-58 copies exactly these fields)."""
+    lib, n, t = load(), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _check(lib.gsplat_colmap_read_points3d(_enc(path), None, 0, ctypes.byref(n), None, None, 0, ctypes.byref(t)))
+    arr = (ColmapPoint3D * max(n.value, 1))()
+    img = np.empty(max(t.value, 1), np.int32)
+    idx = np.empty(max(t.value, 1), np.int32)
+    _check(lib.gsplat_colmap_read_points3d(_enc(path), arr, n.value, ctypes.byref(n), img.ctypes.data, idx.ctypes.data,
+                                           t.value, ctypes.byref(t)))
+    P = ColmapPoint3D
+    dt = np.dtype(dict(names=["id", "xyz", "rgb"], formats=["<u8", ("<f8", 3), ("u1", 3)],
+                       offsets=[P.id.offset, P.xyz.offset, P.rgb.offset], itemsize=ctypes.sizeof(P)))
+    rec = np.frombuffer(arr, dtype=dt, count=n.value)
+    return rec["id"].copy(), np.ascontiguousarray(rec["xyz"], np.float64), np.ascontiguousarray(rec["rgb"], np.uint8)
+
+
 def qvec_to_rotmat(qvec):
     q, R = np.ascontiguousarray(qvec, np.float64), np.empty(9, np.float64)
     load().gsplat_qvec_to_rotmat(q.ctypes.data, R.ctypes.data)

@@ -1,0 +1,54 @@
+"""BASELINE config 4's shape, cut down: a COLMAP dataset on disk (tools/make_colmap_dataset.py) -> train.py with the
+reference's argv -> test/train split -> a few hundred iterations of the full loop (SH growth, density control, opacity
+reset, evaluation) -> PLY.  The test split's PSNR must rise."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = dict(dataset_path="toy", downsample_factor=4, output_dir="", print_interval=100, test_eval_interval=500,
+            test_split_ratio=8, initial_opacity=0.2, initial_scale_num_neighbors=3, initial_scale_factor=0.8,
+            max_initial_scale=0.1, near_thresh=0.3, mh_dist=3.0, cull_mask_padding=100, num_iters=400, ssim_frac=0.2,
+            base_lr=1e-3, xyz_lr_multiplier_init=1.6e-1, xyz_lr_multiplier_final=1.6e-3, quat_lr_multiplier=1.0,
+            scale_lr_multiplier=5.0, opacity_lr_multiplier=25, rgb_lr_multiplier=2.5, sh_lr_multiplier=0.125,
+            use_background="true", use_background_end=2000, use_sh_precompute="true", max_sh_band=3,
+            add_sh_band_interval=100, reset_opacity_interval=3000, reset_opacity_value=0.05, reset_opacity_start=1050,
+            reset_opacity_end=5000, use_split="true", use_clone="true", use_delete="true", adaptive_control_start=100,
+            adaptive_control_end=350, adaptive_control_interval=50, max_gaussians=400000,
+            delete_opacity_threshold=0.02, uv_grad_threshold=0.0002, split_scale_factor=1.6)
+
+
+def test_disk_to_ply_training_run(tmp_path):
+    root = tmp_path / "data"
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_colmap_dataset.py"), str(root), "--name", "toy",
+                          "--views", "24", "--full-width", "1280", "--full-height", "832", "--focal", "950",
+                          "--gt", "60000", "--points", "6000"], capture_output=True, text=True, timeout=600)
+    assert gen.returncode == 0, gen.stdout[-1500:] + gen.stderr[-3000:]
+    assert len(os.listdir(root / "toy" / "images_4")) == 24
+    cfg = dict(KEYS, output_dir=str(tmp_path / "renders"))
+    (tmp_path / "toy.yaml").write_text("".join(f"{k}: {v}\n" for k, v in cfg.items()))
+    env = dict(os.environ, GSPLAT_SUMMARY_JSON=str(tmp_path / "summary.json"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), str(tmp_path / "toy.yaml"), str(root)],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=1200)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    s = json.load(open(tmp_path / "summary.json"))
+    assert s["views"] == 24 and s["test_views"] == 3 and s["iterations"] == 400  # every 8th image, sorted by name
+    it0, psnr0 = s["evals"][0]
+    assert it0 == 0 and np.isfinite(psnr0)                       # the reference evaluates at iteration 0 (iter % 3000)
+    assert s["psnr_test"] > psnr0 + 3.0, (psnr0, s["psnr_test"], run.stdout[-2000:])
+    assert s["gaussians"] != 6000 and s["peak_gaussians"] >= s["gaussians"] * 0.5
+    head = (tmp_path / "gaussians.ply").read_bytes().split(b"end_header\n", 1)[0].decode()
+    assert f"element vertex {s['gaussians']}" in head and "f_rest_44" in head  # SH degree 3 reached at iteration 300
+    assert (tmp_path / "renders" / "rendered_image_400.png").exists()
+    # a wrong argv is the reference's usage error
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "one"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "Usage:" in bad.stderr
