@@ -255,6 +255,25 @@ def test_per_gaussian_backward_chain(gpu, case):
     assert np.isfinite(sh_part).all()
 
 
+def test_projection_jacobian_backward_alone(gpu, orc, case):
+    """H1 (cuda/gaussian_backward.cu:6-95) on its own, against the oracle: the `+=` into a pre-filled xyz_c gradient
+    and the plain value (the chain test above only sees it summed with Q1)."""
+    torch, ops = gpu, pkg("ops")
+    f, b, cam, W, H = case["fwd"], case["bwd"], case["cam"], case["W"], case["H"]
+    M = f["num_culled"]
+    tfx = float(np.tan(np.float32(2) * np.arctan(np.float32(W) / (np.float32(2) * np.float32(cam["fx"]))) * np.float32(.5)))
+    tfy = float(np.tan(np.float32(2) * np.arctan(np.float32(H) / (np.float32(2) * np.float32(cam["fy"]))) * np.float32(.5)))
+    want = orc.compute_projection_jacobian_backward(f["xyz_c"], cam["fx"], cam["fy"], tfx, tfy, b["J"])
+    assert np.abs(want).max() > 0
+    got = torch.zeros(M, 3, device="cuda")
+    ops.compute_projection_jacobian_backward(_dev(torch, f["xyz_c"]), cam["fx"], cam["fy"], tfx, tfy, _dev(torch, b["J"]), M, got)
+    assert_grad_close(got.cpu().numpy(), want, "H1 alone", rel=1e-5)
+    seed = np.random.default_rng(0).normal(size=(M, 3)).astype(np.float32) * np.abs(want).mean()
+    got2 = _dev(torch, seed.copy())
+    ops.compute_projection_jacobian_backward(_dev(torch, f["xyz_c"]), cam["fx"], cam["fy"], tfx, tfy, _dev(torch, b["J"]), M, got2)
+    assert_grad_close(got2.cpu().numpy(), seed + want, "H1 accumulates", rel=1e-5)
+
+
 def test_compact_and_scatter(gpu, orc):  # reference tests/cuda_data_test.cpp:38-125
     torch, ops = gpu, pkg("ops")
     rng = np.random.default_rng(3)
