@@ -142,16 +142,19 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # cheap when the library is fresh (mtime scan); on a box without hipcc a prebuilt, up-to-date library is used as is
-    try:
-        build()
-    except (OSError, subprocess.CalledProcessError):
-        if not os.path.exists(LIB_PATH):
-            raise
+    path = os.environ.get("GSPLAT_LIB")  # tooling (tools/ab, diagnostic builds): load exactly this prebuilt variant
+    if not path:
+        # cheap when the library is fresh (mtime scan); on a box without hipcc a prebuilt, up-to-date library is used as is
+        try:
+            build()
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(LIB_PATH):
+                raise
+        path = LIB_PATH
     # torch owns device memory and ships its own HIP runtime: import it first so that this library binds to the
     # same runtime instance (two runtimes in one process do not see each other's allocations)
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync
         fn.restype = res

@@ -33,6 +33,20 @@
 #ifndef GS_ABLATE
 #define GS_ABLATE 0
 #endif
+// Diagnostic build (-DGS_STAMP=1, tools/bwd_timeline.py): every wave of render_bwd records where its cycles went
+// (s_memtime around the barriers, staging, list building, the trip loop and the flush) into a device array that
+// gsplat_debug_read_stamps copies out.  No stamp code exists in the normal build.
+#ifndef GS_STAMP
+#define GS_STAMP 0
+#endif
+#if GS_STAMP
+#define GS_STAMP_WORDS 16
+__device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
+#define GS_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#define GS_LAP(acc) do { const unsigned long long _n = GS_NOW(); (acc) += _n - st_last; st_last = _n; } while (0)
+#else
+#define GS_LAP(acc) do { } while (0)
+#endif
 // Backward batch size: 128 slots keep the block at 21 KB of LDS (records 4 KB, f64 accumulators 10 KB, lists + third
 // record array 6 KB), i.e. 7 workgroups per CU, matching the 72 VGPRs; 256 slots (41 KB, 3 blocks/CU) measured 0.76 ms
 // vs 0.57 ms when tried, 64 slots 0.63 ms (twice the barriers and per-batch work).
@@ -274,6 +288,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
+#if GS_STAMP
+  const unsigned long long st_t0 = GS_NOW(), st_rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0, st_bar = 0, st_bar1 = 0, st_bar2 = 0, st_bar3 = 0, st_stage = 0, st_lists = 0, st_loop = 0, st_flush = 0, st_trips = 0, st_batches = 0;
+  auto st_write = [&]() {
+    if (lane == 0) {
+      unsigned long long *o = gs_stamp_buf + ((size_t)blockIdx.x * 4 + wave) * GS_STAMP_WORDS;
+      o[0] = (unsigned long long)tile; o[1] = st_rt0; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = GS_NOW() - st_t0;
+      o[4] = st_bar; o[5] = st_stage; o[6] = st_lists; o[7] = st_loop; o[8] = st_flush; o[9] = st_trips; o[10] = st_batches;
+      unsigned int xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[11] = xcc; o[12] = st_bar1; o[13] = st_bar2; o[14] = st_bar3; o[15] = (unsigned long long)wave;
+    }
+  };
+#endif
   const int tile_x = tile % ntx, tile_y = tile / ntx;
   const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
   const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
@@ -310,6 +338,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   if (lane == 0) atomicMax(&s_top, wave_top);
   __syncthreads();
   const int top = s_top;  // cuda/render_backward.cu:64,74: start at (max n over the tile) - 1
+#if GS_STAMP
+  GS_LAP(st_stage);
+  if (top <= 0) { st_write(); return; }
+#endif
   if (top <= 0) return;
   // where this lane's share of the nine row totals goes (see row_moments9), and the lane constants of the sums:
   // pixel position relative to the tile centre, pixel gradient
@@ -323,7 +355,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // would sit in registers across the compositing loop and end up spilled to scratch
     int t = tid;
     asm volatile("" : "+v"(t));
+#if GS_STAMP
+    ++st_batches;
+    GS_LAP(st_flush);
+#endif
     __syncthreads();
+    GS_LAP(st_bar);
     if (t < count) {  // count <= kB
       const int g = sorted[start + base + t];
       SplatRec s = load_record<kPacked>(g, recs, raw);
@@ -341,7 +378,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       s_id[t] = g;
     }
     for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
+    GS_LAP(st_stage);
     __syncthreads();
+    GS_LAP(st_bar1);
     if (base < wave_top) {
       // (list addresses from the opaque index too)
       unsigned short *lists = s_list + (t >> 6) * 4 * kB;
@@ -349,6 +388,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
           (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + ((t >> 4) & 3) * kB);
       const RowCounts rc = build_row_lists<kB>(s_r2, lists, count, t >> 6, t & 63, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+#if GS_STAMP
+      st_trips += trips;
+      GS_LAP(st_lists);
+#endif
       const int n_rel = (n - base) * 16;  // "base + slot < n" on byte offsets
       // The lane constants of the nine sums (pixel position relative to the tile centre, pixel gradient) are rebuilt
       // per batch behind an opaque copy, so that they are not live across staging and flush: held for the whole
@@ -406,8 +449,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #endif
 #endif
       }
+      GS_LAP(st_loop);
     }
     __syncthreads();
+    GS_LAP(st_bar2);
     // flush, step 1: one thread per gaussian turns its nine raw sums into the nine gradient values (uniform control
     // flow, the double arithmetic once per gaussian instead of once per lane of a 16-lane group)
     if (t < count) {
@@ -436,7 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       res[7] = keep * (-(ca * sx + cb * sy) * (0.5f * (float)width));                // u (render_backward.cu:180-186)
       res[8] = keep * (-(cc * sy + cb * sx) * (0.5f * (float)height));               // v (:181-187)
     }
+    GS_LAP(st_flush);
     __syncthreads();
+    GS_LAP(st_bar3);
     // step 2: 16 lanes per gaussian -> each wave instruction touches four whole 64-byte rows
     const int k = t & 15;
     if (k < 9) {
@@ -462,6 +509,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       }
     }
   }
+#if GS_STAMP
+  GS_LAP(st_flush);
+  st_write();
+#endif
 }
 
 // host-side launchers shared with gs_fused.hip ------------------------------------------
@@ -501,6 +552,14 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
 }  // namespace gs
 
 extern "C" {
+
+#if GS_STAMP
+// diagnostic builds only: copies the stamp words of the last render_bwd launch (GS_STAMP_WORDS per wave, 4 waves per block)
+int gsplat_debug_read_stamps(unsigned long long *dst, size_t words) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gs_stamp_buf), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int gsplat_render_image(const float *uv, const float *opacity, const float *conic, const float *rgb,
                         float background_opacity, const int *sorted_splats, const int *splat_range_by_tile,
