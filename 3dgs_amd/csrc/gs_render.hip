@@ -47,11 +47,13 @@ __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
 #else
 #define GS_LAP(acc) do { } while (0)
 #endif
-// Backward batch size: 128 slots keep the block at 21 KB of LDS (records 4 KB, f64 accumulators 10 KB, lists + third
-// record array 6 KB), i.e. 7 workgroups per CU, matching the 72 VGPRs; 256 slots (41 KB, 3 blocks/CU) measured 0.76 ms
-// vs 0.57 ms when tried, 64 slots 0.63 ms (twice the barriers and per-batch work).
+// Backward batch size: 124 slots keep the block at 20 392 B of LDS (records 4 KB, f64 accumulators 9.7 KB, lists + third
+// record array 5.8 KB), i.e. EIGHT workgroups per CU (160 KB / 8 = 20 480 B), matching the 64 VGPRs the kernel is held
+// to below: 8 waves per SIMD and 2048 resident workgroups, which 1080p's 8160 tiles fill in 3.98 rounds (r02: 0.350 ->
+// 0.342 ms against 128 slots / 72 VGPRs / 7 workgroups per CU).  256 slots (41 KB, 3 blocks/CU) measured 0.76 ms vs
+// 0.57 ms when tried in r01, 64 slots 0.63 ms (twice the barriers and per-batch work).
 #ifndef GS_BWD_BATCH
-#define GS_BWD_BATCH 128
+#define GS_BWD_BATCH 124
 #endif
 
 namespace gs {
@@ -129,8 +131,11 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
   return rc;
 }
 
+#ifndef GS_FWD_WAVES
+#define GS_FWD_WAVES 7
+#endif
 template <bool kPacked>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void render_fwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVES, 8))) void render_fwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
                                                               const int *__restrict__ sorted,
                                                               const int *__restrict__ ranges, int width, int height,
                                                               int ntx, int num_tiles, float bg,
@@ -262,7 +267,7 @@ __device__ __forceinline__ int row_max_int(int v) {  // max over the 16 lanes of
 }
 
 template <bool kPacked, bool kRows, int kB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_bwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
                                                               const int *__restrict__ sorted,
                                                               const int *__restrict__ ranges,
                                                               const int *__restrict__ n_px,
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     const int k = t & 15;
     if (k < 9) {
 #pragma unroll 4
-      for (int r = 0; r < kB / 16; ++r) {
+      for (int r = 0; r < (kB + 15) / 16; ++r) {
         const int slot = r * 16 + (t >> 4);
         if (slot >= count) continue;
         const float val = s_res[slot * 9 + k];
