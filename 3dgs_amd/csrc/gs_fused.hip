@@ -346,9 +346,42 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
     if (__all(!live || i == i0 + lane)) {  // consecutive gaussians (no culling in between): one linear span
       rows_to_lds<kRest>(g.sh + (size_t)i0 * kRest, wsh, rows, lane);
     } else {
-      for (int r = 0; r < rows; ++r) {
-        const int ir = __shfl(i, r, 64);
-        if (lane < kRest) wsh[r * kRest + lane] = g.sh[(size_t)ir * kRest + lane];
+      // Culled gaussians in between (every real training view): the wave's rows are scattered.  Twelve lanes fetch one
+      // row -- eleven 16-byte pieces and the last float(s) -- so a wave instruction brings in five whole rows (880 B)
+      // instead of one (180 B with one float per lane: 64 load instructions per wave, r01), and all of a wave's loads
+      // are issued before the first LDS store.  Rows sit at a pitch of kRest words in LDS (conflict-free for the
+      // per-lane walk of sh_bwd), which is not 16-byte aligned: the pieces are stored as four words.
+      constexpr int kPieces = (kRest + 3) / 4, kPer = 64 / kPieces, kIter = (64 + kPer - 1) / kPer;
+      static_assert(kPieces <= 64 && kPer >= 1, "row too long for one lane group");
+      const int grp = lane / kPieces, piece = lane - grp * kPieces;
+      const bool in_grp = grp < kPer;
+      float4 v[kIter];
+#pragma unroll
+      for (int it = 0; it < kIter; ++it) {
+        const int r = it * kPer + grp;
+        const int ir = __shfl(i, r < rows ? r : 0, 64);
+        v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in_grp && r < rows) {
+          const float *src = g.sh + (size_t)ir * kRest + 4 * piece;
+          if (4 * piece + 3 < kRest) {
+            v[it] = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src));
+          } else {  // the row's last, partial piece
+            v[it].x = src[0];
+            if (4 * piece + 1 < kRest) v[it].y = src[1];
+            if (4 * piece + 2 < kRest) v[it].z = src[2];
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < kIter; ++it) {
+        const int r = it * kPer + grp;
+        if (in_grp && r < rows) {
+          float *dst = wsh + r * kRest + 4 * piece;
+          dst[0] = v[it].x;
+          if (4 * piece + 1 < kRest) dst[1] = v[it].y;
+          if (4 * piece + 2 < kRest) dst[2] = v[it].z;
+          if (4 * piece + 3 < kRest) dst[3] = v[it].w;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -108,6 +108,28 @@ def cull_half(params, seed=SEED):
     return out
 
 
+def morton_order(params):
+    """The same gaussians re-ordered by the 63-bit Morton code of their positions -- the order the training loop keeps
+    them in (TrainerImpl::sort_gaussians after every density step, cuda/trainer.cu:853-922): neighbours in memory are
+    neighbours in space, so their tile instances land next to each other."""
+    xyz = params["xyz"].astype(np.float64)
+    lo, hi = xyz.min(0), xyz.max(0)
+    q = np.clip((xyz - lo) / np.maximum(hi - lo, 1e-30) * 2097151.0, 0, 2097151).astype(np.uint64)
+
+    def spread(v):
+        v &= np.uint64(0x1FFFFF)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    code = (spread(q[:, 2].copy()) << np.uint64(2)) | (spread(q[:, 1].copy()) << np.uint64(1)) | spread(q[:, 0].copy())
+    order = np.argsort(code, kind="stable")
+    return {k: np.ascontiguousarray(v[order]) for k, v in params.items()}
+
+
 def make_grad_image(width, height, seed=SEED):
     g = (uniform24(seed, 60, 3 * width * height) * 2.0 - 1.0) / (3.0 * width * height)
     return g.reshape(height, width, 3).astype(np.float32)
@@ -127,4 +149,6 @@ WORKLOADS = {
     # not a BASELINE config: config3 with about half of the gaussians culled, interleaved (cull_half): the
     # per-gaussian kernels' non-consecutive-row paths, which M = N never takes
     "config3_halfculled": (1_000_000, 1920, 1080, 3, True),
+    # not a BASELINE config: config3's gaussians in Morton order (morton_order), the memory order of a training run
+    "config3_morton": (1_000_000, 1920, 1080, 3, True),
 }

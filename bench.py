@@ -113,6 +113,8 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
     cam = scene.make_camera(W, H, 0)
     if name == "config3_halfculled":
         params = scene.cull_half(params)
+    if name == "config3_morton":
+        params = scene.morton_order(params)
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
     dgi = torch.as_tensor(scene.make_grad_image(W, H)).to(dev)
     ctx = raster.RasterContext(N, W, H)
@@ -217,6 +219,8 @@ def main():
     params = scene.make_gaussians(N, W, H, L)
     if args.workload == "config3_halfculled":
         params = scene.cull_half(params)
+    if args.workload == "config3_morton":
+        params = scene.morton_order(params)
     cam = scene.make_camera(W, H, view_index=rank)  # every rank its own training view
     gi = scene.make_grad_image(W, H)
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
@@ -300,14 +304,14 @@ def main():
     # profiles/traffic.json, divided by the launch duration measured live above)
     alg_bytes = (76 * S_eff + 20 * P) if do_bwd else (40 * S_eff + 20 * P)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = valu_insts = None
+    traffic = valu_insts = valu_busy = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")  # filled from the rocprofv3 --pmc passes (profiles/README.md)
     if os.path.exists(tfile) and args.workload == "config3":
         try:
             tj = json.load(open(tfile))
-            traffic, valu_insts = tj.get(dom), tj.get(dom + "_valu_insts")
+            traffic, valu_insts, valu_busy = tj.get(dom), tj.get(dom + "_valu_insts"), tj.get(dom + "_valu_busy")
         except Exception:
-            traffic = valu_insts = None
+            traffic = valu_insts = valu_busy = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                 "avg_launch_ms": dom_ms}
@@ -316,9 +320,12 @@ def main():
         ginst = valu_insts / (dom_ms * 1e-3) / 1e9
         roofline_valu = {"kernel": dom, "bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST,
                          "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST,
-                         "valu_instructions_per_launch": valu_insts,
-                         "note": "SQ_INSTS_VALU per launch (profiles/, same workload) / live launch duration; peak = "
-                                 "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
+                         "valu_instructions_per_launch": valu_insts, "valu_busy_profiled": valu_busy,
+                         "note": "achieved = SQ_INSTS_VALU per launch (profiles/, same workload) / live launch duration; "
+                                 "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 v_fma_f32 (MI355X_MICROARCH.md); "
+                                 "valu_busy_profiled = rocprof's VALUBusy (4 x SQ_ACTIVE_INST_VALU / SIMD cycles) of "
+                                 "the profiled launch: the kernel's mix (DPP, min/max, compares, selects, exp, rcp) "
+                                 "issues at 4.2-8.3 cycles per instruction, not 2 (profiles/microbench/)"}
 
     # ---- forward-only rate (render fps), outside the timed region
     torch.cuda.synchronize()
@@ -374,7 +381,7 @@ def main():
     extra = None
     if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
         extra = {}
-        for name in ("config3_halfculled", "dense4m"):
+        for name in ("config3_halfculled", "config3_morton", "dense4m"):
             try:
                 extra[name] = extra_workload(torch, scene, raster, name, dev)
             except Exception as e:  # never lose the headline line to a side measurement

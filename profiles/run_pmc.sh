@@ -2,13 +2,14 @@
 # Collects per-kernel PMC counters for the bench workload in separate passes (never combined with tracing).
 # usage (on the GPU box, from the repo root): bash profiles/run_pmc.sh <outdir>
 set -e
+export GSPLAT_BENCH_TRAIN_STEP=0
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/$OUT/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-workloads > $R/$OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU

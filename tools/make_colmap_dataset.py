@@ -10,7 +10,7 @@ are rendered -- with this repo's own rasterizer -- from a procedural ground-trut
 a ground disc, a table with an object in the centre, a ring of bushes; cameras orbit on a ring looking inwards.
 The SfM point cloud is a noisy subsample of the ground-truth centres.  Deterministic for a given --seed.
 
-    python tools/make_colmap_dataset.py <root> [--name garden] [--views 185] [--gt 1200000] [--points 138000]
+    python tools/make_colmap_dataset.py <root> [--name garden] [--views 185] [--gt 3000000] [--points 138000]
 """
 import argparse
 import importlib
@@ -61,7 +61,7 @@ def look_at(C, target):
 def texture(p, rng_phase):
     """smooth procedural colour in [0,1]^3 with a few octaves: something a radiance field can learn."""
     out = np.zeros((len(p), 3))
-    for o, (freq, amp) in enumerate(((0.9, 0.30), (2.7, 0.22), (7.1, 0.14), (19.0, 0.08))):
+    for o, (freq, amp) in enumerate(((0.9, 0.25), (2.7, 0.20), (7.1, 0.15), (19.0, 0.12), (47.0, 0.10), (113.0, 0.08))):
         for c in range(3):
             k = rng_phase[o, c, :3] * freq
             out[:, c] += amp * np.sin(p @ k + rng_phase[o, c, 3] * 6.283)
@@ -76,7 +76,7 @@ def ground_truth(n, rng):
     # ground disc (y = 0.9 is "down": COLMAP's y axis points down), radius 6
     r = 6.0 * np.sqrt(rng.uniform(0, 1, n_ground))
     a = rng.uniform(0, 2 * math.pi, n_ground)
-    parts.append((np.c_[r * np.cos(a), 0.9 + 0.01 * rng.normal(size=n_ground), r * np.sin(a)], 0.026, 0.35))
+    parts.append((np.c_[r * np.cos(a), 0.9 + 0.01 * rng.normal(size=n_ground), r * np.sin(a)], 0.016, 0.35))
     # table top + a vase-like object of revolution in the centre
     nt = n_table // 2
     r = 0.9 * np.sqrt(rng.uniform(0, 1, nt))
@@ -87,19 +87,20 @@ def ground_truth(n, rng):
     rad = 0.16 + 0.12 * np.sin(h * 5.0) ** 2 + 0.05 * h
     a = rng.uniform(0, 2 * math.pi, nv)
     vase = np.c_[rad * np.cos(a), 0.2 - 0.75 * h, rad * np.sin(a)] + 0.003 * rng.normal(size=(nv, 3))
-    parts.append((np.r_[table, vase], 0.011, 0.30))
+    parts.append((np.r_[table, vase], 0.007, 0.30))
     # a ring of bushes: volumetric blobs between radius 2.2 and 5
     nb = 60
     centres = np.c_[rng.uniform(2.2, 5.0, nb), rng.uniform(-0.2, 0.6, nb), rng.uniform(0, 2 * math.pi, nb)]
     which = rng.integers(0, nb, n_bush)
     cr, cy, ca = centres[which].T
     blob = rng.normal(size=(n_bush, 3)) * np.array([0.28, 0.30, 0.28])
-    parts.append((np.c_[cr * np.cos(ca), cy, cr * np.sin(ca)] + blob, 0.030, 0.40))
+    parts.append((np.c_[cr * np.cos(ca), cy, cr * np.sin(ca)] + blob, 0.018, 0.40))
     xyz = np.concatenate([p for p, _, _ in parts])
     sigma = np.concatenate([np.full(len(p), s) for p, s, _ in parts])
     jitter = np.concatenate([np.full(len(p), j) for p, _, j in parts])
-    phase = rng.uniform(-1, 1, (4, 3, 4))
-    rgb01 = texture(xyz, phase)
+    phase = rng.uniform(-1, 1, (6, 3, 4))
+    # per-gaussian colour jitter on top of the smooth texture: pixel-scale detail, what drives densification
+    rgb01 = np.clip(texture(xyz, phase) + 0.07 * rng.normal(size=(len(xyz), 3)), 0.02, 0.98)
     scale = np.log(sigma[:, None] * np.exp(jitter[:, None] * rng.normal(size=(len(xyz), 3))))
     quat = rng.normal(size=(len(xyz), 4))
     opacity = rng.uniform(1.5, 4.0, len(xyz))
@@ -138,7 +139,7 @@ def main():
     ap.add_argument("--full-height", type=int, default=3361)
     ap.add_argument("--focal", type=float, default=3838.0)
     ap.add_argument("--downsample", type=int, default=4)
-    ap.add_argument("--gt", type=int, default=1_200_000, help="ground-truth gaussians")
+    ap.add_argument("--gt", type=int, default=3_000_000, help="ground-truth gaussians")
     ap.add_argument("--points", type=int, default=138_000, help="SfM points written to points3D.bin")
     ap.add_argument("--seed", type=int, default=0x3D65)
     args = ap.parse_args()

@@ -1,9 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>   e.g. r02
+# bench line, rocprofv3 kernel-trace summary of the same command, and the PMC passes (counters in their own runs, never
+# combined with tracing); everything lands under gpurun_out/<tag>_*, from where the summaries are copied to profiles/.
 set -e
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/r01_bench.json
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+export GSPLAT_BENCH_TRAIN_STEP=0   # the profiled runs: the headline workload's kernels only
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-workloads > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats.log 2>&1
 cd $GRAFT_REPO_ROOT
-bash profiles/run_pmc.sh gpurun_out/pmc_final > gpurun_out/pmc_final.log 2>&1
-python3 profiles/summarize_pmc.py gpurun_out/pmc_final > gpurun_out/r01_pmc_summary.json
-ls -t gpurun_out/stats/runc/*kernel_stats.csv | head -1
+cp "$(ls -t gpurun_out/${TAG}_stats/*/*kernel_stats.csv | head -1)" gpurun_out/${TAG}_kernel_stats.csv
+bash profiles/run_pmc.sh gpurun_out/${TAG}_pmc > gpurun_out/${TAG}_pmc.log 2>&1
+python3 profiles/summarize_pmc.py gpurun_out/${TAG}_pmc > gpurun_out/${TAG}_pmc_summary.json
+python3 profiles/make_traffic.py gpurun_out/${TAG}_pmc_summary.json > gpurun_out/${TAG}_traffic.json
+head -12 gpurun_out/${TAG}_kernel_stats.csv
