@@ -29,6 +29,7 @@
 #include "gs_render.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef GS_ABLATE
 #define GS_ABLATE 0
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
   // a 36-lane instruction), and the merge across the tile's 16 blocks needs one atomic per trip.
   constexpr int kAcc = 10;  // doubles per slot (nine used): 80 bytes = 5 x the list entry's byte offset
-  __shared__ double s_acc[kB * kAcc];
+  __shared__ double s_acc[(kB + 1) * kAcc];  // slot kB: the sentinel's (rows past the end of their list add zeros there)
   __shared__ int s_id[kB];
   // row lists | third record array; both are dead once the batch's trips are done, and the flush parks the nine
   // gradient values per gaussian on top of them (kB*36 bytes: the lists and the first slots of s_r2, not the sentinel)
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // pixel position relative to the tile centre, pixel gradient
   const int red_idx = row_moments9_index(lane);
   const bool red_lane = red_idx >= 0;
+  const unsigned int acc_lane = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)accb + (unsigned int)(red_idx * 8);
 
   for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
     const int count = min(kB, top - base);
@@ -405,55 +407,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       asm volatile("" : "+v"(g0b), "+v"(g1b), "+v"(g2b));
       const RowWeights rw = make_row_weights(lane, (float)((wave & 1) * 8 + (row & 1) * 4 + (j & 3)) - 7.5f,
                                              (float)((wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2)) - 7.5f, g0b, g1b, g2b);
-      for (int i = trips - 1; i >= 0; --i) {
-        // ds_read_u16 zero-extends; read through asm, the compiler would add an "and 0xffff" to every trip
-        int off;
-        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(list_lds + 2 * i) : "memory");
-        const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
+      // The loop is bound by VALU issue at the measured per-instruction costs (tools/valu_cost_model.py: compares,
+      // selects and min/max cost 4.4 cycles per wave instruction against 2.9 for a multiply), so it exists twice: when
+      // every pixel of the wave needs the whole batch (no pixel stopped inside it: the common case), the per-trip
+      // "slot below the pixel's stop index" compare is dropped.
+      auto run_trips = [&](auto check_n) {
+        constexpr bool kCheckN = decltype(check_n)::value;
+        for (int i = trips - 1; i >= 0; --i) {
+          // ds_read_u16 zero-extends; read through asm, the compiler would add an "and 0xffff" to every trip
+          int off;
+          asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(list_lds + 2 * i) : "memory");
+          const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
 #if GS_ABLATE == 4
-        const float4 c = make_float4(0.5f, 0.25f, 0.125f, 0.0f);
+          const float4 c = make_float4(0.5f, 0.25f, 0.125f, 0.0f);
 #else
-        const float4 c = *reinterpret_cast<const float4 *>(r2b + off);
+          const float4 c = *reinterpret_cast<const float4 *>(r2b + off);
 #endif
-        const float dx = a.x - fpx, dy = a.y - fpy;
-        // opa * exp(power): d alpha / d gg . gg (the reference differentiates through the 0.99 cap as if absent)
-        float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);
-        float alpha = fminf(kAlphaMax, og);
-        // a row past the end of its list reads the sentinel record (alpha 0).  n is 0 for pixels outside the image,
-        // so "inside" needs no separate test.
-        const bool valid = (alpha >= kAlphaMin) && (off < n_rel);
-        if (__ballot(valid) == 0ull) continue;
+          const float dx = a.x - fpx, dy = a.y - fpy;
+          // opa * exp(power): d alpha / d gg . gg (the reference differentiates through the 0.99 cap as if absent)
+          float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);
+          float alpha = fminf(kAlphaMax, og);
+          // a row past the end of its list reads the sentinel record (alpha 0).  n is 0 for pixels outside the image,
+          // so "inside" needs no separate test.
+          const bool valid = kCheckN ? ((alpha >= kAlphaMin) && (off < n_rel)) : (alpha >= kAlphaMin);
+          if (__ballot(valid) == 0ull) continue;
 #if GS_ABLATE == 8
-        asm volatile("" ::"v"(og));
-        continue;
+          asm volatile("" ::"v"(og));
+          continue;
 #endif
-        alpha = valid ? alpha : 0.0f;
-        og = valid ? og : 0.0f;
-        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
-        T *= inv;                                           // transmittance in front of this splat
-        const float aT = alpha * T;
-        const v2f d01 = v2f{c.x, c.y} - c01;
-        const float d2 = c.z - c2;
-        float ga = __builtin_fmaf(d01.x, g0, __builtin_fmaf(d01.y, g1, d2 * g2));
-        ga = __builtin_fmaf(ga, T, -(tfb * inv));           // d/d alpha (cuda/render_backward.cu:139-151)
-        c01 = __builtin_elementwise_fma(v2f{alpha, alpha}, d01, c01);  // colour behind the next (nearer) splat
-        c2 = __builtin_fmaf(alpha, d2, c2);
-        const float gp = og * ga;                           // d/d power
-        // nine raw sums: aT x pixel gradient (d/d rgb) and the six moments of gp about the tile centre; signs, the
-        // -1/2 factors, (1 - opa), the shift to the gaussian's centre and 0.5*W / 0.5*H are applied once per gaussian
-        // at flush time
+          alpha = valid ? alpha : 0.0f;
+          og = valid ? og : 0.0f;
+          const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+          T *= inv;                                           // transmittance in front of this splat
+          const float aT = alpha * T;
+          const v2f d01 = v2f{c.x, c.y} - c01;
+          const float d2 = c.z - c2;
+          float ga = __builtin_fmaf(d01.x, g0, __builtin_fmaf(d01.y, g1, d2 * g2));
+          ga = __builtin_fmaf(ga, T, -(tfb * inv));           // d/d alpha (cuda/render_backward.cu:139-151)
+          c01 = __builtin_elementwise_fma(v2f{alpha, alpha}, d01, c01);  // colour behind the next (nearer) splat
+          c2 = __builtin_fmaf(alpha, d2, c2);
+          const float gp = og * ga;                           // d/d power
+          // nine raw sums: aT x pixel gradient (d/d rgb) and the six moments of gp about the tile centre; signs, the
+          // -1/2 factors, (1 - opa), the shift to the gaussian's centre and 0.5*W / 0.5*H are applied once per gaussian
+          // at flush time
 #if GS_ABLATE == 2
-        asm volatile("" ::"v"(aT), "v"(gp));
+          asm volatile("" ::"v"(aT), "v"(gp));
 #else
-        const float red = row_moments9(aT, gp, rw);
-        // all-zero sums (rows past their list, blocks without a valid pixel) add nothing: skip their atomics
+          const float red = row_moments9(aT, gp, rw);
 #if GS_ABLATE == 1
-        asm volatile("" ::"v"(red));
+          asm volatile("" ::"v"(red));
 #else
-        if (red_lane && red != 0.0f) atomicAdd(reinterpret_cast<double *>(accb + off * 5 + red_idx * 8), (double)red);
+          // Every lane that holds a sum adds it, zero or not (a compare to skip zeros costs more issue cycles than the
+          // few extra lanes cost the LDS; rows past their list add zeros to the sentinel slot's accumulators).  32-bit
+          // LDS address on purpose: through a generic pointer the compiler forms off * 5 with a 64-bit multiply-add.
+          if (red_lane)
+            __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double *>(acc_lane + __umul24((unsigned int)off, 5u)),
+                                   (double)red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 #endif
-      }
+        }
+      };
+      if (__any(n_rel < count * 16)) run_trips(std::true_type{});
+      else run_trips(std::false_type{});
       GS_LAP(st_loop);
     }
     __syncthreads();

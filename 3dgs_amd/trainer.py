@@ -10,6 +10,7 @@ the view order), so this loop is judged statistically (PSNR, gaussian counts), n
 itself deterministic.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -248,6 +249,12 @@ class Trainer:
 
     def adaptive_density_step(self):  # cuda/trainer.cu:518-779
         c, n = self.cfg, self.num_gaussians
+        if os.environ.get("GSPLAT_DEBUG_DENSITY") and self.rank == 0:
+            avg = (self.opt.uv_grad_accum / self.opt.grad_accum_dur.clamp(min=1).float())
+            q = torch.quantile(avg[:: max(1, n // 500000)], torch.tensor([0.5, 0.9, 0.99, 0.999], device=avg.device)).tolist()
+            print(f"[density] iter {self.iter}: n {n}, avg |grad_uv| quantiles 50/90/99/99.9 % = "
+                  + " ".join(f"{v:.2e}" for v in q) + f", threshold {c['uv_grad_threshold']:.1e}, mean views seen "
+                  f"{self.opt.grad_accum_dur.float().mean().item():.1f}", flush=True)
         max_scale = self.scene_extent * 0.1
         clone_thresh = self.scene_extent * 0.01
         prune, clone, split, keep, (n_prune, n_clone, n_split) = ops.density_masks(

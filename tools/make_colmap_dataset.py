@@ -59,12 +59,22 @@ def look_at(C, target):
 
 
 def texture(p, rng_phase):
-    """smooth procedural colour in [0,1]^3 with a few octaves: something a radiance field can learn."""
+    """procedural colour in [0,1]^3: a few smooth octaves plus hard-edged stripe and checker patterns -- coherent
+    pixel-scale structure (edges), which is what produces the positional gradients that drive densification."""
     out = np.zeros((len(p), 3))
-    for o, (freq, amp) in enumerate(((0.9, 0.25), (2.7, 0.20), (7.1, 0.15), (19.0, 0.12), (47.0, 0.10), (113.0, 0.08))):
+    for o, (freq, amp) in enumerate(((0.9, 0.22), (2.7, 0.16), (7.1, 0.10))):
         for c in range(3):
             k = rng_phase[o, c, :3] * freq
             out[:, c] += amp * np.sin(p @ k + rng_phase[o, c, 3] * 6.283)
+    for o, (freq, amp) in enumerate(((23.0, 0.16), (61.0, 0.12)), start=3):
+        for c in range(3):
+            k = rng_phase[o, c, :3] * freq
+            out[:, c] += amp * np.sign(np.sin(p @ k + rng_phase[o, c, 3] * 6.283))
+    # random-coloured 3-D cells of 0.09 units (a hash of the cell index): high-contrast patches with sharp borders
+    ci = np.floor(p * 11.0).astype(np.int64)
+    h = (ci[:, 0] * 73856093) ^ (ci[:, 1] * 19349663) ^ (ci[:, 2] * 83492791)
+    for c in range(3):
+        out[:, c] += 0.30 * ((((h >> (8 * c)) & 255) / 255.0) - 0.5)
     return np.clip(0.5 + out, 0.02, 0.98)
 
 
@@ -100,7 +110,7 @@ def ground_truth(n, rng):
     jitter = np.concatenate([np.full(len(p), j) for p, _, j in parts])
     phase = rng.uniform(-1, 1, (6, 3, 4))
     # per-gaussian colour jitter on top of the smooth texture: pixel-scale detail, what drives densification
-    rgb01 = np.clip(texture(xyz, phase) + 0.07 * rng.normal(size=(len(xyz), 3)), 0.02, 0.98)
+    rgb01 = np.clip(texture(xyz, phase) + 0.03 * rng.normal(size=(len(xyz), 3)), 0.02, 0.98)
     scale = np.log(sigma[:, None] * np.exp(jitter[:, None] * rng.normal(size=(len(xyz), 3))))
     quat = rng.normal(size=(len(xyz), 4))
     opacity = rng.uniform(1.5, 4.0, len(xyz))
