@@ -25,13 +25,19 @@ KEYS = dict(dataset_path="toy", downsample_factor=4, output_dir="", print_interv
             delete_opacity_threshold=0.02, uv_grad_threshold=0.0002, split_scale_factor=1.6)
 
 
-def test_disk_to_ply_training_run(tmp_path):
-    root = tmp_path / "data"
+@pytest.fixture(scope="module")
+def toy_root(tmp_path_factory):
+    root = tmp_path_factory.mktemp("data")
     gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_colmap_dataset.py"), str(root), "--name", "toy",
                           "--views", "24", "--full-width", "1280", "--full-height", "832", "--focal", "950",
                           "--gt", "60000", "--points", "6000"], capture_output=True, text=True, timeout=600)
     assert gen.returncode == 0, gen.stdout[-1500:] + gen.stderr[-3000:]
     assert len(os.listdir(root / "toy" / "images_4")) == 24
+    return root
+
+
+def test_disk_to_ply_training_run(tmp_path, toy_root):
+    root = toy_root
     cfg = dict(KEYS, output_dir=str(tmp_path / "renders"))
     (tmp_path / "toy.yaml").write_text("".join(f"{k}: {v}\n" for k, v in cfg.items()))
     env = dict(os.environ, GSPLAT_SUMMARY_JSON=str(tmp_path / "summary.json"))
@@ -52,3 +58,28 @@ def test_disk_to_ply_training_run(tmp_path):
     # a wrong argv is the reference's usage error
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "one"], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "Usage:" in bad.stderr
+
+
+def test_view_sharded_run_from_disk(tmp_path, toy_root):
+    """The same program as two ranks (one process per rank, gloo so that both can share this GPU): every iteration
+    trains on two views, the gradients are exchanged, and rank 0 writes the PLY (BASELINE config 5's shape)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cfg = dict(KEYS, output_dir=str(tmp_path / "renders"), num_iters=120, adaptive_control_start=40,
+               adaptive_control_interval=40, adaptive_control_end=110, add_sh_band_interval=50)
+    (tmp_path / "toy.yaml").write_text("".join(f"{k}: {v}\n" for k, v in cfg.items()))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_NO_RENDER_DUMPS="1",
+                   GSPLAT_SUMMARY_JSON=str(tmp_path / "summary2.json"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "train.py"), str(tmp_path / "toy.yaml"), str(toy_root)],
+                                      cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=1200)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-2000:] + outs[1][-2000:]
+    s = json.load(open(tmp_path / "summary2.json"))
+    assert s["world"] == 2 and s["iterations"] == 120 and np.isfinite(s["psnr_test"])
+    assert s["psnr_test"] > s["evals"][0][1] + 2.0, s
+    assert (tmp_path / "gaussians.ply").exists()

@@ -67,8 +67,10 @@ def _full_size_bookkeeping(fwd, ref, W, H, what):
             f"{len(rep['only_ref'])} only in the oracle's; ceil'ed radii differing: {len(rep['radius_diff'])}; worst "
             f"borderline margins: OBB/tile slack {worst['slack_px']:.2e} px, alpha/T {worst['alpha_rel']:.2e} relative")
     print(line)
-    assert rep["mean_l1"] < 1e-5 and rep["p9999_l1"] < 5e-3, line
-    assert rep["frac_above"] <= 2e-4 and rep["n_mismatch"] <= 2e-4 * W * H, line
+    # r02 figures on MI355X: config3 1 pixel of 2 073 600 above 1e-4 (max 1.7e-3), 6 stop-index mismatches, identical
+    # lists; config2 1 pixel of 640 000 (max 2.8e-4); the bars below leave a factor ~20 for other boxes / libm builds
+    assert rep["mean_l1"] < 1e-6 and rep["p9999_l1"] < 1e-4, line
+    assert rep["frac_above"] <= 1e-5 and rep["n_mismatch"] <= 1e-4 * W * H, line
     assert len(rep["only_gpu"]) + len(rep["only_ref"]) <= 1e-5 * rep["S_ref"] + 2, line
     return rep
 
