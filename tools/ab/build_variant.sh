@@ -1,10 +1,16 @@
 #!/bin/bash
-# usage: tools/ab/build_variant.sh <tag> <gs_render.hip variant> [extra flags]: links tools/ab/lib<tag>.so from the
-# current objects with gs_render.o replaced by the given source (same flags as the Makefile)
-tag=$1; src=$2; shift 2
+# usage: tools/ab/build_variant.sh <tag> <source.hip> [extra flags]: links tools/ab/lib<tag>.so from the current objects with
+# the object of the given source (its basename decides which: gs_render.hip, gs_binning.hip, ...) rebuilt from that file
+# with the Makefile's flags plus the extra ones
+tag=$1; src=$(readlink -f "$2"); shift 2
+name=$(basename "$src" .hip)
 cd "$(dirname "$0")/../../3dgs_amd/csrc" || exit 1
-cp "$src" ./_variant_render.hip
+cp "$src" ./_variant_$name.hip
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -mllvm -amdgpu-atomic-optimizer-strategy=None \
-  -Wno-unused-function "$@" -c -o /tmp/_variant_render_$tag.o ./_variant_render.hip || { rm -f ./_variant_render.hip; exit 1; }
-rm -f ./_variant_render.hip
-hipcc --offload-arch=gfx950 -shared -o ../../tools/ab/lib$tag.so gs_common.o gs_pergaussian.o gs_binning.o /tmp/_variant_render_$tag.o gs_fused.o gs_loss.o gs_init.o gs_density.o
+  -Wno-unused-function "$@" -c -o /tmp/_variant_${name}_$tag.o ./_variant_$name.hip || { rm -f ./_variant_$name.hip; exit 1; }
+rm -f ./_variant_$name.hip
+objs=""
+for o in gs_common gs_pergaussian gs_binning gs_render gs_fused gs_loss gs_init gs_density; do
+  if [ "$o" == "$name" ]; then objs="$objs /tmp/_variant_${name}_$tag.o"; else objs="$objs $o.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -o ../../tools/ab/lib$tag.so $objs
