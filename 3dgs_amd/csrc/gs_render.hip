@@ -43,6 +43,7 @@
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
+__device__ unsigned long long gs_stamp_fwd[(1 << 16) * GS_STAMP_WORDS];  // render_fwd: same layout, phases mapped below
 #define GS_NOW() ((unsigned long long)__builtin_readcyclecounter())
 #define GS_LAP(acc) do { const unsigned long long _n = GS_NOW(); (acc) += _n - st_last; st_last = _n; } while (0)
 #else
@@ -155,6 +156,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   const int tile = block_to_tile(blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
+#if GS_STAMP
+  const unsigned long long st_t0 = GS_NOW(), st_rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0, st_bar = 0, st_bar1 = 0, st_bar2 = 0, st_stage = 0, st_lists = 0, st_loop = 0, st_trips = 0, st_batches = 0;
+#endif
   if (tid == 0) {
     s_r0[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     s_r1[kBatch] = sentinel_r1();
@@ -182,7 +187,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     // rebuilt per batch instead of living in registers across the compositing loop
     int t = tid;
     asm volatile("" : "+v"(t));
+#if GS_STAMP
+    ++st_batches;
+    GS_LAP(st_lists);  // (prologue of the first batch; nothing between the batches)
+#endif
     __syncthreads();
+    GS_LAP(st_bar);
     if (t < count) {
       const int g = sorted[start + base + t];
       SplatRec s = load_record<kPacked>(g, recs, raw);
@@ -192,7 +202,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
       stage_record(s);
       s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
     }
+    GS_LAP(st_stage);
     __syncthreads();
+    GS_LAP(st_bar1);
     if (live > 0) {
       // rows whose 16 pixels are all saturated (or outside) need no list
       const int big = kBatch;
@@ -204,6 +216,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
                                            (unsigned int)((satmask >> 32) & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 48) & 0xFFFFull) == 0xFFFFu ? 0 : big, 2);
       const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+#if GS_STAMP
+      st_trips += (trips + 1) / 2;
+      GS_LAP(st_lists);
+#endif
       for (int i = 0; i < trips; i += 2) {
         // two list entries per trip: both records are fetched and both exponentials evaluated before the
         // (sequential) blending; a row past the end of its list reads the sentinel record and blends with alpha 0
@@ -246,7 +262,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
         }
       }
     }
-    if (__syncthreads_and(live <= 0 ? 1 : 0)) break;
+    GS_LAP(st_loop);
+    const int all_done = __syncthreads_and(live <= 0 ? 1 : 0);
+    GS_LAP(st_bar2);
+    if (all_done) break;
   }
   if (inside) {
     const int pid = py * width + px;
@@ -257,6 +276,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     image[3 * pid + 1] = ag + Tout * bg;
     image[3 * pid + 2] = ab + Tout * bg;
   }
+#if GS_STAMP
+  if (lane == 0) {
+    unsigned long long *o = gs_stamp_fwd + ((size_t)blockIdx.x * 4 + wave) * GS_STAMP_WORDS;
+    o[0] = (unsigned long long)tile; o[1] = st_rt0; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = GS_NOW() - st_t0;
+    o[4] = st_bar; o[5] = st_stage; o[6] = st_lists; o[7] = st_loop; o[8] = 0; o[9] = st_trips; o[10] = st_batches;
+    o[11] = 0; o[12] = st_bar1; o[13] = st_bar2; o[14] = 0; o[15] = (unsigned long long)wave;
+  }
+#endif
 }
 
 __device__ __forceinline__ int row_max_int(int v) {  // max over the 16 lanes of a row, in every lane of the row
@@ -578,6 +605,10 @@ extern "C" {
 int gsplat_debug_read_stamps(unsigned long long *dst, size_t words) {
   (void)hipDeviceSynchronize();
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gs_stamp_buf), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+int gsplat_debug_read_stamps_fwd(unsigned long long *dst, size_t words) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gs_stamp_fwd), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }
 #endif
 

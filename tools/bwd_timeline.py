@@ -12,6 +12,7 @@ import torch
 scene = importlib.import_module("3dgs_amd.scene"); raster = importlib.import_module("3dgs_amd.raster")
 lib = importlib.import_module("3dgs_amd._lib").load()
 name = sys.argv[1] if len(sys.argv) > 1 else "config3"
+which = sys.argv[2] if len(sys.argv) > 2 else "bwd"   # "fwd": render_fwd's stamps (flush / barrier-after-flush columns unused)
 N, W, H, L, _ = scene.WORKLOADS[name]
 cfg = scene.CONFIG
 params = scene.make_gaussians(N, W, H, L)
@@ -29,14 +30,15 @@ ntiles = ((W + 15) // 16) * ((H + 15) // 16)
 nblocks = (ntiles + 7) // 8 * 8
 WORDS = 16
 buf = np.zeros(nblocks * 4 * WORDS, np.uint64)
-lib.gsplat_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-rc = lib.gsplat_debug_read_stamps(buf.ctypes.data, buf.size)
+reader = lib.gsplat_debug_read_stamps_fwd if which == "fwd" else lib.gsplat_debug_read_stamps
+reader.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+rc = reader(buf.ctypes.data, buf.size)
 assert rc == 0, rc
 s = buf.reshape(nblocks * 4, WORDS).astype(np.float64)
 s = s[s[:, 2] > 0]  # waves that ran (padding blocks and skipped tiles write nothing)
 tile, rt0, rt1, cyc, bar0, stage, lists, loop, flush, trips, batches, xcc, bar1, bar2, bar3, wv = s.T
 bar = bar0 + bar1 + bar2 + bar3
-print(f"{name}: {len(s)} waves stamped, {len(np.unique(tile))} tiles")
+print(f"{name} ({which}): {len(s)} waves stamped, {len(np.unique(tile))} tiles")
 t0 = rt0.min(); dur_us = (rt1.max() - t0) / 100.0  # s_memrealtime ticks at 100 MHz
 print(f"launch span {dur_us:.1f} us (first wave start -> last wave end)")
 tot = cyc.sum()
