@@ -68,10 +68,10 @@ def decode_image(path, width, height, device):
     import torch
     from PIL import Image
     with Image.open(path) as im:
-        a = np.asarray(im.convert("RGB"))
+        a = np.array(im.convert("RGB"))  # a writable copy: torch.from_numpy refuses to share a read-only buffer silently
     if a.shape[0] != height or a.shape[1] != width:
         raise RuntimeError(f"{path}: {a.shape[1]}x{a.shape[0]} pixels, the camera says {width}x{height}")
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device).to(torch.float32).mul_(1.0 / 255.0)
+    return torch.from_numpy(a).to(device).to(torch.float32).mul_(1.0 / 255.0)
 
 
 def load_scene(config, root_dir, device="cuda", log=print):

@@ -219,14 +219,3 @@ class ViewShardedStep:
         if self.world > 1:
             self.exchange_gradients(cam)
         return fwd
-
-    def local_packed(self, cam):
-        """Single-process use (world 1): this view's gradients in the packed global-order layout, no collective."""
-        if self._blind:
-            self._reduce_buf.zero_()
-            self.packed.zero_()
-            return self.packed
-        if self.with_uv_norm:
-            self.raster.pack_uv_grad_norm(self.ctx, self.grads, self.N, self.uv_norm_sum)
-        self.ctx.pack_gradients_global(self.grads, self.l_max, self.N, self.packed)
-        return self.packed
