@@ -172,6 +172,23 @@ def main(argv=None, log=print):
             save_render(img, os.path.join(config["output_dir"], f"rendered_image_{done}.png"))
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if os.environ.get("GSPLAT_DEBUG_STAGES") and rank == 0 and world == 1:
+        # where the GPU time of an iteration goes at the end of training: 50 more iterations with every stage of the
+        # rasterizer bracketed by events (diagnostic; they move the parameters a little further)
+        ctx = trainer._context_for(trainer.num_gaussians)
+        ctx.set_timing(True)
+        ta = time.perf_counter()
+        trainer.train(50, loss_every=0)
+        torch.cuda.synchronize()
+        per_it = (time.perf_counter() - ta) / 50 * 1e3
+        st = ctx.get_timing()
+        ctx.set_timing(False)
+        f = ctx.rasterize_image(dict(trainer.params), views[0][0], trainer.cfg, 0.0, trainer.l_max)
+        lens = (f["ranges"][1:] - f["ranges"][:-1]).float()
+        log(f"[stages] {per_it:.3f} ms per iteration at {trainer.num_gaussians} gaussians; rasterizer stages (ms): "
+            + ", ".join(f"{k} {v[0]:.3f}" for k, v in st.items() if v[1])
+            + f"; view 0: M {f['num_culled']}, candidate pairs {f['num_pairs']}, instances {f['num_splats']}, tile lists "
+              f"mean {lens.mean().item():.0f} / max {lens.max().item():.0f}", flush=True)
     train_psnr = trainer.evaluate(views[:: max(1, len(views) // 16)])
     test_psnr = trainer.evaluate(test_views) if test_views else float("nan")
     if rank == 0:

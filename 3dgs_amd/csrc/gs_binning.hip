@@ -619,12 +619,56 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
   __syncthreads();
   // the compacted gaussians of this workgroup's slice of global indices (rank = exclusive scan of the cull mask)
   const int lo = rank[(long long)N * blockIdx.x / kBinBlocks], hi = rank[(long long)N * (blockIdx.x + 1) / kBinBlocks];
-  for (int j = lo + threadIdx.x; j < hi; j += kBinThreads) {
-    const unsigned long long pay = ((unsigned long long)float_sort_bits(xyz_c[3 * j + 2]) << 32) | (unsigned int)j;
-    for_each_hit_tile(j, uv, radius, hitmask, ntx, nty, [&](int tile) {
-      const int pos = atomicAdd(&s_cur[tile], 1);
-      if (pos < capacity) payload[pos] = pay;
-    });
+  const int lane = threadIdx.x & 63;
+  auto place = [&](int tile, unsigned long long pay) {
+    const int pos = atomicAdd(&s_cur[tile], 1);
+    if (pos < capacity) payload[pos] = pay;
+  };
+  // wave-uniform trip count: rectangles of more than 64 tiles carry no hit mask and repeat the separating-axis tests;
+  // one lane walking thousands of tiles alone decided this kernel's duration on scenes with large splats, so the wave
+  // takes those one at a time, every lane testing every 64th tile of the rectangle's clipped span (the same functions
+  // on the same broadcast inputs as the count in preprocess_kernel: the same instances).
+  for (int jb = lo + (int)(threadIdx.x - lane); jb < hi; jb += kBinThreads) {
+    const int j = jb + lane;
+    float4 rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float u = 0.0f, v = 0.0f;
+    unsigned long long pay = 0ull;
+    bool big = false;
+    if (j < hi) {
+      rd = reinterpret_cast<const float4 *>(radius)[j];
+      u = uv[2 * j]; v = uv[2 * j + 1];
+      pay = ((unsigned long long)float_sort_bits(xyz_c[3 * j + 2]) << 32) | (unsigned int)j;
+      const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
+      const int rh = r.y1 - r.y0;
+      if (r.x1 > r.x0 && rh > 0) {
+        if ((r.x1 - r.x0) * rh <= 64) {
+          unsigned long long m = hitmask[j];
+          const float inv_rh = 1.0f / (float)rh;  // b / rh for b < 64, rh <= 64: exact through the float reciprocal
+          while (m != 0ull) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int col = (int)(((float)b + 0.5f) * inv_rh), row = b - col * rh;
+            place((r.y0 + row) * ntx + r.x0 + col, pay);
+          }
+        } else {
+          big = true;
+        }
+      }
+    }
+    for (unsigned long long todo = __ballot(big); todo != 0ull; todo &= todo - 1ull) {
+      const int owner = __builtin_ctzll(todo);
+      const float ou = __shfl(u, owner, 64), ov = __shfl(v, owner, 64);
+      const float o0 = __shfl(rd.x, owner, 64), o1 = __shfl(rd.y, owner, 64), o2 = __shfl(rd.z, owner, 64), o3 = __shfl(rd.w, owner, 64);
+      const unsigned long long opay = __shfl(pay, owner, 64);
+      const TileRect r = coarse_rect(ou, ov, o0, ntx, nty);
+      const Obb ob = make_obb(ou, ov, o0, o1, o2, o3);
+      const TileRect sp = obb_span(ob, r);
+      const int sh = sp.y1 - sp.y0, total = (sp.x1 - sp.x0) * sh;
+      for (int p = lane; p < total; p += 64) {
+        const int tx = sp.x0 + p / sh, ty = sp.y0 + p % sh;
+        if (obb_hits_tile(ob, tx, ty)) place(ty * ntx + tx, opay);
+      }
+    }
   }
 }
 

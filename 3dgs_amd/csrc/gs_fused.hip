@@ -192,6 +192,8 @@ __global__ __launch_bounds__(kBlock) void project_cull_kernel(const float *__res
   flags[i] = k ? 1 : 0;
 }
 
+constexpr int kCoopTiles = 64;  // candidate tiles above which a splat's tile tests are shared by its wave
+
 struct PreOut {
   int *c2g;
   float *xyz_c, *uv, *sigma, *conic, *J, *rgb, *radius;
@@ -224,12 +226,19 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
   const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks) + (blockIdx.x == gs::kBinBlocks - 1 ? 1 : 0);
   unsigned long long coarse = 0;
-  for (int i = lo + threadIdx.x; i < hi; i += gs::kBinThreads) {
+  const int lane = threadIdx.x & 63;
+  // wave-uniform trip count: the tiles of LARGE splats are tested by the whole wave together (below)
+  for (int ib = lo + (int)(threadIdx.x - lane); ib < hi; ib += gs::kBinThreads) {
+  const int i = ib + lane;
   // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
   // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
-  if (i <= N && i >= rank[N]) o.counts[i] = 0;
-  if (i < N && mask[i]) {
-  const int j = rank[i];
+  if (i < hi && i <= N && i >= rank[N]) o.counts[i] = 0;
+  int j = 0, hits = 0, span_n = 0;
+  unsigned long long hm = 0ull;
+  float bu = 0.0f, bv = 0.0f, br0 = 0.0f, br1 = 0.0f, br2 = 0.0f, br3 = 0.0f;  // what a cooperative test needs of a lane
+  const bool act = i < hi && i < N && mask[i];
+  if (act) {
+  j = rank[i];
   constexpr int n = (L + 1) * (L + 1);
   const gs::Mat34 vw = gs::load_view(view);
   // colour
@@ -246,27 +255,28 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   gs::jacobian(x, y, z, fx, fy, tan_fovx, tan_fovy, J);
   gs::conic_radius(J, sg, vw, mh_dist, con, rad);
   // exact tile count
-  int hits = 0;
-  unsigned long long hm = 0ull;
   const gs::TileRect r = gs::coarse_rect(u, v, rad[0], ntx, nty);
   if (r.x1 > r.x0 && r.y1 > r.y0) {
     coarse += (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
     const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
     const gs::TileRect sp = gs::obb_span(ob, r);
     const int rh = r.y1 - r.y0;
-    for (int tx = sp.x0; tx < sp.x1; ++tx)
-      for (int ty = sp.y0; ty < sp.y1; ++ty) {
-        const bool h = gs::obb_hits_tile(ob, tx, ty);
-        const int bit = (tx - r.x0) * rh + (ty - r.y0);  // position in the full coarse rectangle
-        hits += h ? 1 : 0;
-        hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the binning kernels when the rectangle has <= 64 tiles
-        if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
-      }
+    span_n = max(0, sp.x1 - sp.x0) * max(0, sp.y1 - sp.y0);
+    if (span_n <= kCoopTiles) {
+      for (int tx = sp.x0; tx < sp.x1; ++tx)
+        for (int ty = sp.y0; ty < sp.y1; ++ty) {
+          const bool h = gs::obb_hits_tile(ob, tx, ty);
+          const int bit = (tx - r.x0) * rh + (ty - r.y0);  // position in the full coarse rectangle
+          hits += h ? 1 : 0;
+          hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the binning kernels when the rectangle has <= 64 tiles
+          if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
+        }
+    } else {
+      bu = u; bv = v; br0 = rad[0]; br1 = rad[1]; br2 = rad[2]; br3 = rad[3];
+    }
   }
-  // stores (compacted order)
+  // stores (compacted order); counts and hitmask follow the cooperative tests
   o.c2g[j] = i;
-  o.counts[j] = hits;
-  o.hitmask[j] = hm;
   o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
   o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
   if (o.sigma) {  // null in a render-only context: only the backward and the caller read these four
@@ -278,6 +288,35 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
   const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
   o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
+  }
+  // Large splats (more than kCoopTiles candidate tiles after the axis-aligned clipping: a capture early in training has
+  // gaussians over hundreds or thousands of tiles): one lane walking them alone decided the kernel's duration.  The
+  // wave takes them one at a time: the owner's six numbers are broadcast, every lane rebuilds the same OBB (the same
+  // functions on the same inputs: bit-identical decisions) and tests every 64th tile of the span.  Such splats have
+  // rectangles of more than 64 tiles, so they carry no hit mask.
+  for (unsigned long long big = __ballot(span_n > kCoopTiles); big != 0ull; big &= big - 1ull) {
+    const int owner = __builtin_ctzll(big);
+    const float ou = __shfl(bu, owner, 64), ov = __shfl(bv, owner, 64);
+    const float o0 = __shfl(br0, owner, 64), o1 = __shfl(br1, owner, 64), o2 = __shfl(br2, owner, 64), o3 = __shfl(br3, owner, 64);
+    const gs::TileRect r = gs::coarse_rect(ou, ov, o0, ntx, nty);
+    const gs::Obb ob = gs::make_obb(ou, ov, o0, o1, o2, o3);
+    const gs::TileRect sp = gs::obb_span(ob, r);
+    const int sh = sp.y1 - sp.y0, total = (sp.x1 - sp.x0) * sh;
+    int found = 0;
+    for (int p = lane; p < total + lane; p += 64) {  // uniform trip count: every lane reaches the ballot
+      bool h = false;
+      if (p < total) {
+        const int tx = sp.x0 + p / sh, ty = sp.y0 + p % sh;
+        h = gs::obb_hits_tile(ob, tx, ty);
+        if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
+      }
+      found += __popcll(__ballot(h));
+    }
+    if (lane == owner) hits = found;
+  }
+  if (act) {
+    o.counts[j] = hits;
+    o.hitmask[j] = hm;
   }
   }
   // candidate-pair count (what call 1 of get_sorted_gaussian_list reports): one atomic per wave, spread over 64

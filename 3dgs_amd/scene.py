@@ -81,14 +81,15 @@ def make_camera(width, height, view_index=0):
                 view=view, proj=proj, campos=campos)
 
 
-def make_gaussians(num, width, height, l_max, seed=SEED):
-    """Gaussian parameters in the reference's device layout (cuda_data.cuh:11-16)."""
+def make_gaussians(num, width, height, l_max, seed=SEED, splat_scale=1.0):
+    """Gaussian parameters in the reference's device layout (cuda_data.cuh:11-16).  splat_scale multiplies the
+    median projected size (1.5 px by default: the benchmark scene; real captures early in training are far larger)."""
     fx = width / (2.0 * math.tan(math.radians(30.0)))
     u = (uniform24(seed, 1, num) * 1.10 - 0.05) * width
     v = (uniform24(seed, 2, num) * 1.10 - 0.05) * height
     z = 2.0 + 10.0 * uniform24(seed, 3, num)
     xyz = np.stack([(u - width / 2.0) * z / fx, (v - height / 2.0) * z / fx, z], 1).astype(np.float32)
-    s0 = 1.5 * 7.0 / fx
+    s0 = splat_scale * 1.5 * 7.0 / fx
     scale = np.log(s0 * np.exp(0.35 * normal(seed, 10, 3 * num))).reshape(num, 3).astype(np.float32)
     quaternion = normal(seed, 20, 4 * num).reshape(num, 4).astype(np.float32)
     opacity = (-2.0 + 5.0 * uniform24(seed, 30, num)).astype(np.float32)
@@ -151,4 +152,20 @@ WORKLOADS = {
     "config3_halfculled": (1_000_000, 1920, 1080, 3, True),
     # not a BASELINE config: config3's gaussians in Morton order (morton_order), the memory order of a training run
     "config3_morton": (1_000_000, 1920, 1080, 3, True),
+    # not a BASELINE config: the regime of a capture early in training (the generated garden dataset of DESIGN section 9
+    # after 7 000 iterations: 145 k visible gaussians, 54 candidate tiles and 12.6 instances per gaussian, tile lists of
+    # 420 entries on average): few, large splats at the Mip-NeRF 360 1/4 resolution
+    "bigsplats": (150_000, 1297, 840, 3, True),
 }
+
+
+def make_workload_gaussians(name, seed=SEED):
+    """The gaussians of a named workload, with its variant applied (half culled, Morton order, large splats)."""
+    N, W, H, L, _ = WORKLOADS[name]
+    params = make_gaussians(N, W, H, L, seed, splat_scale=5.0 if name == "bigsplats" else 1.0)
+    if name == "config3_halfculled":
+        params = cull_half(params, seed)
+    if name == "config3_morton":
+        params = morton_order(params)
+    return params
+

@@ -109,12 +109,8 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
     """A non-headline workload, per-stage times only (outside every timed region)."""
     N, W, H, L, _ = scene.WORKLOADS[name]
     cfg = scene.CONFIG
-    params = scene.make_gaussians(N, W, H, L)
+    params = scene.make_workload_gaussians(name)
     cam = scene.make_camera(W, H, 0)
-    if name == "config3_halfculled":
-        params = scene.cull_half(params)
-    if name == "config3_morton":
-        params = scene.morton_order(params)
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
     dgi = torch.as_tensor(scene.make_grad_image(W, H)).to(dev)
     ctx = raster.RasterContext(N, W, H)
@@ -131,7 +127,7 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
         ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    out = {"N": N, "M": M, "S": S, "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
+    out = {"N": N, "M": M, "S": S, "num_pairs": fwd["num_pairs"], "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
            "preprocess": hbm_entry("preprocess", 288 * M + 13 * N, st["preprocess"][0]),
            "preprocess_backward": hbm_entry("preprocess_backward", 560 * M, st["preprocess_backward"][0])}
     ctx.close()
@@ -216,11 +212,7 @@ def main():
     N, W, H, L, do_bwd = scene.WORKLOADS[args.workload]
     cfg = scene.CONFIG
     t0 = time.time()
-    params = scene.make_gaussians(N, W, H, L)
-    if args.workload == "config3_halfculled":
-        params = scene.cull_half(params)
-    if args.workload == "config3_morton":
-        params = scene.morton_order(params)
+    params = scene.make_workload_gaussians(args.workload)
     cam = scene.make_camera(W, H, view_index=rank)  # every rank its own training view
     gi = scene.make_grad_image(W, H)
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
@@ -381,7 +373,7 @@ def main():
     extra = None
     if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
         extra = {}
-        for name in ("config3_halfculled", "config3_morton", "dense4m"):
+        for name in ("config3_halfculled", "config3_morton", "dense4m", "bigsplats"):
             try:
                 extra[name] = extra_workload(torch, scene, raster, name, dev)
             except Exception as e:  # never lose the headline line to a side measurement

@@ -454,6 +454,31 @@ def test_interleaved_culling_at_scale(gpu, scene, orc):
         assert_grad_close(_np(grads[k]), bref[k], "intermediate grad_" + k)
 
 
+@pytest.mark.parametrize("splat_scale", [6.0, 25.0])
+def test_large_splats_match_oracle(gpu, scene, orc, splat_scale):
+    """Splats over tens to thousands of tiles (a capture early in training): their tile tests and placements are shared
+    by the lanes of a wave (preprocess_kernel / bin_scatter_kernel), rectangles above 64 tiles carry no hit mask.  Lists
+    bit-exact against the oracle, image and gradients within tolerance."""
+    torch, raster = gpu, pkg("raster")
+    N, W, H, L = 3000, 640, 360, 1
+    params = scene.make_gaussians(N, W, H, L, splat_scale=splat_scale)
+    params["opacity"][:] -= 3.0  # faint: long lists stay relevant, nothing saturates early
+    cam = scene.make_camera(W, H, 1)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=16)
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    big = (ref["radius"][:, 0] > 64).sum()
+    assert fwd["num_pairs"] > 64 * 0.2 * N and big > 0.05 * N, (fwd["num_pairs"], big)
+    _check_forward(fwd, ref)
+    gi = scene.make_grad_image(W, H)
+    grads = ctx.alloc_gradients(fwd["num_culled"], L)
+    ctx.backward_pass(dp, dc, torch.as_tensor(gi).cuda(), c["bg"], L, grads)
+    _check_backward(grads, orc.backward_pass(ref, cam, gi, c["bg"], L, threads=16))
+
+
 def test_render_only_context(gpu, scene, orc):
     """gsplat_context_set_render_only: same image, counts and lists; the backward-only outputs come back null and the
     backward is refused until the mode is switched off."""

@@ -15,9 +15,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "config3"
 which = sys.argv[2] if len(sys.argv) > 2 else "bwd"   # "fwd": render_fwd's stamps (flush / barrier-after-flush columns unused)
 N, W, H, L, _ = scene.WORKLOADS[name]
 cfg = scene.CONFIG
-params = scene.make_gaussians(N, W, H, L)
-if name == "config3_halfculled":
-    params = scene.cull_half(params)
+params = scene.make_workload_gaussians(name)
 dp, dc = raster.device_params(params), raster.device_camera(scene.make_camera(W, H, 0))
 dgi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
 ctx = raster.RasterContext(N, W, H)
