@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void tile_ranges32_kernel(const unsigned in
 // index, the first step of each merge pairs i with its mirror image), so virtual +infinity padding above `len`
 // never moves and comparators that touch it can simply be skipped: any list length works without padding stores.
 // Lists up to kLdsSort entries are sorted in LDS, longer ones in place in global memory by the same workgroup.
-constexpr int kLdsSort = 4096;
+constexpr int kLdsSort = 16384;  // 128 KB of LDS: the 16-wave instantiation of tile_depth_sort_kernel
 
 // kWaveLocal: the buffer is LDS.  Thread t of a wave owns comparators whose operands lie in that wave's own
 // 128-element span whenever the comparator distance is <= 64, and a wave executes its LDS operations in order, so
@@ -414,7 +414,9 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
     const int tile = long_tiles[1 + t];
     const int start = ranges[tile], len = ranges[tile + 1] - start;
-    if (kWaves == 2 ? len > 2 * kWaveSortMax : len <= 2 * kWaveSortMax) continue;  // the other instantiation's tile
+    // instantiation kWaves takes the lists of (kWaves / 2, kWaves] runs of kWaveSortMax entries (2: from one run up;
+    // 16: also everything longer, in place in global memory)
+    if (len <= (kWaves == 2 ? 1 : kWaves / 2) * kWaveSortMax || (kWaves < 16 && len > kWaves * kWaveSortMax)) continue;
     int n2 = 1;
     while (n2 < len) n2 <<= 1;
     __syncthreads();  // buf is reused across iterations
@@ -472,6 +474,15 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
     if (max_longer > 0 && (longest < 0 || longest > 2 * kWaveSortMax))
       tile_depth_sort_kernel<4><<<std::min(max_longer, 5 * 256), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out,
                                                                                 long_tiles);
+    GS_LAUNCH_CHECK();
+    // dense captures (thousands of entries per tile): 8 and 16 register-sorted runs merged in 64 / 128 KB of LDS
+    const int max8 = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(4 * kWaveSortMax));
+    if (max8 > 0 && (longest < 0 || longest > 4 * kWaveSortMax))
+      tile_depth_sort_kernel<8><<<std::min(max8, 2 * 256), 512, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
+    GS_LAUNCH_CHECK();
+    const int max16 = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(8 * kWaveSortMax));
+    if (max16 > 0 && (longest < 0 || longest > 8 * kWaveSortMax))
+      tile_depth_sort_kernel<16><<<std::min(max16, 256), 1024, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
     GS_LAUNCH_CHECK();
   }
   return GSPLAT_OK;

@@ -335,6 +335,33 @@ def test_few_long_tile_lists_in_a_sparse_scene(gpu, scene, orc):
     _check_forward(fwd, ref)
 
 
+def test_very_long_tile_lists(gpu, scene, orc):
+    """Tile lists of 5 000, 9 000 and 17 500 entries in an otherwise sparse scene: eight and sixteen register-sorted
+    runs merged in 64 / 128 KB of LDS, and beyond 16 384 entries the in-place global-memory network."""
+    raster = pkg("raster")
+    N, W, H, L = 36000, 256, 144, 0
+    params = scene.make_gaussians(N, W, H, L)
+    params["opacity"][:] = -4.0
+    cam = scene.make_camera(W, H)
+    rng = np.random.default_rng(7)
+    for lo, hi, (cu, cv) in ((4000, 9000, (40.0, 40.0)), (9000, 18000, (200.0, 100.0)), (18000, 35500, (120.0, 60.0))):
+        k = hi - lo
+        z = rng.uniform(3.0, 9.0, k)
+        u, v = cu + rng.uniform(-2, 2, k), cv + rng.uniform(-2, 2, k)
+        params["xyz"][lo:hi, 0] = (u - W / 2) * z / cam["fx"]
+        params["xyz"][lo:hi, 1] = (v - H / 2) * z / cam["fy"]
+        params["xyz"][lo:hi, 2] = z
+        params["scale"][lo:hi] = np.log(0.004)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    ctx.set_binning_route(1)  # counting sort + per-tile depth sorts, whatever the density
+    fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
+    lens = np.diff(ref["ranges"])
+    assert lens.max() > 16384 and ((lens > 8192) & (lens <= 16384)).any() and ((lens > 4096) & (lens <= 8192)).any()
+    _check_forward(fwd, ref)
+
+
 def test_factored_exchange_equals_full_rows(gpu, scene):
     """Simulates a 3-rank view-sharded step on one GPU: per-view factored rows, summed like the all-reduce would,
     then unpacked, must equal the sum of the full packed rows of the three views."""
