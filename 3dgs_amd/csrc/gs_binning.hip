@@ -414,9 +414,10 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
     const int tile = long_tiles[1 + t];
     const int start = ranges[tile], len = ranges[tile + 1] - start;
-    // instantiation kWaves takes the lists of (kWaves / 2, kWaves] runs of kWaveSortMax entries (2: from one run up;
-    // 16: also everything longer, in place in global memory)
-    if (len <= (kWaves == 2 ? 1 : kWaves / 2) * kWaveSortMax || (kWaves < 16 && len > kWaves * kWaveSortMax)) continue;
+    // instantiation kWaves takes the handed-over lists of (kWaves / 2, kWaves] runs of kWaveSortMax entries; 2: every
+    // list up to two runs (short lists arrive here when a key has no double form); 16: also everything longer, in place
+    // in global memory
+    if ((kWaves > 2 && len <= kWaves / 2 * kWaveSortMax) || (kWaves < 16 && len > kWaves * kWaveSortMax)) continue;
     int n2 = 1;
     while (n2 < len) n2 <<= 1;
     __syncthreads();  // buf is reused across iterations
