@@ -688,10 +688,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
 // three-kernel rocPRIM scan of a few thousand integers.
 // It also publishes the forward's host record {M | S << 32, candidate pairs, ticket} (see publish_counts_kernel in
 // gs_fused.hip) when `pub` is given: S is known here first, and it saves a launch on the path to the host's wake-up.
+// `cap`: room of the instance buffers.  The kernels queued behind this one run before the host has seen S (see
+// gsplat_rasterize_image), so the ranges they read are clamped to the room: when S does not fit they work on truncated
+// lists inside the buffers, and the host -- which reads the TRUE S from the record -- grows the buffers, calls this
+// kernel again (pub == nullptr) and redoes them.
 __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__restrict__ totals, int *__restrict__ ranges,
                                                           const int *__restrict__ m_total,
                                                           const unsigned long long *__restrict__ pair_counters,
-                                                          volatile unsigned long long *pub, unsigned long long ticket) {
+                                                          volatile unsigned long long *pub, unsigned long long ticket,
+                                                          long long cap) {
   __shared__ int s_part[1024];
   __shared__ int s_longest;  // the longest tile list: the host picks the next forward's binning route by it
   if (threadIdx.x == 0) s_longest = 0;
@@ -721,8 +726,9 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
     }
   }
   int run = s_part[threadIdx.x] - sum;
-  for (int t = lo; t < hi; ++t) { ranges[t] = run; run += totals[t]; }
-  if (threadIdx.x == 1023) ranges[T] = s_part[1023];
+  const int room = (int)min(cap, 0x7FFFFFFFll);
+  for (int t = lo; t < hi; ++t) { ranges[t] = min(run, room); run += totals[t]; }
+  if (threadIdx.x == 1023) ranges[T] = min(s_part[1023], room);
 }
 
 bool binning_supports_counting_sort(int num_tiles) { return num_tiles <= kBinMaxTiles; }
@@ -743,12 +749,20 @@ size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_til
 // left in `table` (kBinBlocks * T ints, followed by T + 1 totals).
 int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
                     const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
-                    hipStream_t st) {
+                    long long capacity, hipStream_t st) {
   const int T = ntx * nty;
   int *totals = table + (size_t)kBinBlocks * T;
   bin_offsets_kernel<<<div_up(T, 64), 256, 0, st>>>(T, table, totals, long_tiles);
   GS_LAUNCH_CHECK();
-  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, m_total, pair_counters, pub, ticket);
+  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, m_total, pair_counters, pub, ticket, capacity);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+// The ranges again, for a larger room (the instance buffers were grown): the totals are still behind the table.
+int binning_ranges_again(int ntx, int nty, int *table, int *ranges, long long capacity, hipStream_t st) {
+  const int T = ntx * nty;
+  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, table + (size_t)kBinBlocks * T, ranges, nullptr, nullptr, nullptr, 0ull, capacity);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

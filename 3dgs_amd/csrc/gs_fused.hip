@@ -31,7 +31,8 @@ bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles
 size_t binning_table_bytes(int num_tiles);
 int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
                     const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
-                    hipStream_t st);
+                    long long capacity, hipStream_t st);
+int binning_ranges_again(int ntx, int nty, int *table, int *ranges, long long capacity, hipStream_t st);
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
                              const int *table, const int *ranges, size_t S, unsigned long long *payload,
@@ -104,6 +105,7 @@ struct gsplat_context {
   // state of the last forward
   int N = 0, M = 0, l_max = 0, width = 0, height = 0;
   size_t S = 0;
+  long long last_longest = -1;  // longest tile list of the last counting-sort forward (-1: unknown)
   bool have_forward = false;
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
@@ -702,11 +704,17 @@ __global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__res
 
 int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   int rc;
+  const void *pay_before = c->pay_a.ptr, *sorted_before = c->sorted.ptr;
   if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned int)))) return rc;
   if ((rc = c->keys_b.reserve((S + 1) * sizeof(unsigned int)))) return rc;
   if ((rc = c->pay_a.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
   if ((rc = c->pay_b.reserve((S + 1) * sizeof(unsigned long long)))) return rc;
   if ((rc = c->sorted.reserve((S + 1) * sizeof(int)))) return rc;
+  // Fresh instance buffers start as zeros.  The sparse forward queues its sorts and render_fwd before the host has
+  // seen S; when S outgrows the room those kernels run on truncated lists whose slots may not have been written by
+  // this forward -- whatever they hold must still be a valid gaussian id (0, or one of an earlier forward).
+  if (c->pay_a.ptr != pay_before) GS_HIP(hipMemset(c->pay_a.ptr, 0, c->pay_a.bytes));
+  if (c->sorted.ptr != sorted_before) GS_HIP(hipMemset(c->sorted.ptr, 0, c->sorted.bytes));
   if ((rc = c->blockmasks.reserve((S + 1) * sizeof(unsigned short)))) return rc;
   if ((rc = c->temp.reserve(gs::binning_temp_bytes((size_t)c->max_gaussians, S ? S : 1, num_tiles)))) return rc;
   return GSPLAT_OK;
@@ -934,11 +942,18 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   size_t inst_cap = 0;
   // the one host read-back of the forward: M, S (and the candidate count)
   const unsigned long long ticket = ++c->ticket;
+  size_t spec_cap = 0;  // sparse route: room of the instance buffers, what the kernels queued before the wait may use
   if (sparse) {
+    auto room_of = [&]() {
+      return std::min(std::min(c->pay_a.bytes / sizeof(unsigned long long), c->sorted.bytes / sizeof(int)),
+                      std::min(c->blockmasks.bytes / sizeof(unsigned short), c->keys_a.bytes / sizeof(unsigned int)));
+    };
+    if (room_of() < 2 && (rc = reserve_instances(c, 4 * (size_t)N, num_tiles))) return rc;
+    spec_cap = room_of() - 1;
     c->mark(1, true, st);
     c->mark(2, false, st);
     rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), c->rank.as<int>() + N,
-                             c->pair_counters(), c->d_pub, ticket, st);  // publishes the record too
+                             c->pair_counters(), c->d_pub, ticket, (long long)spec_cap, st);  // publishes the record too
     if (rc) return rc;
   } else {
     rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
@@ -958,6 +973,42 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
                               c->hitmask.as<unsigned long long>(), (long long)inst_cap,
                               c->keys_a.as<unsigned int>(), c->pay_a.as<unsigned long long>(), st);
     if (rc) return rc;
+  }
+  // Sparse route: nothing behind the counts needs them on the HOST -- the placement only needs room for its writes,
+  // the per-tile sorts read `ranges` on the device, the compositing nothing at all.  So scatter, sorts and render_fwd
+  // are queued right here, bounded by the buffers' capacity, and the host sleeps on the read-back while they run (r01
+  // launched them after the wake-up: the GPU idled for the round trip, ~13 us per forward).  Which long-list kernels
+  // to queue follows the previous forward's longest list; afterwards the record is checked, and a forward whose
+  // instances outgrew the buffers or whose longest list needed a kernel that was not queued is redone from the
+  // placement on (results are unaffected: every launch overwrites).
+  auto list_class = [](long long longest) {  // which of the workgroup sort kernels a list of that length needs
+    return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : 1;
+  };
+  auto queue_tail = [&](size_t cap, long long longest_hint) -> int {
+    int r = gs::binning_scatter_and_sort(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(),
+                                         c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
+                                         c->bin_table.as<int>(), c->ranges.as<int>(), cap, c->pay_a.as<unsigned long long>(),
+                                         c->keys_a.as<int>(), c->sorted.as<int>(), longest_hint, st);
+    if (r) return r;
+    c->mark(2, true, st);
+    c->mark(4, false, st);
+    r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
+                              c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
+                              c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
+                              ro ? nullptr : c->blockmasks.as<unsigned short>());
+    if (r) return r;
+    c->mark(4, true, st);
+    return GSPLAT_OK;
+  };
+  // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
+  if (c->rows_zeroed) c->backward_seen = false;  // the last forward's cleared rows were never used: rendering only
+  c->rows_zeroed = c->backward_seen && !ro;
+  long long spec_hint = -1;
+  if (sparse) {
+    // `ranges` on the device are clamped to spec_cap (bin_ranges_kernel): whatever S turns out to be, the queued kernels
+    // stay inside the buffers
+    spec_hint = c->last_longest >= 0 ? c->last_longest + c->last_longest / 2 + 64 : -1;  // unknown: every kernel
+    if ((rc = queue_tail(spec_cap, spec_hint))) return rc;
   }
   {
     // Poll the mapped record; every few hundred polls ask the runtime about the stream, which both keeps its
@@ -987,38 +1038,39 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;
   }
-  c->dense_route = gs::binning_next_route_is_radix(sparse, S, num_tiles, (long long)c->h_pub[3]);
+  const long long longest = sparse ? (long long)c->h_pub[3] : -1;
+  c->dense_route = gs::binning_next_route_is_radix(sparse, S, num_tiles, longest);
+  c->last_longest = longest;
   const bool emitted = S <= inst_cap;  // dense route: else grow the instance buffers (synchronises) and emit again
-  const void *keys_before = c->keys_a.ptr;
-  rc = reserve_instances(c, S, num_tiles);
-  if (rc) return rc;
   if (sparse) {
-    // the long-tile counter lives at the head of keys_a and was zeroed by bin_offsets: redo it if the buffer moved
-    if (c->keys_a.ptr != keys_before) GS_HIP(hipMemsetAsync(c->keys_a.ptr, 0, sizeof(int), st));
-    rc = gs::binning_scatter_and_sort(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(),
-                                      c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
-                                      c->bin_table.as<int>(), c->ranges.as<int>(), S, c->pay_a.as<unsigned long long>(),
-                                      c->keys_a.as<int>(), c->sorted.as<int>(), (long long)c->h_pub[3], st);
+    const bool fits = S <= spec_cap;
+    if (!fits || !(spec_hint < 0 || list_class(longest) <= list_class(spec_hint))) {
+      if (!fits) {  // grow (synchronises), then the true ranges
+        if ((rc = reserve_instances(c, S + S / 4, num_tiles))) return rc;
+        if ((rc = gs::binning_ranges_again(ntx, nty, c->bin_table.as<int>(), c->ranges.as<int>(), (long long)S, st))) return rc;
+      }
+      // the long-tile counter lives at the head of keys_a: zeroed by bin_offsets, then used by the queued sorts
+      GS_HIP(hipMemsetAsync(c->keys_a.ptr, 0, sizeof(int), st));
+      if ((rc = queue_tail(S, longest))) return rc;
+    }
   } else {
+    if ((rc = reserve_instances(c, S, num_tiles))) return rc;
     rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                               c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
                               c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
                               c->pay_a.as<unsigned long long>(), c->pay_b.as<unsigned long long>(),
                               c->sorted.as<int>(), c->ranges.as<int>(), c->temp.ptr, c->temp.bytes, st, emitted,
                               c->hitmask.as<unsigned long long>());
+    if (rc) return rc;
+    c->mark(2, true, st);
+    c->mark(4, false, st);
+    rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
+                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
+                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
+                               ro ? nullptr : c->blockmasks.as<unsigned short>());
+    if (rc) return rc;
+    c->mark(4, true, st);
   }
-  if (rc) return rc;
-  c->mark(2, true, st);
-  c->mark(4, false, st);
-  // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
-  if (c->rows_zeroed) c->backward_seen = false;  // the last forward's cleared rows were never used: rendering only
-  c->rows_zeroed = c->backward_seen && !ro;
-  rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
-                             c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
-                             c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
-                             ro ? nullptr : c->blockmasks.as<unsigned short>());
-  if (rc) return rc;
-  c->mark(4, true, st);
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
   c->have_forward = !ro;  // a render-only forward leaves nothing for a backward
   if (out) {

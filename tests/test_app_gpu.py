@@ -30,7 +30,7 @@ def toy_root(tmp_path_factory):
     root = tmp_path_factory.mktemp("data")
     gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_colmap_dataset.py"), str(root), "--name", "toy",
                           "--views", "24", "--full-width", "1280", "--full-height", "832", "--focal", "950",
-                          "--gt", "60000", "--points", "6000"], capture_output=True, text=True, timeout=600)
+                          "--gt", "60000", "--points", "20000"], capture_output=True, text=True, timeout=600)
     assert gen.returncode == 0, gen.stdout[-1500:] + gen.stderr[-3000:]
     assert len(os.listdir(root / "toy" / "images_4")) == 24
     return root
@@ -50,8 +50,8 @@ def test_disk_to_ply_training_run(tmp_path, toy_root):
     assert s["views"] == 24 and s["test_views"] == 3 and s["iterations"] == 400  # every 8th image, sorted by name
     it0, psnr0 = s["evals"][0]
     assert it0 == 0 and np.isfinite(psnr0)                       # the reference evaluates at iteration 0 (iter % 3000)
-    assert s["psnr_test"] > psnr0 + 1.5, (psnr0, s["psnr_test"], run.stdout[-2000:])
-    assert s["gaussians"] != 6000 and s["peak_gaussians"] >= s["gaussians"] * 0.5
+    assert s["psnr_test"] > psnr0 + 1.0, (psnr0, s["psnr_test"], run.stdout[-2000:])
+    assert s["gaussians"] != 20000 and s["peak_gaussians"] >= s["gaussians"] * 0.5
     head = (tmp_path / "gaussians.ply").read_bytes().split(b"end_header\n", 1)[0].decode()
     assert f"element vertex {s['gaussians']}" in head and "f_rest_44" in head  # SH degree 3 reached at iteration 300
     assert (tmp_path / "renders" / "rendered_image_400.png").exists()
@@ -81,5 +81,5 @@ def test_view_sharded_run_from_disk(tmp_path, toy_root):
     assert all(p.returncode == 0 for p in procs), outs[0][-2000:] + outs[1][-2000:]
     s = json.load(open(tmp_path / "summary2.json"))
     assert s["world"] == 2 and s["iterations"] == 120 and np.isfinite(s["psnr_test"])
-    assert s["psnr_test"] > s["evals"][0][1] + 1.0, s
+    assert s["psnr_test"] > s["evals"][0][1] + 0.5, s
     assert (tmp_path / "gaussians.ply").exists()
