@@ -355,11 +355,17 @@ def test_very_long_tile_lists(gpu, scene, orc):
     c = scene.CONFIG
     ctx = raster.RasterContext(N, W, H)
     ctx.set_binning_route(1)  # counting sort + per-tile depth sorts, whatever the density
+    # a forward with short lists first: the next one queues its sort kernels by THIS forward's longest list, finds its
+    # own lists far longer when the counts arrive, and has to redo placement, sorts and compositing
+    plain = scene.make_gaussians(N, W, H, L)
+    short = ctx.rasterize_image(raster.device_params(plain), raster.device_camera(cam), c, 0.5, L)
+    assert int((short["ranges"][1:] - short["ranges"][:-1]).max()) < 1024
     fwd = ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L)
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
     lens = np.diff(ref["ranges"])
     assert lens.max() > 16384 and ((lens > 8192) & (lens <= 16384)).any() and ((lens > 4096) & (lens <= 8192)).any()
     _check_forward(fwd, ref)
+    _check_forward(ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L), ref)
 
 
 def test_factored_exchange_equals_full_rows(gpu, scene):
