@@ -382,7 +382,10 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(scene, args, params, cam, gi, cfg, N, W, H, L, do_bwd)
+        try:
+            cpu = cpu_baseline(scene, args, params, cam, gi, cfg, N, W, H, L, do_bwd)
+        except Exception as e:  # never lose the measured line to the baseline leg
+            cpu = {"error": repr(e)[:300]}
 
     ms = elapsed / args.steps * 1e3
     origin = {"config2": "BASELINE configs[1]", "config3": "BASELINE configs[2]"}.get(args.workload,
