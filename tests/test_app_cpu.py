@@ -66,3 +66,17 @@ def test_test_train_split_follows_the_reference():
 def test_main_usage_error(capsys):
     assert pkg("app").main(["train.py", "only-one-argument"]) == 1  # src/main.cpp:12-15
     assert "Usage:" in capsys.readouterr().err
+
+
+def test_written_config_parses_with_every_key(tmp_path):
+    """tools/write_config.py -> gsplat_parse_config: all 42 keys of ConfigParameters, overrides applied."""
+    import subprocess, sys
+    ds = pkg("dataset")
+    ds.build()
+    out = tmp_path / "garden.yaml"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "write_config.py"), str(out), "num_iters=1234",
+                        "dataset_path=bicycle"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    c = ds.parseConfig(out)
+    assert len(c) == 42 and c["num_iters"] == 1234 and c["dataset_path"] == "bicycle"
+    assert c["max_gaussians"] == 4250000 and c["use_background"] is True and abs(c["uv_grad_threshold"] - 2e-4) < 1e-12
