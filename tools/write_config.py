@@ -4,7 +4,10 @@ hyper-parameters BASELINE config 4 names (the reference's base schedule: 7 000 i
 1/4 resolution), from the defaults the host mirror already carries (3dgs_amd/trainer.py DEFAULT_CONFIG, optimizer.py
 DEFAULT_LR) plus the dataset keys.  Every key of ConfigParameters is required by the parser.
 
-    python tools/write_config.py garden.yaml [key=value ...]      e.g. num_iters=30000 dataset_path=bicycle
+    python tools/write_config.py garden.yaml [--extended] [key=value ...]      e.g. dataset_path=bicycle
+
+--extended: the reference's 30 000-iteration schedule (print every 500, background / opacity reset / density control
+until 10 000 / 15 000 / 15 000).
 """
 import importlib
 import os
@@ -27,7 +30,12 @@ ORDER = ("dataset_path downsample_factor output_dir print_interval test_eval_int
 def main():
     trainer = importlib.import_module("3dgs_amd.trainer")
     cfg = dict(trainer.DEFAULT_CONFIG, **DATASET)
-    for kv in sys.argv[2:]:
+    args = sys.argv[2:]
+    if "--extended" in args:
+        args.remove("--extended")
+        cfg.update(print_interval=500, num_iters=30000, use_background_end=10000, reset_opacity_end=15000,
+                   adaptive_control_end=15000)
+    for kv in args:
         k, v = kv.split("=", 1)
         if k not in cfg:
             raise SystemExit(f"unknown key {k}")
