@@ -5,20 +5,35 @@
 // reference: 11-tap separable Gaussian window, clamped borders for the statistics, zero padding for the adjoint
 // convolution, gradient scaled by 1/(H*W*3), NaN gradients treated as 0 by Adam.
 //
-// Structure: one 256-thread workgroup per 16x16 pixel tile; the 26x26 halo tile of both images (all three
-// interleaved channels) is loaded once into LDS with coalesced reads, the horizontal pass writes a 26x16 strip per
-// channel, the vertical pass finishes in registers.  The loss is reduced per wave on DPP and added to one of 256
-// spread counters (a single hot atomic would serialise 32k adds), summed by the host when it asks for the value.
+// Structure: one 256-thread workgroup per 32x16 pixel tile.  The 42x26 halo tile is staged once into LDS as channel
+// planes (thread = one interleaved column of one image, 26 row loads in flight, scalar row clamps), then per channel
+// the horizontal pass computes four adjacent outputs per thread from three ds_read_b128 + one ds_read_b64 per plane
+// (3.5 LDS words per output instead of 11) and writes stat planes, and the vertical pass computes two adjacent rows
+// per thread from twelve rows of those planes (two stats per ds_read_b64).  Pitches and the lane -> (row, quad) maps
+// are chosen with the LDS bank rules of MI355X_MICROARCH.md so that every wide access is conflict-free (forward) or
+// two-way at worst (backward, whose nine planes leave no room for the wider pitch at three workgroups per CU).
+// Results of the three channels stay in registers and leave as three contiguous floats per pixel.  Workgroups are
+// dealt to the eight XCDs round-robin by the hardware; tile_of() gives each XCD one contiguous band of the image,
+// so the halo rows and columns shared by neighbouring tiles hit that XCD's L2 instead of being fetched 2.1 times
+// over the fabric (FETCH_SIZE 251 MB -> see profiles/).  The loss is reduced per wave on DPP and added to one of
+// 256 spread counters (a single hot atomic would serialise the adds), summed by the host when it asks for the value.
 #include "gs_common.h"
 #include "gs_render.h"
 
 namespace {
 
-constexpr int kT = 16, kHalo = 5, kS = kT + 2 * kHalo;  // 26
+constexpr int kTW = 32, kTH = 16, kHalo = 5, kSW = kTW + 2 * kHalo, kSH = kTH + 2 * kHalo;  // 42 x 26 halo tile
+constexpr int kPitchF = 48;        // staged row pitch, forward: rows 48 words apart + row-fastest lanes = no conflicts
+constexpr int kPitchB = 44;        // backward: the smallest 16-byte aligned pitch that holds 42 columns
+constexpr int kPair = 68, kSingle = 36;  // row pitches of a two-stat interleaved plane / a one-stat plane
+constexpr int kCols = kSW * 3;     // interleaved floats in one halo row of one image
 constexpr int kSpread = 256;
+static_assert(2 * kCols <= 256 && kSH <= 32 && kTW * (kTH / 2) == 256, "tile shape vs 256 threads");
 
 // 11-tap window (cuda/loss.cu:12-17); a constexpr table so that the fully unrolled taps become literal operands
-// (a v_fma with an SGPR operand issues 1.7x slower than one with a literal on this chip, profiles/microbench)
+// (a v_fma with an SGPR operand issues 1.7x slower than one with a literal on this chip, profiles/microbench).
+// The convolutions use explicit fmaf: the library is built with -ffp-contract=off, and mul + add would double the
+// VALU instructions of kernels that are VALU-issue bound.
 constexpr float cGauss[11] = {0.001028380123898387f,  0.0075987582094967365f, 0.036000773310661316f,
                               0.10936068743467331f,   0.21300552785396576f,   0.26601171493530273f,
                               0.21300552785396576f,   0.10936068743467331f,   0.036000773310661316f,
@@ -31,142 +46,246 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void loss_forward_kernel(int H, int W, float ssim_weight,
+// XCD-aware tile order: workgroup id -> XCD id % 8 (hardware), so XCD x takes tiles [x * per, (x + 1) * per)
+__device__ __forceinline__ bool tile_of(int ntx, int nty, int &tx, int &ty, int &t) {
+  const int n = ntx * nty, per = (n + 7) >> 3;
+  t = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= n) return false;
+  ty = t / ntx;
+  tx = t - ty * ntx;
+  return true;
+}
+
+// LDS accesses that must keep their width: left to itself the compiler re-slices neighbouring reads into
+// ds_read_b96 / ds_read2_b64 / ds_read2_b32 forms, which the LDS serves at half the rate of b128 / b64.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) v4f *lds4;
+typedef const volatile __attribute__((address_space(3))) v2f *lds2;
+
+// fourteen consecutive words of a staged row: three ds_read_b128 and one ds_read_b64
+__device__ __forceinline__ void load_row14(const float *p, float (&v)[14]) {
+  const lds4 q = (lds4)(__attribute__((address_space(3))) const float *)p;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const v4f t = q[k];
+    v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+  }
+  const v2f t = *(lds2)(q + 3);
+  v[12] = t.x; v[13] = t.y;
+}
+
+// two vertically adjacent 11-tap outputs of both stats of an interleaved plane (twelve ds_read_b64)
+__device__ __forceinline__ void column_pair(const float *col, float (&a)[2], float (&b)[2]) {
+  const lds2 q = (lds2)(__attribute__((address_space(3))) const float *)col;
+  v2f v[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) v[k] = q[k * (kPair / 2)];
+  a[0] = a[1] = b[0] = b[1] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    a[0] = fmaf(cGauss[k], v[k].x, a[0]); a[1] = fmaf(cGauss[k], v[k + 1].x, a[1]);
+    b[0] = fmaf(cGauss[k], v[k].y, b[0]); b[1] = fmaf(cGauss[k], v[k + 1].y, b[1]);
+  }
+}
+
+__device__ __forceinline__ void column_single(const float *col, float (&a)[2]) {
+  float v[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) v[k] = col[k * kSingle];
+  a[0] = a[1] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) { a[0] = fmaf(cGauss[k], v[k], a[0]); a[1] = fmaf(cGauss[k], v[k + 1], a[1]); }
+}
+
+__global__ __launch_bounds__(256) void loss_forward_kernel(int H, int W, int ntx, int nty, float ssim_weight,
                                                            const float *__restrict__ pred,
                                                            const float *__restrict__ gt, float *__restrict__ acc,
                                                            float *__restrict__ dm_mu, float *__restrict__ dm_s1,
                                                            float *__restrict__ dm_s12) {
-  __shared__ float sT[kS * kS * 6];       // [y][x][pred rgb | gt rgb]
-  __shared__ float sH[kS * kT * 5];       // horizontal pass of one channel: [y][x][5 stats]
-  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-  const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+  __shared__ __attribute__((aligned(16))) float sR[6 * kSH * kPitchF];  // planes: pred r g b, gt r g b
+  __shared__ __attribute__((aligned(16))) float sP[2 * kSH * kPair];    // horizontal pass: (X, X^2) and (Y, Y^2) planes
+  __shared__ __attribute__((aligned(16))) float sQ[kSH * kSingle];      // ... and the XY plane
+  const int tid = threadIdx.x;
+  int tx, ty, tile;
+  if (!tile_of(ntx, nty, tx, ty, tile)) return;
+  const int x0 = tx * kTW, y0 = ty * kTH;
   const float C1 = (0.01f * 1.0f) * (0.01f * 1.0f), C2 = (0.03f * 1.0f) * (0.03f * 1.0f);
-  for (int t = tid; t < kS * kS; t += 256) {
-    const int sy = t / kS, sx = t % kS;
-    const int gy = min(max(y0 + sy - kHalo, 0), H - 1), gx = min(max(x0 + sx - kHalo, 0), W - 1);
-    const size_t g = ((size_t)gy * W + gx) * 3;
-    sT[t * 6 + 0] = pred[g]; sT[t * 6 + 1] = pred[g + 1]; sT[t * 6 + 2] = pred[g + 2];
-    sT[t * 6 + 3] = gt[g]; sT[t * 6 + 4] = gt[g + 1]; sT[t * 6 + 5] = gt[g + 2];
+  if (tid < 2 * kCols) {  // borders replicate the edge pixel (cuda/loss.cu:42-47, 100-101)
+    const int img = tid >= kCols, e = tid - img * kCols, px = e / 3, c = e - px * 3;
+    const int gx = min(max(x0 + px - kHalo, 0), W - 1);
+    const float *src = (img ? gt : pred) + (size_t)gx * 3 + c;
+    float *dst = &sR[(img * 3 + c) * kSH * kPitchF + px];
+    float v[kSH];
+#pragma unroll
+    for (int r = 0; r < kSH; ++r) v[r] = src[(size_t)min(max(y0 + r - kHalo, 0), H - 1) * W * 3];
+#pragma unroll
+    for (int r = 0; r < kSH; ++r) dst[r * kPitchF] = v[r];
   }
   __syncthreads();
-  const int px = x0 + lx, py = y0 + ly;
-  const bool inside = px < W && py < H;
+  const int hr = (tid >> 6) * 8 + (tid & 7), hq = (tid >> 3) & 7;  // horizontal pass: row hr, outputs 4hq .. 4hq+3
+  const int vx = tid & (kTW - 1), vy = (tid >> 5) * 2;             // vertical pass: column vx, output rows vy, vy+1
+  float k_mu[3][2], k_s1[3][2], k_s12[3][2];
   float loss = 0.0f;
-  for (int c = 0; c < 3; ++c) {
-    for (int o = tid; o < kS * kT; o += 256) {  // horizontal pass: 26 rows x 16 columns
-      const int ry = o / kT, rx = o % kT + kHalo;
-      float sX = 0, sX2 = 0, sY = 0, sY2 = 0, sXY = 0;
 #pragma unroll
-      for (int d = 1; d <= kHalo; ++d) {
-        const float w = cGauss[kHalo - d];
-        const float Xl = sT[(ry * kS + rx - d) * 6 + c], Yl = sT[(ry * kS + rx - d) * 6 + 3 + c];
-        const float Xr = sT[(ry * kS + rx + d) * 6 + c], Yr = sT[(ry * kS + rx + d) * 6 + 3 + c];
-        sX += (Xl + Xr) * w; sX2 += (Xl * Xl + Xr * Xr) * w; sY += (Yl + Yr) * w; sY2 += (Yl * Yl + Yr * Yr) * w;
-        sXY += (Xl * Yl + Xr * Yr) * w;
+  for (int c = 0; c < 3; ++c) {
+    if (hr < kSH) {
+      float X[14], Y[14], o[5][4];
+      load_row14(&sR[(c * kSH + hr) * kPitchF + 4 * hq], X);
+      load_row14(&sR[((3 + c) * kSH + hr) * kPitchF + 4 * hq], Y);
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[s][j] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        const float x = X[k], y = Y[k], xx = x * x, yy = y * y, xy = x * y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k - j < 0 || k - j > 10) continue;
+          const float w = cGauss[k - j];
+          o[0][j] = fmaf(w, x, o[0][j]); o[1][j] = fmaf(w, xx, o[1][j]); o[2][j] = fmaf(w, y, o[2][j]);
+          o[3][j] = fmaf(w, yy, o[3][j]); o[4][j] = fmaf(w, xy, o[4][j]);
+        }
       }
-      const float wc = cGauss[kHalo], Xc = sT[(ry * kS + rx) * 6 + c], Yc = sT[(ry * kS + rx) * 6 + 3 + c];
-      sX += Xc * wc; sX2 += Xc * Xc * wc; sY += Yc * wc; sY2 += Yc * Yc * wc; sXY += Xc * Yc * wc;
-      float *h = &sH[o * 5];
-      h[0] = sX; h[1] = sX2; h[2] = sY; h[3] = sY2; h[4] = sXY;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float4 *d = reinterpret_cast<float4 *>(&sP[(pr * kSH + hr) * kPair + 8 * hq]);
+        d[0] = make_float4(o[2 * pr][0], o[2 * pr + 1][0], o[2 * pr][1], o[2 * pr + 1][1]);
+        d[1] = make_float4(o[2 * pr][2], o[2 * pr + 1][2], o[2 * pr][3], o[2 * pr + 1][3]);
+      }
+      *reinterpret_cast<float4 *>(&sQ[hr * kSingle + 4 * hq]) = make_float4(o[4][0], o[4][1], o[4][2], o[4][3]);
     }
     __syncthreads();
-    if (inside) {  // vertical pass + SSIM
-      float o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-      const int cy = ly + kHalo;
+    {  // vertical pass + SSIM (cuda/loss.cu:150-240)
+      float o[5][2];
+      column_pair(&sP[(0 * kSH + vy) * kPair + 2 * vx], o[0], o[1]);
+      column_pair(&sP[(1 * kSH + vy) * kPair + 2 * vx], o[2], o[3]);
+      column_single(&sQ[vy * kSingle + vx], o[4]);
 #pragma unroll
-      for (int d = 1; d <= kHalo; ++d) {
-        const float w = cGauss[kHalo - d];
-        const float *t = &sH[((cy - d) * kT + lx) * 5], *b = &sH[((cy + d) * kT + lx) * 5];
-        o0 += (t[0] + b[0]) * w; o1 += (t[1] + b[1]) * w; o2 += (t[2] + b[2]) * w; o3 += (t[3] + b[3]) * w;
-        o4 += (t[4] + b[4]) * w;
+      for (int j = 0; j < 2; ++j) {
+        const float mu1 = o[0][j], mu2 = o[2][j], mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+        const float s1 = o[1][j] - mu1_sq, s2 = o[3][j] - mu2_sq, s12 = o[4][j] - mu1 * mu2;
+        const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu1 * mu2 + C1, D = 2.f * s12 + C2;
+        // the reference's six divisions (cuda/loss.cu:214-236) share two reciprocals: 1/A and 1/B
+        const float iA = __builtin_amdgcn_rcpf(A), iB = __builtin_amdgcn_rcpf(B), iAB = iA * iB;
+        const float ssim = Cc * D * iAB;
+        const int ti = (vy + j + kHalo) * kPitchF + vx + kHalo;
+        const float l1 = fabsf(sR[c * kSH * kPitchF + ti] - sR[(3 + c) * kSH * kPitchF + ti]);
+        const bool inside = x0 + vx < W && y0 + vy + j < H;
+        loss += inside ? (1.0f - ssim_weight) * l1 + ssim_weight * (1.0f - ssim) : 0.0f;
+        const float two_mu1_ssim = 2.f * mu1 * ssim;
+        const float d_mu1 = 2.f * mu2 * (D - Cc) * iAB - two_mu1_ssim * iA + two_mu1_ssim * iB;
+        k_mu[c][j] = -ssim_weight * d_mu1;
+        k_s1[c][j] = ssim_weight * (ssim * iB);
+        k_s12[c][j] = -ssim_weight * (2.f * Cc * iAB);
       }
-      const float wc = cGauss[kHalo];
-      const float *ct = &sH[(cy * kT + lx) * 5];
-      o0 += ct[0] * wc; o1 += ct[1] * wc; o2 += ct[2] * wc; o3 += ct[3] * wc; o4 += ct[4] * wc;
-      const float mu1 = o0, mu2 = o2, mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
-      const float s1 = o1 - mu1_sq, s2 = o3 - mu2_sq, s12 = o4 - mu1 * mu2;
-      const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu1 * mu2 + C1, D = 2.f * s12 + C2;
-      // the reference's six divisions (cuda/loss.cu:214-236) share two reciprocals: 1/A and 1/B
-      const float iA = __builtin_amdgcn_rcpf(A), iB = __builtin_amdgcn_rcpf(B), iAB = iA * iB;
-      const float ssim = Cc * D * iAB;
-      const int ti = ((ly + kHalo) * kS + lx + kHalo) * 6;
-      const float l1 = fabsf(sT[ti + c] - sT[ti + 3 + c]);
-      loss += (1.0f - ssim_weight) * l1 + ssim_weight * (1.0f - ssim);
-      const float two_mu1_ssim = 2.f * mu1 * ssim;
-      const float d_mu1 = 2.f * mu2 * (D - Cc) * iAB - two_mu1_ssim * iA + two_mu1_ssim * iB;
-      const size_t id = ((size_t)py * W + px) * 3 + c;
-      dm_mu[id] = -ssim_weight * d_mu1;
-      dm_s1[id] = ssim_weight * (ssim * iB);
-      dm_s12[id] = -ssim_weight * (2.f * Cc * iAB);
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int px = x0 + vx, py = y0 + vy + j;
+    if (px < W && py < H) {
+      const size_t id = ((size_t)py * W + px) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { dm_mu[id + c] = k_mu[c][j]; dm_s1[id + c] = k_s1[c][j]; dm_s12[id + c] = k_s12[c][j]; }
+    }
+  }
   loss = wave_sum(loss);
-  if ((tid & 63) == 0) atomicAdd(&acc[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6) & (kSpread - 1)], loss);
+  if ((tid & 63) == 0) atomicAdd(&acc[(tile * 4 + (tid >> 6)) & (kSpread - 1)], loss);
 }
 
-__global__ __launch_bounds__(256) void loss_backward_kernel(int H, int W, float ssim_weight,
+__global__ __launch_bounds__(256) void loss_backward_kernel(int H, int W, int ntx, int nty, float ssim_weight,
                                                             const float *__restrict__ pred,
                                                             const float *__restrict__ gt,
                                                             const float *__restrict__ dm_mu,
                                                             const float *__restrict__ dm_s1,
                                                             const float *__restrict__ dm_s12,
                                                             float *__restrict__ image_grad) {
-  __shared__ float sD[kS * kS * 9];   // [y][x][channel][3 maps], zero outside the image
-  __shared__ float sV[kS * kT * 3];   // horizontal pass of one channel
-  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-  const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
-  for (int t = tid; t < kS * kS; t += 256) {
-    const int sy = t / kS, sx = t % kS;
-    const int gy = y0 + sy - kHalo, gx = x0 + sx - kHalo;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const size_t g = in ? ((size_t)gy * W + gx) * 3 : 0;
+  __shared__ __attribute__((aligned(16))) float sD[9 * kSH * kPitchB];  // plane = channel * 3 + map, zero outside the image
+  __shared__ __attribute__((aligned(16))) float sP[kSH * kPair];        // horizontal pass: maps (mu, s1) interleaved
+  __shared__ __attribute__((aligned(16))) float sQ[kSH * kSingle];      // ... and s12
+  const int tid = threadIdx.x;
+  int tx, ty, tile;
+  if (!tile_of(ntx, nty, tx, ty, tile)) return;
+  const int x0 = tx * kTW, y0 = ty * kTH;
+  const int vx = tid & (kTW - 1), vy = (tid >> 5) * 2;
+  float p1[2][3], p2[2][3];  // the two pixels this thread finishes
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      sD[t * 9 + c * 3 + 0] = in ? dm_mu[g + c] : 0.0f;
-      sD[t * 9 + c * 3 + 1] = in ? dm_s1[g + c] : 0.0f;
-      sD[t * 9 + c * 3 + 2] = in ? dm_s12[g + c] : 0.0f;
-    }
+  for (int j = 0; j < 2; ++j) {
+    const int px = x0 + vx, py = y0 + vy + j;
+    const bool inside = px < W && py < H;
+    const size_t id = inside ? ((size_t)py * W + px) * 3 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p1[j][c] = pred[id + c]; p2[j][c] = gt[id + c]; }
+  }
+  unsigned rows_in = 0;  // bit r: halo row r lies inside the image (uniform)
+#pragma unroll
+  for (int r = 0; r < kSH; ++r) rows_in |= (unsigned)(y0 + r - kHalo >= 0 && y0 + r - kHalo < H) << r;
+  for (int it = tid; it < 3 * kCols; it += 256) {  // adjoint convolution pads with zeros (cuda/loss.cu:49-55, 339-341)
+    const int m = it / kCols, e = it - m * kCols, px = e / 3, c = e - px * 3;
+    const int gx = x0 + px - kHalo;
+    const bool in_x = gx >= 0 && gx < W;
+    const unsigned keep = in_x ? rows_in : 0u;
+    const float *src = (m == 0 ? dm_mu : m == 1 ? dm_s1 : dm_s12) + (in_x ? (size_t)gx * 3 + c : 0);
+    float *dst = &sD[(c * 3 + m) * kSH * kPitchB + px];
+    float v[kSH];
+#pragma unroll
+    for (int r = 0; r < kSH; ++r)  // always a valid address, the value is dropped outside: no branches around loads
+      v[r] = src[(size_t)min(max(y0 + r - kHalo, 0), H - 1) * W * 3];
+#pragma unroll
+    for (int r = 0; r < kSH; ++r) dst[r * kPitchB] = (keep >> r & 1u) ? v[r] : 0.0f;
   }
   __syncthreads();
-  const int px = x0 + lx, py = y0 + ly;
-  const bool inside = px < W && py < H;
+  // horizontal pass lanes: row bits (l0 l2 l1), quad bits (l3 l5 l4) -- the best this pitch allows for ds_read_b128
+  const int hr = (tid >> 6) * 8 + ((tid & 1) | ((tid >> 1) & 2) | ((tid << 1) & 4));
+  const int hq = ((tid >> 3) & 1) | ((tid >> 4) & 2) | ((tid >> 2) & 4);
   const float grad_scale = 1.0f / (float)(H * W * 3);
+  float out[2][3];
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
-    for (int o = tid; o < kS * kT; o += 256) {
-      const int ry = o / kT, rx = o % kT + kHalo;
-      float a0 = 0, a1 = 0, a2 = 0;
+    if (hr < kSH) {
+      float o[3][4];
 #pragma unroll
-      for (int d = 1; d <= kHalo; ++d) {
-        const float w = cGauss[kHalo - d];
-        const float *l = &sD[(ry * kS + rx - d) * 9 + c * 3], *r = &sD[(ry * kS + rx + d) * 9 + c * 3];
-        a0 += (l[0] + r[0]) * w; a1 += (l[1] + r[1]) * w; a2 += (l[2] + r[2]) * w;
+      for (int m = 0; m < 3; ++m) {
+        float D[14];
+        load_row14(&sD[((c * 3 + m) * kSH + hr) * kPitchB + 4 * hq], D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[m][j] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 14; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (k - j >= 0 && k - j <= 10) o[m][j] = fmaf(cGauss[k - j], D[k], o[m][j]);
       }
-      const float *m = &sD[(ry * kS + rx) * 9 + c * 3];
-      const float wc = cGauss[kHalo];
-      a0 += m[0] * wc; a1 += m[1] * wc; a2 += m[2] * wc;
-      sV[o * 3] = a0; sV[o * 3 + 1] = a1; sV[o * 3 + 2] = a2;
+      float4 *d = reinterpret_cast<float4 *>(&sP[hr * kPair + 8 * hq]);
+      d[0] = make_float4(o[0][0], o[1][0], o[0][1], o[1][1]);
+      d[1] = make_float4(o[0][2], o[1][2], o[0][3], o[1][3]);
+      *reinterpret_cast<float4 *>(&sQ[hr * kSingle + 4 * hq]) = make_float4(o[2][0], o[2][1], o[2][2], o[2][3]);
     }
     __syncthreads();
-    if (inside) {
-      float s0 = 0, s1 = 0, s2 = 0;
-      const int cy = ly + kHalo;
+    {
+      float s[3][2];
+      column_pair(&sP[vy * kPair + 2 * vx], s[0], s[1]);
+      column_single(&sQ[vy * kSingle + vx], s[2]);
 #pragma unroll
-      for (int d = 1; d <= kHalo; ++d) {
-        const float w = cGauss[kHalo - d];
-        const float *t = &sV[((cy - d) * kT + lx) * 3], *b = &sV[((cy + d) * kT + lx) * 3];
-        s0 += (t[0] + b[0]) * w; s1 += (t[1] + b[1]) * w; s2 += (t[2] + b[2]) * w;
+      for (int j = 0; j < 2; ++j) {
+        const float ssim_g = s[0][j] + (2.f * p1[j][c]) * s[1][j] + p2[j][c] * s[2][j];
+        const float l1_g = (1.0f - ssim_weight) * ((p1[j][c] > p2[j][c]) ? 1.0f : -1.0f);
+        out[j][c] = (ssim_g + l1_g) * grad_scale;
       }
-      const float *ct = &sV[(cy * kT + lx) * 3];
-      const float wc = cGauss[kHalo];
-      s0 += ct[0] * wc; s1 += ct[1] * wc; s2 += ct[2] * wc;
-      const size_t id = ((size_t)py * W + px) * 3 + c;
-      const float p1 = pred[id], p2 = gt[id];
-      const float ssim_g = s0 + (2.f * p1) * s1 + p2 * s2;
-      const float l1_g = (1.0f - ssim_weight) * ((p1 > p2) ? 1.0f : -1.0f);
-      image_grad[id] = (ssim_g + l1_g) * grad_scale;
     }
     __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int px = x0 + vx, py = y0 + vy + j;
+    if (px < W && py < H) {
+      const size_t id = ((size_t)py * W + px) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) image_grad[id + c] = out[j][c];
+    }
   }
 }
 
@@ -329,12 +448,13 @@ int gsplat_fused_loss(const float *predicted_data, const float *gt_data, int row
       (rc = acc.reserve(kSpread * sizeof(float))))
     return rc;
   GS_HIP(hipMemsetAsync(acc.ptr, 0, kSpread * sizeof(float), st));
-  const dim3 grid((cols + kT - 1) / kT, (rows + kT - 1) / kT), block(256);
-  loss_forward_kernel<<<grid, block, 0, st>>>(rows, cols, ssim_weight, predicted_data, gt_data, acc.as<float>(),
-                                              mu.as<float>(), s1.as<float>(), s12.as<float>());
+  const int ntx = (cols + kTW - 1) / kTW, nty = (rows + kTH - 1) / kTH;
+  const dim3 grid((unsigned)(((ntx * nty + 7) / 8) * 8)), block(256);  // whole rounds of the eight XCDs: tile_of()
+  loss_forward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data,
+                                              acc.as<float>(), mu.as<float>(), s1.as<float>(), s12.as<float>());
   GS_LAUNCH_CHECK();
-  loss_backward_kernel<<<grid, block, 0, st>>>(rows, cols, ssim_weight, predicted_data, gt_data, mu.as<float>(),
-                                               s1.as<float>(), s12.as<float>(), image_grad);
+  loss_backward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data,
+                                               mu.as<float>(), s1.as<float>(), s12.as<float>(), image_grad);
   GS_LAUNCH_CHECK();
   if (loss_out) {  // the reference returns the value, i.e. blocks (cuda/loss.cu:468-470)
     double total;

@@ -12,7 +12,7 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("shape", [(16, 16), (37, 53), (128, 200), (1, 1), (5, 300)])
+@pytest.mark.parametrize("shape", [(16, 16), (37, 53), (128, 200), (1, 1), (5, 300), (33, 65), (17, 31), (48, 96)])
 def test_fused_loss_matches_oracle(gpu, orc, shape):
     import torch
     ops = pkg("ops")
