@@ -579,28 +579,30 @@ __device__ __forceinline__ void for_each_hit_tile(int j, const float *__restrict
 }
 
 // column t of table -> exclusive prefix over the workgroups; totals[t] = column sum (totals[T] = 0 for the scan).
-// One workgroup per 64 tiles: wave w owns the rows 64w .. 64w+63 of the table (lane = tile, so every load and store
-// is a coalesced 256-byte row segment), keeps its 64 counts in registers and only the four wave sums meet in LDS.
-__global__ __launch_bounds__(256) void bin_offsets_kernel(int T, int *__restrict__ table, int *__restrict__ totals,
-                                                          int *__restrict__ long_tile_count) {
-  static_assert(kBinBlocks == 256, "four waves x 64 table rows");
-  __shared__ int s_sum[4][64];
+// One workgroup per 64 tiles: wave w of sixteen owns the rows 16w .. 16w+15 of the table (lane = tile, so every load
+// and store is a coalesced 256-byte row segment), keeps its 16 counts in registers and only the wave sums meet in
+// LDS.  (Four waves of 64 rows each took twice as long: 64 dependent-latency loads per thread on 68 workgroups.)
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int *__restrict__ table, int *__restrict__ totals,
+                                                           int *__restrict__ long_tile_count) {
+  constexpr int kRows = kBinBlocks / 16;
+  static_assert(kBinBlocks % 16 == 0, "sixteen waves share the table rows");
+  __shared__ int s_sum[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
   if (blockIdx.x == 0 && threadIdx.x == 0) { totals[T] = 0; *long_tile_count = 0; }
-  int v[64], sum = 0;
+  int v[kRows], sum = 0;
   if (t < T) {
 #pragma unroll
-    for (int k = 0; k < 64; ++k) { v[k] = table[(size_t)(64 * w + k) * T + t]; sum += v[k]; }
+    for (int k = 0; k < kRows; ++k) { v[k] = table[(size_t)(kRows * w + k) * T + t]; sum += v[k]; }
   }
   s_sum[w][lane] = sum;
   __syncthreads();
   if (t >= T) return;
   int run = 0;
   for (int q = 0; q < w; ++q) run += s_sum[q][lane];
-  if (w == 3) totals[t] = run + sum;
+  if (w == 15) totals[t] = run + sum;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) { table[(size_t)(64 * w + k) * T + t] = run; run += v[k]; }
+  for (int k = 0; k < kRows; ++k) { table[(size_t)(kRows * w + k) * T + t] = run; run += v[k]; }
 }
 
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *__restrict__ uv,
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
 
 // ranges[0..T] = exclusive scan of totals[0..T) (ranges[T] = S): one workgroup, T <= kBinMaxTiles.  Replaces a
 // three-kernel rocPRIM scan of a few thousand integers.
-// It also publishes the forward's host record {M | S << 32, candidate pairs, ticket} (see publish_counts_kernel in
+// It also publishes the forward's host record (publish_record in gs_common.h, see publish_counts_kernel in
 // gs_fused.hip) when `pub` is given: S is known here first, and it saves a launch on the path to the host's wake-up.
 // `cap`: room of the instance buffers.  The kernels queued behind this one run before the host has seen S (see
 // gsplat_rasterize_image), so the ranges they read are clamped to the room: when S does not fit they work on truncated
@@ -697,38 +699,49 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
                                                           const unsigned long long *__restrict__ pair_counters,
                                                           volatile unsigned long long *pub, unsigned long long ticket,
                                                           long long cap) {
-  __shared__ int s_part[1024];
-  __shared__ int s_longest;  // the longest tile list: the host picks the next forward's binning route by it
-  if (threadIdx.x == 0) s_longest = 0;
-  const int per = (T + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, T);
-  int sum = 0, longest = 0;
-  for (int t = lo; t < hi; ++t) { const int v = totals[t]; sum += v; longest = max(longest, v); }
-  s_part[threadIdx.x] = sum;
+  constexpr int kPer = kBinMaxTiles / 1024;  // 16 consecutive tiles per thread at most
+  __shared__ int s_wave[16], s_long[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = (T + 1023) / 1024, lo = threadIdx.x * per;
+  int v[kPer], sum = 0, longest = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    v[k] = (k < per && lo + k < T) ? totals[lo + k] : 0;
+    sum += v[k];
+    longest = max(longest, v[k]);
+  }
+  int incl = sum;  // inclusive scan of the thread sums inside the wave, then of the sixteen wave sums
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
+  if (lane == 63) { s_wave[w] = incl; s_long[w] = longest; }
   __syncthreads();
-  if (longest > 0) atomicMax(&s_longest, longest);
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
-    const int v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
-    __syncthreads();
-    s_part[threadIdx.x] += v;
-    __syncthreads();
+  int before = 0, S = 0, longest_all = 0;  // the longest tile list: the host picks the next forward's binning route by it
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int x = s_wave[q];
+    before += q < w ? x : 0;
+    S += x;
+    longest_all = max(longest_all, s_long[q]);
   }
   if (pub && threadIdx.x < 64) {
-    unsigned long long v = pair_counters[threadIdx.x];
+    unsigned long long c = pair_counters[threadIdx.x];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (threadIdx.x == 0) {
-      pub[0] = ((unsigned long long)(unsigned int)s_part[1023] << 32) | (unsigned long long)(unsigned int)*m_total;
-      pub[1] = v;
-      pub[3] = (unsigned long long)s_longest;
-      __threadfence_system();
-      pub[2] = ticket;
-      __threadfence_system();
-    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (threadIdx.x == 0) publish_record(pub, ticket, (unsigned int)*m_total, (unsigned int)S, c, (unsigned int)longest_all);
   }
-  int run = s_part[threadIdx.x] - sum;
+  int run = before + incl - sum;
   const int room = (int)min(cap, 0x7FFFFFFFll);
-  for (int t = lo; t < hi; ++t) { ranges[t] = min(run, room); run += totals[t]; }
-  if (threadIdx.x == 1023) ranges[T] = min(s_part[1023], room);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    if (k < per && lo + k < T) ranges[lo + k] = min(run, room);
+    run += v[k];
+  }
+  if (threadIdx.x == 1023) ranges[T] = min(S, room);
 }
 
 bool binning_supports_counting_sort(int num_tiles) { return num_tiles <= kBinMaxTiles; }
@@ -752,7 +765,7 @@ int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, 
                     long long capacity, hipStream_t st) {
   const int T = ntx * nty;
   int *totals = table + (size_t)kBinBlocks * T;
-  bin_offsets_kernel<<<div_up(T, 64), 256, 0, st>>>(T, table, totals, long_tiles);
+  bin_offsets_kernel<<<div_up(T, 64), 1024, 0, st>>>(T, table, totals, long_tiles);
   GS_LAUNCH_CHECK();
   bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, m_total, pair_counters, pub, ticket, capacity);
   GS_LAUNCH_CHECK();

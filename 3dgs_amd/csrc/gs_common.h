@@ -55,6 +55,26 @@ int check_device_ptr(const void *p, const char *name, const char *fn);
 // Counting-sort binning (gs_binning.hip) and the per-gaussian forward (gs_fused.hip) split the gaussians into the same
 // kBinBlocks contiguous slices: workgroup b of either kernel owns global indices [N*b/kBinBlocks, N*(b+1)/kBinBlocks).
 constexpr int kBinBlocks = 256, kBinThreads = 1024;
+// The forward's host record: pinned, mapped host memory the GPU writes and the host polls.  Five 64-bit words, each
+// {value << 32 | low half of the forward's ticket}: M, S, candidate pairs (low, high), longest tile list.  A word is
+// one aligned 8-byte store, so it cannot tear, and the host takes the record when all five carry its ticket -- no
+// ordering between the stores is needed, hence no __threadfence_system() (a system-scope release writes back the
+// XCD's whole L2: several microseconds on the GPU's critical path, behind kernels that left megabytes dirty).
+constexpr int kRecordWords = 5;
+__host__ __device__ inline unsigned long long record_word(unsigned int value, unsigned long long ticket) {
+  return ((unsigned long long)value << 32) | (ticket & 0xFFFFFFFFull);
+}
+#ifdef __HIPCC__
+__device__ inline void publish_record(volatile unsigned long long *pub, unsigned long long ticket, unsigned int M,
+                                      unsigned int S, unsigned long long pairs, unsigned int longest) {
+  pub[0] = record_word(M, ticket);
+  pub[1] = record_word(S, ticket);
+  pub[2] = record_word((unsigned int)(pairs & 0xFFFFFFFFull), ticket);
+  pub[3] = record_word((unsigned int)(pairs >> 32), ticket);
+  pub[4] = record_word(longest, ticket);
+}
+#endif
+
 constexpr int kBinMaxTiles = 16384;  // 64 KB of LDS counters; larger tile grids take the radix-sort route
 
 static inline unsigned int div_up(long long a, long long b) { return (unsigned int)((a + b - 1) / b); }

@@ -73,13 +73,12 @@ struct gsplat_context {
   bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
   bool backward_seen = false, rows_zeroed = false;  // training use: the forward clears grad_rows for the backward
   bool render_only = false;  // gsplat_context_set_render_only: forwards skip what only a backward would read
-  // {M | S << 32, pairs, ticket}: pinned host memory the GPU writes and the host polls (see publish_counts_kernel)
+  // the forward's record (gs_common.h: publish_record): pinned host memory the GPU writes and the host polls
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
-  // 64 spread counters + the 16-byte {M, S, pairs} record, parked behind the N+1 scan flags
-  unsigned long long *pair_counters() const {
-    return reinterpret_cast<unsigned long long *>(flags.as<char>() + (((size_t)max_gaussians + 1) * 4 + 63) / 64 * 64);
-  }
+  // small device counters: 64 spread counters of candidate pairs, then the kBinBlocks slice counts of the cull
+  unsigned long long *pair_counters() const { return flags.as<unsigned long long>(); }
+  int *slice_counts() const { return flags.as<int>() + 128; }
   // optional per-stage HIP-event timing (gsplat_context_set_timing)
   static constexpr int kStages = 8, kSlots = 32;
   unsigned int timing = 0;  // bit k: stage k is timed
@@ -167,31 +166,68 @@ __device__ __forceinline__ void rows_from_lds(float *__restrict__ dst, const flo
   for (int e = (total & ~3) + lane; e < total; e += 64) dst[e] = wsh[e];
 }
 
-// ---- A: world -> camera -> pixel -> keep-mask, for all N
-__global__ __launch_bounds__(kBlock) void project_cull_kernel(const float *__restrict__ xyz,
-                                                              const float *__restrict__ view,
-                                                              const float *__restrict__ proj, int N, int width,
-                                                              int height, float near_thresh, int padding,
-                                                              float *__restrict__ xyz_c, float *__restrict__ uv,
-                                                              unsigned char *__restrict__ mask,
-                                                              int *__restrict__ flags,
-                                                              unsigned long long *__restrict__ pair_counters) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < 64) pair_counters[i] = 0ull;  // consumed by preprocess_kernel, two launches later on the same stream
-  if (i >= N) {
-    if (i == N) flags[N] = 0;
-    return;
-  }
+// ---- A: world -> camera -> pixel -> keep-mask, for all N, and the compaction ranks
+// Launched like preprocess_kernel: kBinBlocks workgroups of kBinThreads, workgroup b owns the global indices
+// [N*b/kBinBlocks, N*(b+1)/kBinBlocks).  rank[i] leaves this kernel as the exclusive count of kept gaussians INSIDE
+// the slice and slice_counts[b] as the slice's total; preprocess_kernel (same slices) adds the counts of the slices
+// before its own and stores the global rank.  That replaces a two-kernel rocPRIM scan over N + 1 flags (12 us of
+// launch + drain on the forward's critical path and 12 MB of traffic) by two barriers in a kernel that is here anyway.
+// Pass 1 has no barrier, so the loads of all trips overlap; it leaves one ballot per (trip, wave) in LDS, wave 0 scans
+// their counts, pass 2 only stores.
+__global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const float *__restrict__ xyz,
+                                                                       const float *__restrict__ view,
+                                                                       const float *__restrict__ proj, int N, int width,
+                                                                       int height, float near_thresh, int padding,
+                                                                       float *__restrict__ xyz_c, float *__restrict__ uv,
+                                                                       unsigned char *__restrict__ mask,
+                                                                       int *__restrict__ rank,
+                                                                       int *__restrict__ slice_counts,
+                                                                       unsigned long long *__restrict__ pair_counters) {
+  extern __shared__ unsigned long long s_ballot[];  // [trips * 16] ballots, then [trips * 16] exclusive counts (int)
+  constexpr int kWaves = gs::kBinThreads / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
+  const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks);
+  const int trips = (hi - lo + gs::kBinThreads - 1) / gs::kBinThreads;
+  int *s_before = reinterpret_cast<int *>(s_ballot + trips * kWaves);
+  if (blockIdx.x == 0 && threadIdx.x < 64) pair_counters[threadIdx.x] = 0ull;  // consumed by preprocess_kernel
   const gs::Mat34 v = gs::load_view(view);
   const gs::Mat44 p = gs::load_proj(proj);
-  float x, y, z, u, w;
-  gs::camera_space(v, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], x, y, z);
-  gs::to_screen(p, x, y, z, width, height, u, w);
-  const bool k = gs::keep(u, w, z, near_thresh, padding, width, height);
-  xyz_c[3 * i] = x; xyz_c[3 * i + 1] = y; xyz_c[3 * i + 2] = z;
-  uv[2 * i] = u; uv[2 * i + 1] = w;
-  mask[i] = k ? 1 : 0;
-  flags[i] = k ? 1 : 0;
+  for (int t = 0; t < trips; ++t) {
+    const int i = lo + t * gs::kBinThreads + (int)threadIdx.x;
+    bool k = false;
+    if (i < hi) {
+      float x, y, z, u, q;
+      gs::camera_space(v, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], x, y, z);
+      gs::to_screen(p, x, y, z, width, height, u, q);
+      k = gs::keep(u, q, z, near_thresh, padding, width, height);
+      xyz_c[3 * i] = x; xyz_c[3 * i + 1] = y; xyz_c[3 * i + 2] = z;
+      uv[2 * i] = u; uv[2 * i + 1] = q;
+      mask[i] = k ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(k);
+    if (lane == 0) s_ballot[t * kWaves + w] = bal;
+  }
+  __syncthreads();
+  if (w == 0) {  // exclusive scan of the trips * 16 ballot counts, slice order = (trip, wave)
+    const int n = trips * kWaves, per = (n + 63) / 64;
+    int sum = 0;
+    for (int e = lane * per; e < min(lane * per + per, n); ++e) sum += __popcll(s_ballot[e]);
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    int run = incl - sum;
+    for (int e = lane * per; e < min(lane * per + per, n); ++e) { s_before[e] = run; run += __popcll(s_ballot[e]); }
+    if (lane == 63) slice_counts[blockIdx.x] = incl;
+  }
+  __syncthreads();
+  for (int t = 0; t < trips; ++t) {
+    const int i = lo + t * gs::kBinThreads + (int)threadIdx.x;
+    if (i < hi) rank[i] = s_before[t * kWaves + w] + __popcll(s_ballot[t * kWaves + w] & ((1ull << lane) - 1ull));
+  }
 }
 
 constexpr int kCoopTiles = 64;  // candidate tiles above which a splat's tile tests are shared by its wave
@@ -213,18 +249,32 @@ struct PreOut {
 template <int L>
 __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaussians g, const float *__restrict__ view,
                                                             const unsigned char *__restrict__ mask,
-                                                            const int *__restrict__ rank,
+                                                            int *__restrict__ rank,
+                                                            const int *__restrict__ slice_counts,
                                                             const float *__restrict__ xyz_c_all,
                                                             const float *__restrict__ uv_all, float fx, float fy,
                                                             float tan_fovx, float tan_fovy, float mh_dist, float cx,
                                                             float cy, float cz, int ntx, int nty, PreOut o,
                                                             int *__restrict__ table) {
   extern __shared__ int s_hist[];
+  __shared__ int s_slices[2];
   const int N = g.num_gaussians, T = ntx * nty;
-  if (table) {
-    for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
-    __syncthreads();
+  if (threadIdx.x < 64) {  // kept gaussians in the slices before this one, and in all of them (project_cull_kernel)
+    int before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < gs::kBinBlocks / 64; ++k) {
+      const int q = (int)threadIdx.x + 64 * k, cnt = slice_counts[q];
+      before += q < (int)blockIdx.x ? cnt : 0;
+      all += cnt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); }
+    if (threadIdx.x == 0) { s_slices[0] = before; s_slices[1] = all; }
   }
+  if (table)
+    for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
+  __syncthreads();
+  const int rank_base = s_slices[0], M = s_slices[1];
   const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
   const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks) + (blockIdx.x == gs::kBinBlocks - 1 ? 1 : 0);
   unsigned long long coarse = 0;
@@ -234,13 +284,16 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   const int i = ib + lane;
   // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
   // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
-  if (i < hi && i <= N && i >= rank[N]) o.counts[i] = 0;
+  if (i < hi && i <= N && i >= M) o.counts[i] = 0;
   int j = 0, hits = 0, span_n = 0;
+  if (i < hi && i <= N) {  // local -> global rank, for every index: kernels after this one read rank[] at slice starts
+    j = i < N ? rank_base + rank[i] : M;
+    rank[i] = j;
+  }
   unsigned long long hm = 0ull;
   float bu = 0.0f, bv = 0.0f, br0 = 0.0f, br1 = 0.0f, br2 = 0.0f, br3 = 0.0f;  // what a cooperative test needs of a lane
   const bool act = i < hi && i < N && mask[i];
   if (act) {
-  j = rank[i];
   constexpr int n = (L + 1) * (L + 1);
   const gs::Mat34 vw = gs::load_view(view);
   // colour
@@ -338,18 +391,13 @@ __global__ __launch_bounds__(64) void publish_counts_kernel(const int *__restric
                                                             const unsigned long long *__restrict__ pair_counters,
                                                             volatile unsigned long long *out,
                                                             unsigned long long ticket) {
-  // `out` is pinned host memory mapped into the device: the host polls out[2] for its ticket instead of paying a
+  // `out` is pinned host memory mapped into the device: the host polls it for its ticket instead of paying a
   // copy + stream synchronisation, and the kernels queued behind this one keep the GPU busy meanwhile
   unsigned long long v = pair_counters[threadIdx.x];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if (threadIdx.x == 0) {
-    out[0] = ((unsigned long long)(unsigned int)*offsets_total << 32) | (unsigned long long)(unsigned int)*rank_total;
-    out[1] = v;
-    __threadfence_system();
-    out[2] = ticket;
-    __threadfence_system();
-  }
+  if (threadIdx.x == 0)
+    gs::publish_record(out, ticket, (unsigned int)*rank_total, (unsigned int)*offsets_total, v, 0u);
 }
 
 struct BwdOut {
@@ -828,7 +876,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   const size_t T = (size_t)((max_width + 15) / 16) * ((max_height + 15) / 16);
   int rc = GSPLAT_OK;
   auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
-  R(c->mask, N + 16); R(c->flags, (N + 1) * 4 + 1024); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
+  R(c->mask, N + 16); R(c->flags, 512 + gs::kBinBlocks * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64); R(c->hitmask, N * 8);
@@ -899,15 +947,15 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     c->harvest(c->slot);
   }
   c->fwd_calls++;
-  const dim3 gridN(gs::div_up((long long)N + 1, kBlock)), block(kBlock);
+  GS_REQUIRE(N <= (64 << 20), "more than 64 Mi gaussians: the cull's per-slice ballots would not fit its LDS");
   c->mark(0, false, st);
-  project_cull_kernel<<<gridN, block, 0, st>>>(g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh,
-                                               cfg->cull_mask_padding, c->xyz_c_all.as<float>(), c->uv_all.as<float>(),
-                                               c->mask.as<unsigned char>(), c->flags.as<int>(), c->pair_counters());
-  GS_LAUNCH_CHECK();
-  size_t scan_bytes = c->temp.bytes;
-  GS_HIP(rocprim::exclusive_scan(c->temp.ptr, scan_bytes, c->flags.as<int>(), c->rank.as<int>(), 0, (size_t)N + 1,
-                                 rocprim::plus<int>(), st));
+  {
+    const size_t trips = ((size_t)N / gs::kBinBlocks + 1 + gs::kBinThreads - 1) / gs::kBinThreads + 1;
+    project_cull_kernel<<<gs::kBinBlocks, gs::kBinThreads, trips * (gs::kBinThreads / 64) * 12, st>>>(
+        g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh, cfg->cull_mask_padding, c->xyz_c_all.as<float>(),
+        c->uv_all.as<float>(), c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->pair_counters());
+    GS_LAUNCH_CHECK();
+  }
   int rc = GSPLAT_OK;
   c->mark(0, true, st);
   c->mark(1, false, st);
@@ -929,7 +977,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   const size_t hist_bytes = sparse ? (size_t)num_tiles * sizeof(int) : 0;
 #define GS_PRE(LL)                                                                                                     \
   preprocess_kernel<LL><<<gs::kBinBlocks, gs::kBinThreads, hist_bytes, st>>>(                                          \
-      *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->xyz_c_all.as<float>(), c->uv_all.as<float>(),  \
+      *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->xyz_c_all.as<float>(),         \
+      c->uv_all.as<float>(),                                                                                            \
       fx, fy, tan_fovx, tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1], cam->campos[2], ntx, nty, po, bin_table)
   switch (l_max) {
     case 0: GS_PRE(0); break;
@@ -1014,12 +1063,18 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // Poll the mapped record; every few hundred polls ask the runtime about the stream, which both keeps its
     // submission path moving and tells us when everything queued so far has drained.
     volatile unsigned long long *pub = c->h_pub;
+    auto arrived = [&]() {
+      for (int k = 0; k < gs::kRecordWords; ++k)
+        if ((__atomic_load_n(&pub[k], __ATOMIC_RELAXED) & 0xFFFFFFFFull) != (ticket & 0xFFFFFFFFull)) return false;
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return true;
+    };
     long long polls = 0;
-    while (__atomic_load_n(&pub[2], __ATOMIC_ACQUIRE) != ticket) {
+    while (!arrived()) {
       if ((++polls & 255) == 0) {
         const hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess) {  // stream drained: the record must be there now
-          if (__atomic_load_n(&pub[2], __ATOMIC_ACQUIRE) == ticket) break;
+          if (arrived()) break;
           gs::set_error("gsplat_rasterize_image: the count record never arrived");
           return GSPLAT_ERR_HIP;
         }
@@ -1031,14 +1086,14 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       __builtin_ia32_pause();
     }
   }
-  const unsigned long long word0 = c->h_pub[0], pairs = c->h_pub[1];
-  const int M = (int)(unsigned int)(word0 & 0xFFFFFFFFull);
-  const size_t S = (size_t)(word0 >> 32);
+  const int M = (int)(unsigned int)(c->h_pub[0] >> 32);
+  const size_t S = (size_t)(c->h_pub[1] >> 32);
+  const unsigned long long pairs = (c->h_pub[2] >> 32) | (c->h_pub[3] & 0xFFFFFFFF00000000ull);
   if (M == 0) {
     gs::set_error("gsplat_rasterize_image: no gaussians in view");  // cuda/raster.cu:38-41
     return GSPLAT_ERR_NO_VISIBLE;
   }
-  const long long longest = sparse ? (long long)c->h_pub[3] : -1;
+  const long long longest = sparse ? (long long)(c->h_pub[4] >> 32) : -1;
   c->dense_route = gs::binning_next_route_is_radix(sparse, S, num_tiles, longest);
   c->last_longest = longest;
   const bool emitted = S <= inst_cap;  // dense route: else grow the instance buffers (synchronises) and emit again
