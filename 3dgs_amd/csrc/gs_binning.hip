@@ -605,6 +605,15 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int *__restric
   for (int k = 0; k < kRows; ++k) { table[(size_t)(kRows * w + k) * T + t] = run; run += v[k]; }
 }
 
+// what bin_scatter_kernel needs to publish the forward's host record (pub == nullptr: nothing to publish)
+struct RecordSource {
+  volatile unsigned long long *pub;
+  unsigned long long ticket;
+  const int *m_total;
+  const unsigned long long *pair_counters;
+  const int *summary;
+};
+
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *__restrict__ uv,
                                                                   const float *__restrict__ xyz_c,
                                                                   const float *__restrict__ radius,
@@ -612,9 +621,18 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
                                                                   const int *__restrict__ rank, int N, int ntx, int nty,
                                                                   const int *__restrict__ table,
                                                                   const int *__restrict__ ranges, long long capacity,
-                                                                  unsigned long long *__restrict__ payload) {
+                                                                  unsigned long long *__restrict__ payload,
+                                                                  RecordSource rec) {
   extern __shared__ int s_cur[];
   const int T = ntx * nty;
+  if (rec.pub && blockIdx.x == kBinBlocks - 1 && threadIdx.x >= kBinThreads - 64) {  // the forward's host record
+    unsigned long long c = rec.pair_counters[threadIdx.x & 63];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0)
+      publish_record(rec.pub, rec.ticket, (unsigned int)*rec.m_total, (unsigned int)rec.summary[0], c,
+                     (unsigned int)rec.summary[1]);
+  }
   {  // cursors = tile starts + this workgroup's offsets: all loads of a thread in flight before the first LDS store
     constexpr int kPer = kBinMaxTiles / kBinThreads;  // 16
     int start_t[kPer], off_t[kPer];
@@ -688,17 +706,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
 
 // ranges[0..T] = exclusive scan of totals[0..T) (ranges[T] = S): one workgroup, T <= kBinMaxTiles.  Replaces a
 // three-kernel rocPRIM scan of a few thousand integers.
-// It also publishes the forward's host record (publish_record in gs_common.h, see publish_counts_kernel in
-// gs_fused.hip) when `pub` is given: S is known here first, and it saves a launch on the path to the host's wake-up.
+// summary[0..1] = {S, longest list}: bin_scatter_kernel, the next launch, publishes the forward's host record from
+// them (a record written from THIS kernel kept it 5 us longer on the critical path: one thread's stores to host
+// memory have to drain before a kernel of one workgroup can end, while in the scatter they overlap 60 us of work).
 // `cap`: room of the instance buffers.  The kernels queued behind this one run before the host has seen S (see
 // gsplat_rasterize_image), so the ranges they read are clamped to the room: when S does not fit they work on truncated
 // lists inside the buffers, and the host -- which reads the TRUE S from the record -- grows the buffers, calls this
 // kernel again (pub == nullptr) and redoes them.
 __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__restrict__ totals, int *__restrict__ ranges,
-                                                          const int *__restrict__ m_total,
-                                                          const unsigned long long *__restrict__ pair_counters,
-                                                          volatile unsigned long long *pub, unsigned long long ticket,
-                                                          long long cap) {
+                                                          int *__restrict__ summary, long long cap) {
   constexpr int kPer = kBinMaxTiles / 1024;  // 16 consecutive tiles per thread at most
   __shared__ int s_wave[16], s_long[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -728,12 +744,7 @@ __global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__re
     S += x;
     longest_all = max(longest_all, s_long[q]);
   }
-  if (pub && threadIdx.x < 64) {
-    unsigned long long c = pair_counters[threadIdx.x];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if (threadIdx.x == 0) publish_record(pub, ticket, (unsigned int)*m_total, (unsigned int)S, c, (unsigned int)longest_all);
-  }
+  if (threadIdx.x == 0) { summary[0] = S; summary[1] = longest_all; }  // TRUE total and longest list, for the record
   int run = before + incl - sum;
   const int room = (int)min(cap, 0x7FFFFFFFll);
 #pragma unroll
@@ -756,18 +767,16 @@ bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles
   if (!binning_prefers_radix(S, num_tiles)) return false;
   return was_counting_sort ? longest > kLdsSort : true;
 }
-size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 2) * sizeof(int); }
+size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 4) * sizeof(int); }
 
 // Phase 1 (needs nothing from the host): per-workgroup offsets and ranges from the histogram rows preprocess_kernel
-// left in `table` (kBinBlocks * T ints, followed by T + 1 totals).
-int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
-                    const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
-                    long long capacity, hipStream_t st) {
+// left in `table` (kBinBlocks * T ints, followed by T + 1 totals and the two summary words of bin_ranges_kernel).
+int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, long long capacity, hipStream_t st) {
   const int T = ntx * nty;
   int *totals = table + (size_t)kBinBlocks * T;
   bin_offsets_kernel<<<div_up(T, 64), 1024, 0, st>>>(T, table, totals, long_tiles);
   GS_LAUNCH_CHECK();
-  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, m_total, pair_counters, pub, ticket, capacity);
+  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, totals + T + 1, capacity);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
@@ -775,19 +784,25 @@ int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, 
 // The ranges again, for a larger room (the instance buffers were grown): the totals are still behind the table.
 int binning_ranges_again(int ntx, int nty, int *table, int *ranges, long long capacity, hipStream_t st) {
   const int T = ntx * nty;
-  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, table + (size_t)kBinBlocks * T, ranges, nullptr, nullptr, nullptr, 0ull, capacity);
+  int *totals = table + (size_t)kBinBlocks * T;
+  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, totals + T + 1, capacity);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
 
-// Phase 2 (after the host knows S and the buffers hold it): place the payloads, then order every tile by depth.
+// Phase 2: place the payloads (at most S: the room of the buffers), then order every tile by depth.  With `pub` the
+// placement kernel also publishes the forward's host record {M, S, candidate pairs, longest list} under `ticket`.
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
                              const int *table, const int *ranges, size_t S, unsigned long long *payload,
-                             int *long_tiles, int *sorted_out, long long longest, hipStream_t st) {
+                             int *long_tiles, int *sorted_out, long long longest, const int *m_total,
+                             const unsigned long long *pair_counters, unsigned long long *pub,
+                             unsigned long long ticket, hipStream_t st) {
   const int T = ntx * nty;
+  const RecordSource rec = {pub, ticket, m_total, pair_counters, table + (size_t)kBinBlocks * T + T + 1};
   bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
-                                                                             nty, table, ranges, (long long)S, payload);
+                                                                             nty, table, ranges, (long long)S, payload,
+                                                                             rec);
   GS_LAUNCH_CHECK();
   return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest);
 }

@@ -29,14 +29,14 @@ bool binning_supports_counting_sort(int num_tiles);
 bool binning_prefers_radix(size_t S, int num_tiles);
 bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles, long long longest);
 size_t binning_table_bytes(int num_tiles);
-int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, const int *m_total,
-                    const unsigned long long *pair_counters, unsigned long long *pub, unsigned long long ticket,
-                    long long capacity, hipStream_t st);
+int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, long long capacity, hipStream_t st);
 int binning_ranges_again(int ntx, int nty, int *table, int *ranges, long long capacity, hipStream_t st);
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
                              const int *table, const int *ranges, size_t S, unsigned long long *payload,
-                             int *long_tiles, int *sorted_out, long long longest, hipStream_t st);
+                             int *long_tiles, int *sorted_out, long long longest, const int *m_total,
+                             const unsigned long long *pair_counters, unsigned long long *pub,
+                             unsigned long long ticket, hipStream_t st);
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
@@ -1001,8 +1001,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     spec_cap = room_of() - 1;
     c->mark(1, true, st);
     c->mark(2, false, st);
-    rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), c->rank.as<int>() + N,
-                             c->pair_counters(), c->d_pub, ticket, (long long)spec_cap, st);  // publishes the record too
+    rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), (long long)spec_cap, st);
     if (rc) return rc;
   } else {
     rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
@@ -1033,11 +1032,12 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   auto list_class = [](long long longest) {  // which of the workgroup sort kernels a list of that length needs
     return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : 1;
   };
-  auto queue_tail = [&](size_t cap, long long longest_hint) -> int {
+  auto queue_tail = [&](size_t cap, long long longest_hint, bool publish) -> int {  // the placement publishes the record
     int r = gs::binning_scatter_and_sort(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(),
                                          c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
                                          c->bin_table.as<int>(), c->ranges.as<int>(), cap, c->pay_a.as<unsigned long long>(),
-                                         c->keys_a.as<int>(), c->sorted.as<int>(), longest_hint, st);
+                                         c->keys_a.as<int>(), c->sorted.as<int>(), longest_hint, c->rank.as<int>() + N,
+                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st);
     if (r) return r;
     c->mark(2, true, st);
     c->mark(4, false, st);
@@ -1057,7 +1057,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // `ranges` on the device are clamped to spec_cap (bin_ranges_kernel): whatever S turns out to be, the queued kernels
     // stay inside the buffers
     spec_hint = c->last_longest >= 0 ? c->last_longest + c->last_longest / 2 + 64 : -1;  // unknown: every kernel
-    if ((rc = queue_tail(spec_cap, spec_hint))) return rc;
+    if ((rc = queue_tail(spec_cap, spec_hint, true))) return rc;
   }
   {
     // Poll the mapped record; every few hundred polls ask the runtime about the stream, which both keeps its
@@ -1106,7 +1106,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       }
       // the long-tile counter lives at the head of keys_a: zeroed by bin_offsets, then used by the queued sorts
       GS_HIP(hipMemsetAsync(c->keys_a.ptr, 0, sizeof(int), st));
-      if ((rc = queue_tail(S, longest))) return rc;
+      if ((rc = queue_tail(S, longest, false))) return rc;
     }
   } else {
     if ((rc = reserve_instances(c, S, num_tiles))) return rc;
