@@ -202,13 +202,15 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(int H, int W, int nt
                                                             const float *__restrict__ dm_mu,
                                                             const float *__restrict__ dm_s1,
                                                             const float *__restrict__ dm_s12,
-                                                            float *__restrict__ image_grad) {
+                                                            float *__restrict__ image_grad,
+                                                            float *__restrict__ next_acc) {
   __shared__ __attribute__((aligned(16))) float sD[9 * kSH * kPitchB];  // plane = channel * 3 + map, zero outside the image
   __shared__ __attribute__((aligned(16))) float sP[kSH * kPair];        // horizontal pass: maps (mu, s1) interleaved
   __shared__ __attribute__((aligned(16))) float sQ[kSH * kSingle];      // ... and s12
   const int tid = threadIdx.x;
   int tx, ty, tile;
   if (!tile_of(ntx, nty, tx, ty, tile)) return;
+  if (tile == 0) next_acc[tid] = 0.0f;  // the spread counters of the NEXT fused_loss call (kSpread == 256 threads)
   const int x0 = tx * kTW, y0 = ty * kTH;
   const int vx = tid & (kTW - 1), vy = (tid >> 5) * 2;
   float p1[2][3], p2[2][3];  // the two pixels this thread finishes
@@ -445,20 +447,31 @@ int gsplat_fused_loss(const float *predicted_data, const float *gt_data, int row
                    &s12 = gs::scratch(gs::SCR_LOSS_S12), &acc = gs::scratch(gs::SCR_LOSS_ACC);
   int rc;
   if ((rc = mu.reserve(bytes)) || (rc = s1.reserve(bytes)) || (rc = s12.reserve(bytes)) ||
-      (rc = acc.reserve(kSpread * sizeof(float))))
+      (rc = acc.reserve(3 * kSpread * sizeof(float))))
     return rc;
-  GS_HIP(hipMemsetAsync(acc.ptr, 0, kSpread * sizeof(float), st));
+  // the spread counters alternate between two sets: the backward kernel of one call clears the set of the next, which
+  // saves a memset launch per training iteration (the first set of the buffer belongs to gsplat_compute_psnr)
+  static int flip = 0;
+  static bool primed = false;
+  static hipStream_t primed_stream = nullptr;
+  static void *primed_ptr = nullptr;
+  if (!primed || primed_stream != st || primed_ptr != acc.ptr) {
+    GS_HIP(hipMemsetAsync(acc.as<float>() + kSpread, 0, 2 * kSpread * sizeof(float), st));
+    primed = true; primed_stream = st; primed_ptr = acc.ptr;
+  }
+  float *cur = acc.as<float>() + (1 + flip) * kSpread, *next = acc.as<float>() + (2 - flip) * kSpread;
+  flip ^= 1;
   const int ntx = (cols + kTW - 1) / kTW, nty = (rows + kTH - 1) / kTH;
   const dim3 grid((unsigned)(((ntx * nty + 7) / 8) * 8)), block(256);  // whole rounds of the eight XCDs: tile_of()
-  loss_forward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data,
-                                              acc.as<float>(), mu.as<float>(), s1.as<float>(), s12.as<float>());
+  loss_forward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data, cur,
+                                              mu.as<float>(), s1.as<float>(), s12.as<float>());
   GS_LAUNCH_CHECK();
   loss_backward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data,
-                                               mu.as<float>(), s1.as<float>(), s12.as<float>(), image_grad);
+                                               mu.as<float>(), s1.as<float>(), s12.as<float>(), image_grad, next);
   GS_LAUNCH_CHECK();
   if (loss_out) {  // the reference returns the value, i.e. blocks (cuda/loss.cu:468-470)
     double total;
-    if ((rc = read_spread_sum(acc.as<float>(), st, &total))) return rc;
+    if ((rc = read_spread_sum(cur, st, &total))) return rc;
     *loss_out = (float)(total / (double)((size_t)rows * cols * 3));
   }
   return GSPLAT_OK;
@@ -471,7 +484,7 @@ int gsplat_compute_psnr(const float *predicted_data, const float *gt_data, int r
   GS_REQUIRE(rows > 0 && cols > 0, "image size must be positive");
   hipStream_t st = (hipStream_t)stream;
   gs::DeviceBuffer &acc = gs::scratch(gs::SCR_LOSS_ACC);
-  int rc = acc.reserve(kSpread * sizeof(float));
+  int rc = acc.reserve(3 * kSpread * sizeof(float));  // [0, kSpread): this function's; the rest: gsplat_fused_loss
   if (rc) return rc;
   GS_HIP(hipMemsetAsync(acc.ptr, 0, kSpread * sizeof(float), st));
   const long long n = (long long)rows * cols * 3;
