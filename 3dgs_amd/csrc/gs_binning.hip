@@ -611,47 +611,106 @@ struct RecordSource {
   unsigned long long ticket;
   const int *m_total;
   const unsigned long long *pair_counters;
-  const int *summary;
 };
 
+// Placement.  Every workgroup first scans the T tile totals itself (32 KB of L2-resident counts, one wave-shuffle scan
+// and one barrier: about a microsecond, 256 times in parallel) instead of reading `ranges` from a scan kernel of one
+// workgroup that cost 11 us on the stream (a launch, a chain of dependent loads and stores, nothing to overlap them
+// with).  Workgroup 0 stores ranges[0..T] for the kernels behind this one, clamped to `capacity`, the room of the
+// instance buffers: those kernels run before the host has seen S (gsplat_rasterize_image), so when S does not fit they
+// work on truncated lists inside the buffers, and the host -- which reads the TRUE S from the record the last
+// workgroup publishes -- grows the buffers and queues this kernel and the rest again.
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *__restrict__ uv,
                                                                   const float *__restrict__ xyz_c,
                                                                   const float *__restrict__ radius,
                                                                   const unsigned long long *__restrict__ hitmask,
                                                                   const int *__restrict__ rank, int N, int ntx, int nty,
                                                                   const int *__restrict__ table,
-                                                                  const int *__restrict__ ranges, long long capacity,
+                                                                  int *__restrict__ ranges, long long capacity,
                                                                   unsigned long long *__restrict__ payload,
                                                                   RecordSource rec) {
   extern __shared__ int s_cur[];
+  __shared__ int s_wave[kBinThreads / 64], s_long[kBinThreads / 64];
   const int T = ntx * nty;
-  if (rec.pub && blockIdx.x == kBinBlocks - 1 && threadIdx.x >= kBinThreads - 64) {  // the forward's host record
-    unsigned long long c = rec.pair_counters[threadIdx.x & 63];
+  const int lane = threadIdx.x & 63;
+  {
+    constexpr int kPer = kBinMaxTiles / kBinThreads;  // 16 tiles per thread at most
+    const int *totals = table + (size_t)kBinBlocks * T;
+    const int w = threadIdx.x >> 6;
+    // pass A, tile t = thread + 1024 k (coalesced): the totals go to LDS, this workgroup's offsets stay in registers
+    int off_t[kPer];
+    {
+      int tot[kPer];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0)
-      publish_record(rec.pub, rec.ticket, (unsigned int)*rec.m_total, (unsigned int)rec.summary[0], c,
-                     (unsigned int)rec.summary[1]);
-  }
-  {  // cursors = tile starts + this workgroup's offsets: all loads of a thread in flight before the first LDS store
-    constexpr int kPer = kBinMaxTiles / kBinThreads;  // 16
-    int start_t[kPer], off_t[kPer];
+      for (int k = 0; k < kPer; ++k) {  // all loads of a thread in flight before the first LDS store
+        const int t = threadIdx.x + k * kBinThreads;
+        tot[k] = t < T ? totals[t] : 0;
+        off_t[k] = t < T ? table[(size_t)blockIdx.x * T + t] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int t = threadIdx.x + k * kBinThreads;
+        if (t < T) s_cur[t] = tot[k];
+      }
+    }
+    __syncthreads();
+    // pass B, `per` consecutive tiles per thread: exclusive scan in place
+    const int per = (T + kBinThreads - 1) / kBinThreads, lo = threadIdx.x * per;
+    int v[kPer], sum = 0, longest = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      v[k] = (k < per && lo + k < T) ? s_cur[lo + k] : 0;
+      sum += v[k];
+      longest = max(longest, v[k]);
+    }
+    int incl = sum;  // inclusive scan of the thread sums inside the wave, then of the sixteen wave sums
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
+    if (lane == 63) { s_wave[w] = incl; s_long[w] = longest; }
+    __syncthreads();
+    int before = 0, S = 0, longest_all = 0;  // the longest list: the host picks the next forward's binning route by it
+#pragma unroll
+    for (int q = 0; q < kBinThreads / 64; ++q) {
+      const int x = s_wave[q];
+      before += q < w ? x : 0;
+      S += x;
+      longest_all = max(longest_all, s_long[q]);
+    }
+    if (rec.pub && blockIdx.x == kBinBlocks - 1 && threadIdx.x < 64) {  // the forward's host record
+      unsigned long long c = rec.pair_counters[threadIdx.x];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+      if (threadIdx.x == 0)
+        publish_record(rec.pub, rec.ticket, (unsigned int)*rec.m_total, (unsigned int)S, c, (unsigned int)longest_all);
+    }
+    const int room = (int)min(capacity, 0x7FFFFFFFll);
+    int run = before + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (k < per && lo + k < T) s_cur[lo + k] = min(run, room);
+      run += v[k];
+    }
+    __syncthreads();
+    // pass C, coalesced again: ranges for the kernels behind this one, cursors = tile start + this workgroup's offset
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int t = threadIdx.x + k * kBinThreads;
-      start_t[k] = t < T ? ranges[t] : 0;
-      off_t[k] = t < T ? table[(size_t)blockIdx.x * T + t] : 0;
+      if (t < T) {
+        const int start = s_cur[t];
+        if (blockIdx.x == 0) ranges[t] = start;
+        s_cur[t] = start + off_t[k];
+      }
     }
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int t = threadIdx.x + k * kBinThreads;
-      if (t < T) s_cur[t] = start_t[k] + off_t[k];
-    }
+    if (blockIdx.x == 0 && threadIdx.x == kBinThreads - 1) ranges[T] = min(S, room);
   }
   __syncthreads();
   // the compacted gaussians of this workgroup's slice of global indices (rank = exclusive scan of the cull mask)
   const int lo = rank[(long long)N * blockIdx.x / kBinBlocks], hi = rank[(long long)N * (blockIdx.x + 1) / kBinBlocks];
-  const int lane = threadIdx.x & 63;
   auto place = [&](int tile, unsigned long long pay) {
     const int pos = atomicAdd(&s_cur[tile], 1);
     if (pos < capacity) payload[pos] = pay;
@@ -704,57 +763,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
   }
 }
 
-// ranges[0..T] = exclusive scan of totals[0..T) (ranges[T] = S): one workgroup, T <= kBinMaxTiles.  Replaces a
-// three-kernel rocPRIM scan of a few thousand integers.
-// summary[0..1] = {S, longest list}: bin_scatter_kernel, the next launch, publishes the forward's host record from
-// them (a record written from THIS kernel kept it 5 us longer on the critical path: one thread's stores to host
-// memory have to drain before a kernel of one workgroup can end, while in the scatter they overlap 60 us of work).
-// `cap`: room of the instance buffers.  The kernels queued behind this one run before the host has seen S (see
-// gsplat_rasterize_image), so the ranges they read are clamped to the room: when S does not fit they work on truncated
-// lists inside the buffers, and the host -- which reads the TRUE S from the record -- grows the buffers, calls this
-// kernel again (pub == nullptr) and redoes them.
-__global__ __launch_bounds__(1024) void bin_ranges_kernel(int T, const int *__restrict__ totals, int *__restrict__ ranges,
-                                                          int *__restrict__ summary, long long cap) {
-  constexpr int kPer = kBinMaxTiles / 1024;  // 16 consecutive tiles per thread at most
-  __shared__ int s_wave[16], s_long[16];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = (T + 1023) / 1024, lo = threadIdx.x * per;
-  int v[kPer], sum = 0, longest = 0;
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    v[k] = (k < per && lo + k < T) ? totals[lo + k] : 0;
-    sum += v[k];
-    longest = max(longest, v[k]);
-  }
-  int incl = sum;  // inclusive scan of the thread sums inside the wave, then of the sixteen wave sums
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int u = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += u;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
-  if (lane == 63) { s_wave[w] = incl; s_long[w] = longest; }
-  __syncthreads();
-  int before = 0, S = 0, longest_all = 0;  // the longest tile list: the host picks the next forward's binning route by it
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int x = s_wave[q];
-    before += q < w ? x : 0;
-    S += x;
-    longest_all = max(longest_all, s_long[q]);
-  }
-  if (threadIdx.x == 0) { summary[0] = S; summary[1] = longest_all; }  // TRUE total and longest list, for the record
-  int run = before + incl - sum;
-  const int room = (int)min(cap, 0x7FFFFFFFll);
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    if (k < per && lo + k < T) ranges[lo + k] = min(run, room);
-    run += v[k];
-  }
-  if (threadIdx.x == 1023) ranges[T] = min(S, room);
-}
-
 bool binning_supports_counting_sort(int num_tiles) { return num_tiles <= kBinMaxTiles; }
 bool binning_prefers_radix(size_t S, int num_tiles) { return (long long)S > dense_tile_threshold() * (long long)num_tiles; }
 // Route of the NEXT forward.  Up to dense_tile_threshold() entries per tile on average: counting sort + per-tile
@@ -767,39 +775,28 @@ bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles
   if (!binning_prefers_radix(S, num_tiles)) return false;
   return was_counting_sort ? longest > kLdsSort : true;
 }
-size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 4) * sizeof(int); }
+size_t binning_table_bytes(int num_tiles) { return ((size_t)kBinBlocks * num_tiles + num_tiles + 2) * sizeof(int); }
 
-// Phase 1 (needs nothing from the host): per-workgroup offsets and ranges from the histogram rows preprocess_kernel
-// left in `table` (kBinBlocks * T ints, followed by T + 1 totals and the two summary words of bin_ranges_kernel).
-int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, long long capacity, hipStream_t st) {
+// Phase 1 (needs nothing from the host): per-workgroup offsets from the histogram rows preprocess_kernel left in
+// `table` (kBinBlocks * T ints, followed by T + 1 totals).
+int binning_offsets(int ntx, int nty, int *table, int *long_tiles, hipStream_t st) {
   const int T = ntx * nty;
-  int *totals = table + (size_t)kBinBlocks * T;
-  bin_offsets_kernel<<<div_up(T, 64), 1024, 0, st>>>(T, table, totals, long_tiles);
-  GS_LAUNCH_CHECK();
-  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, totals + T + 1, capacity);
+  bin_offsets_kernel<<<div_up(T, 64), 1024, 0, st>>>(T, table, table + (size_t)kBinBlocks * T, long_tiles);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
 
-// The ranges again, for a larger room (the instance buffers were grown): the totals are still behind the table.
-int binning_ranges_again(int ntx, int nty, int *table, int *ranges, long long capacity, hipStream_t st) {
-  const int T = ntx * nty;
-  int *totals = table + (size_t)kBinBlocks * T;
-  bin_ranges_kernel<<<1, 1024, 0, st>>>(T, totals, ranges, totals + T + 1, capacity);
-  GS_LAUNCH_CHECK();
-  return GSPLAT_OK;
-}
-
-// Phase 2: place the payloads (at most S: the room of the buffers), then order every tile by depth.  With `pub` the
-// placement kernel also publishes the forward's host record {M, S, candidate pairs, longest list} under `ticket`.
+// Phase 2: ranges (clamped to S, the room of the buffers) and placement of at most S payloads, then the per-tile depth
+// order.  With `pub` the placement kernel also publishes the forward's host record {M, S, candidate pairs, longest
+// list} under `ticket`.
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
-                             const int *table, const int *ranges, size_t S, unsigned long long *payload,
+                             const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
                              unsigned long long ticket, hipStream_t st) {
   const int T = ntx * nty;
-  const RecordSource rec = {pub, ticket, m_total, pair_counters, table + (size_t)kBinBlocks * T + T + 1};
+  const RecordSource rec = {pub, ticket, m_total, pair_counters};
   bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
                                                                              nty, table, ranges, (long long)S, payload,
                                                                              rec);

@@ -29,11 +29,10 @@ bool binning_supports_counting_sort(int num_tiles);
 bool binning_prefers_radix(size_t S, int num_tiles);
 bool binning_next_route_is_radix(bool was_counting_sort, size_t S, int num_tiles, long long longest);
 size_t binning_table_bytes(int num_tiles);
-int binning_offsets(int ntx, int nty, int *table, int *ranges, int *long_tiles, long long capacity, hipStream_t st);
-int binning_ranges_again(int ntx, int nty, int *table, int *ranges, long long capacity, hipStream_t st);
+int binning_offsets(int ntx, int nty, int *table, int *long_tiles, hipStream_t st);
 int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *radius,
                              const unsigned long long *hitmask, const int *rank, int N, int ntx, int nty,
-                             const int *table, const int *ranges, size_t S, unsigned long long *payload,
+                             const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
                              unsigned long long ticket, hipStream_t st);
@@ -1001,7 +1000,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     spec_cap = room_of() - 1;
     c->mark(1, true, st);
     c->mark(2, false, st);
-    rc = gs::binning_offsets(ntx, nty, bin_table, c->ranges.as<int>(), c->keys_a.as<int>(), (long long)spec_cap, st);
+    rc = gs::binning_offsets(ntx, nty, bin_table, c->keys_a.as<int>(), st);
     if (rc) return rc;
   } else {
     rc = gs::scan_counts(N, c->counts.as<int>(), c->offsets.as<int>(), c->temp.ptr, c->temp.bytes, st);
@@ -1054,7 +1053,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->rows_zeroed = c->backward_seen && !ro;
   long long spec_hint = -1;
   if (sparse) {
-    // `ranges` on the device are clamped to spec_cap (bin_ranges_kernel): whatever S turns out to be, the queued kernels
+    // `ranges` on the device are clamped to spec_cap (bin_scatter_kernel): whatever S turns out to be, the queued kernels
     // stay inside the buffers
     spec_hint = c->last_longest >= 0 ? c->last_longest + c->last_longest / 2 + 64 : -1;  // unknown: every kernel
     if ((rc = queue_tail(spec_cap, spec_hint, true))) return rc;
@@ -1100,10 +1099,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   if (sparse) {
     const bool fits = S <= spec_cap;
     if (!fits || !(spec_hint < 0 || list_class(longest) <= list_class(spec_hint))) {
-      if (!fits) {  // grow (synchronises), then the true ranges
-        if ((rc = reserve_instances(c, S + S / 4, num_tiles))) return rc;
-        if ((rc = gs::binning_ranges_again(ntx, nty, c->bin_table.as<int>(), c->ranges.as<int>(), (long long)S, st))) return rc;
-      }
+      // grow (synchronises); the placement queued below writes the true ranges
+      if (!fits && (rc = reserve_instances(c, S + S / 4, num_tiles))) return rc;
       // the long-tile counter lives at the head of keys_a: zeroed by bin_offsets, then used by the queued sorts
       GS_HIP(hipMemsetAsync(c->keys_a.ptr, 0, sizeof(int), st));
       if ((rc = queue_tail(S, longest, false))) return rc;
