@@ -102,6 +102,7 @@ struct gsplat_context {
   }
   // state of the last forward
   int N = 0, M = 0, l_max = 0, width = 0, height = 0;
+  float tan_fovx = 0.f, tan_fovy = 0.f, mh_dist = 0.f;  // what the per-gaussian backward needs to redo Sigma, J, conic
   size_t S = 0;
   long long last_longest = -1;  // longest tile list of the last counting-sort forward (-1: unknown)
   bool have_forward = false;
@@ -410,11 +411,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
                                                                 const float *__restrict__ proj, int M,
                                                                 const int *__restrict__ c2g,
                                                                 const float *__restrict__ xyz_c_sel,
-                                                                const float *__restrict__ sigma,
-                                                                const float *__restrict__ Jm,
-                                                                const float *__restrict__ conic,
                                                                 const float4 *__restrict__ rows_in, float fx, float fy,
-                                                                float tan_fovx, float tan_fovy, float cx, float cy,
+                                                                float tan_fovx, float tan_fovy, float fwd_tan_fovx,
+                                                                float fwd_tan_fovy, float mh_dist, float cx, float cy,
                                                                 float cz, int width, int height, BwdOut o) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   constexpr int n = (L + 1) * (L + 1), kRest = (n - 1) * 3;
@@ -496,23 +495,31 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   }
   if (!live) return;
   gx = 0.0f + gx; gy = 0.0f + gy; gz = 0.0f + gz;
-  // conic -> (J, Sigma)
-  float Jv[6], sg[6], con[3], dJ[6], dS[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { Jv[k] = Jm[6 * j + k]; sg[k] = sigma[6 * j + k]; }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) con[k] = conic[3 * j + k];
+  // conic -> (J, Sigma).  Sigma, J and the conic are RECOMPUTED from what this kernel reads anyway (quaternion, scale,
+  // camera-space position) with the forward's functions and the forward's tan(fov): bit for bit the values
+  // preprocess_kernel stored, without reading 60 bytes per gaussian back (the kernel is HBM bound).
+  const float x = xyz_c_sel[3 * j], y = xyz_c_sel[3 * j + 1], z = xyz_c_sel[3 * j + 2];
+  float Jv[6], sg[6], con[3], rad_unused[4], dJ[6], dS[6];
+  {
+    const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i];
+    const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
+    gs::sigma_from(rs, sg);
+  }
+  gs::jacobian(x, y, z, fx, fy, fwd_tan_fovx, fwd_tan_fovy, Jv);
+  gs::conic_radius(Jv, sg, vw, mh_dist, con, rad_unused);
   gs::conic_bwd(Jv, sg, vw, con, g_con, dJ, dS);
 #pragma unroll
   for (int k = 0; k < 6; ++k) { dJ[k] = 0.0f + dJ[k]; dS[k] = 0.0f + dS[k]; }
   // J -> xyz_c
-  const float x = xyz_c_sel[3 * j], y = xyz_c_sel[3 * j + 1], z = xyz_c_sel[3 * j + 2];
   float cxg, cyg, czg;
   gs::jacobian_bwd(x, y, z, fx, fy, tan_fovx, tan_fovy, dJ, cxg, cyg, czg);
   cxg = 0.0f + cxg; cyg = 0.0f + cyg; czg = 0.0f + czg;
-  // Sigma -> quaternion, scale
-  const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i];
-  const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
+  // Sigma -> quaternion, scale.  The rotation/scale terms are built a second time from a second (L2-resident) read
+  // through an opaque copy of the index: kept alive across conic_bwd they cost 58 VGPRs and a third of the occupancy.
+  int i2 = i;
+  asm volatile("" : "+v"(i2));
+  const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i2];
+  const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i2], g.scale[3 * i2 + 1], g.scale[3 * i2 + 2]);
   float dQ[4], dSc[3];
   gs::sigma_bwd(rs, dS, dQ, dSc);
   // uv -> xyz_c
@@ -1124,6 +1131,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     c->mark(4, true, st);
   }
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
+  c->tan_fovx = tan_fovx; c->tan_fovy = tan_fovy; c->mh_dist = cfg->mh_dist;
   c->have_forward = !ro;  // a render-only forward leaves nothing for a backward
   if (out) {
     out->num_culled = (size_t)M; out->num_pairs = (size_t)pairs; out->num_splats = S;
@@ -1190,16 +1198,16 @@ int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, cons
   const float fov_x = (float)(2.0 * atan((double)W / (2.0 * (double)fx)));
   const float fov_y = (float)(2.0 * atan((double)H / (2.0 * (double)fy)));
   const float tan_fovx = tanf(fov_x * 0.5f), tan_fovy = tanf(fov_y * 0.5f);
+  const float fwd_tan_fovx = c->tan_fovx, fwd_tan_fovy = c->tan_fovy;  // the recorded forward's (cuda/raster.cu:92-93)
   BwdOut bo = {out->grad_xyz, out->grad_rgb, out->grad_sh, out->grad_opacity, out->grad_scale, out->grad_quaternion,
                out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb};
   const dim3 grid(gs::div_up(M, kBlock)), block(kBlock);
   c->mark(7, false, st);
 #define GS_BWD(LL)                                                                                                     \
   preprocess_bwd_kernel<LL><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),                     \
-                                                    c->xyz_c.as<float>(), c->sigma.as<float>(), c->J.as<float>(),      \
-                                                    c->conic.as<float>(), c->grad_rows.as<float4>(), fx, fy,           \
-                                                    tan_fovx, tan_fovy, cam->campos[0], cam->campos[1],                \
-                                                    cam->campos[2], W, H, bo)
+                                                    c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
+                                                    tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
+                                                    cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo)
   switch (l_max) {
     case 0: GS_BWD(0); break;
     case 1: GS_BWD(1); break;
