@@ -154,11 +154,14 @@ class RasterContext:
         return out
 
     def alloc_gradients(self, M, l_max, intermediates=False, device="cuda"):
+        """Leaf gradients in compacted order; intermediates=True adds the reference's six intermediate gradient arrays
+        (cuda_data.cuh:28-36), an iterable of their names only those (the kernel skips the ones that are absent)."""
         n_rest = (l_max + 1) ** 2 - 1
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         g = dict(xyz=z(M, 3), rgb=z(M, 3), sh=z(M, n_rest, 3), opacity=z(M), scale=z(M, 3), quaternion=z(M, 4))
-        if intermediates:
-            g.update(conic=z(M, 3), uv=z(M, 2), J=z(M, 6), sigma=z(M, 6), xyz_c=z(M, 3), precompute_rgb=z(M, 3))
+        shapes = dict(conic=(M, 3), uv=(M, 2), J=(M, 6), sigma=(M, 6), xyz_c=(M, 3), precompute_rgb=(M, 3))
+        wanted = shapes if intermediates is True else (intermediates or ())  # True: all six; or an iterable of names
+        g.update({k: z(*shapes[k]) for k in wanted})
         return g
 
     @staticmethod

@@ -115,7 +115,7 @@ class Trainer:
         """Per-view gradient arrays in compacted order: allocated for the current gaussian count, sliced per view."""
         n = self.num_gaussians
         if self._grads is None or self._grads[0] < n or self._grads[1] != self.l_max:
-            self._grads = (n, self.l_max, ctx.alloc_gradients(n, self.l_max, intermediates=True))
+            self._grads = (n, self.l_max, ctx.alloc_gradients(n, self.l_max, intermediates=("uv",)))  # density statistics need |grad_uv|
         return {k: v[:m] for k, v in self._grads[2].items()}
 
     def train_step(self, cam, gt_image, want_loss=True):

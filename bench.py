@@ -349,7 +349,7 @@ def main():
         dp_train = {k: v.clone() for k, v in dp.items()}
         target = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)["image"].clone()
         opt = opt_mod.AdamOptimizer(dp_train, L, scene_extent=5.0)
-        tgrads = step.ctx.alloc_gradients(N, L, intermediates=True)
+        tgrads = step.ctx.alloc_gradients(N, L, intermediates=("uv",))  # as the Trainer: density statistics need |grad_uv|
         loss_grad = torch.empty(H, W, 3, device=dev)
 
         def train_step(it):
