@@ -58,7 +58,7 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
 struct gsplat_context {
   int max_gaussians = 0, max_width = 0, max_height = 0;
   // per-gaussian, global order
-  gs::DeviceBuffer mask, flags, rank, xyz_c_all, uv_all;
+  gs::DeviceBuffer mask, counters, rank, xyz_c_all, uv_all;
   // per-gaussian, compacted order
   gs::DeviceBuffer c2g, xyz_c, uv, sigma, conic, J, rgb, radius, recs, counts, offsets, grad_rows, hitmask;
   // instances
@@ -76,8 +76,8 @@ struct gsplat_context {
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
   // small device counters: 64 spread counters of candidate pairs, then the kBinBlocks slice counts of the cull
-  unsigned long long *pair_counters() const { return flags.as<unsigned long long>(); }
-  int *slice_counts() const { return flags.as<int>() + 128; }
+  unsigned long long *pair_counters() const { return counters.as<unsigned long long>(); }
+  int *slice_counts() const { return counters.as<int>() + 128; }
   // optional per-stage HIP-event timing (gsplat_context_set_timing)
   static constexpr int kStages = 8, kSlots = 32;
   unsigned int timing = 0;  // bit k: stage k is timed
@@ -107,7 +107,7 @@ struct gsplat_context {
   long long last_longest = -1;  // longest tile list of the last counting-sort forward (-1: unknown)
   bool have_forward = false;
   size_t bytes() const {
-    const gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
+    const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                      &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks};
     size_t b = 0;
@@ -115,7 +115,7 @@ struct gsplat_context {
     return b;
   }
   void release() {
-    gs::DeviceBuffer *all[] = {&mask, &flags, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
+    gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks};
     for (auto *p : all) p->release();
@@ -882,7 +882,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   const size_t T = (size_t)((max_width + 15) / 16) * ((max_height + 15) / 16);
   int rc = GSPLAT_OK;
   auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
-  R(c->mask, N + 16); R(c->flags, 512 + gs::kBinBlocks * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
+  R(c->mask, N + 16); R(c->counters, 512 + gs::kBinBlocks * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64); R(c->hitmask, N * 8);
