@@ -273,55 +273,86 @@ __device__ __forceinline__ double key_max(double a, double b) {
   return r;
 }
 
-template <int E>
-__device__ __forceinline__ void wave_bitonic_sort_f64(double (&v)[E], int lane) {
-  constexpr int kTotal = 64 * E;
+// Lane exchanges of the network.  Most of them stay inside a row of 16 lanes, where a DPP move on the VALU does what a
+// ds_bpermute does through the LDS: the kernel spent a third of the CU's LDS cycles and most of each wave's time in
+// 21 dependent bpermute round trips per 512-entry sort (PMC: VALU 27 % busy, LDS 34 %), and the LDS is shared by the
+// four SIMDs while the DPP moves are not.  xor 4 and xor 8 are two mirrors in a row (l^7^3, l^15^7).
+template <int kCtrl>
+__device__ __forceinline__ double dpp_move(double x) {
+  const long long b = __double_as_longlong(x);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_mov_dpp(lo, kCtrl, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, kCtrl, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+template <int D>
+__device__ __forceinline__ double from_lane_xor(double x) {  // the value lane ^ D holds, D a power of two
+  if constexpr (D == 1) return dpp_move<0xB1>(x);                        // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return dpp_move<0x4E>(x);                   // quad_perm [2,3,0,1]
+  else if constexpr (D == 4) return dpp_move<0x1B>(dpp_move<0x141>(x));  // row_half_mirror, then quad_perm [3,2,1,0]
+  else if constexpr (D == 8) return dpp_move<0x141>(dpp_move<0x140>(x)); // row_mirror, then row_half_mirror
+  else return __shfl_xor(x, D, 64);
+}
+template <int M>
+__device__ __forceinline__ double from_lane_mirror(double x, int lane) {  // the value lane ^ (M - 1) holds
+  if constexpr (M == 2) return dpp_move<0xB1>(x);
+  else if constexpr (M == 4) return dpp_move<0x1B>(x);
+  else if constexpr (M == 8) return dpp_move<0x141>(x);
+  else if constexpr (M == 16) return dpp_move<0x140>(x);
+  else return __shfl(x, lane ^ (M - 1), 64);
+}
+
+// the compare-exchange steps at distances J, J/2, .. 1 (entries; lane L holds entries L*E .. L*E+E-1)
+template <int E, int J>
+__device__ __forceinline__ void bitonic_clean_f64(double (&v)[E], int lane) {
+  if constexpr (J < E) {
 #pragma unroll
-  for (int k = 2; k <= kTotal; k <<= 1) {
-    if (k <= E) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int o = e ^ (k - 1);
-        if (e < o) {
-          const double a = v[e], b = v[o];
-          v[e] = key_min(a, b);
-          v[o] = key_max(a, b);
-        }
+    for (int e = 0; e < E; ++e)
+      if ((e & J) == 0) {
+        const double a = v[e], b = v[e | J];
+        v[e] = key_min(a, b);
+        v[e | J] = key_max(a, b);
       }
-    } else {
-      const int partner = lane ^ (k / E - 1);
-      const bool lower = (lane & (k / E / 2)) == 0;
-      double got[E];
+  } else {
+    constexpr int d = J / E;
+    const bool upper = (lane & d) != 0;
 #pragma unroll
-      for (int e = 0; e < E; ++e) got[e] = __shfl(v[E - 1 - e], partner, 64);
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const double lo = key_min(got[e], v[e]), hi = key_max(got[e], v[e]);
-        v[e] = lower ? lo : hi;
-      }
-    }
-#pragma unroll
-    for (int j = k >> 2; j > 0; j >>= 1) {
-      if (j < E) {
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-          if ((e & j) == 0) {
-            const double a = v[e], b = v[e | j];
-            v[e] = key_min(a, b);
-            v[e | j] = key_max(a, b);
-          }
-      } else {
-        const int d = j / E;
-        const bool lower = (lane & d) == 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const double got = __shfl_xor(v[e], d, 64);
-          const double lo = key_min(got, v[e]), hi = key_max(got, v[e]);
-          v[e] = lower ? lo : hi;
-        }
-      }
+    for (int e = 0; e < E; ++e) {  // the lower lane keeps the smaller key, the upper lane the larger: one compare, the
+      const double got = from_lane_xor<d>(v[e]);  // wave-constant lane pattern folded in on the scalar unit, one select
+      v[e] = ((got < v[e]) != upper) ? got : v[e];
     }
   }
+  if constexpr (J > 1) bitonic_clean_f64<E, J / 2>(v, lane);
+}
+
+// merge level K (sorted runs of K/2 -> K), then the levels above it
+template <int E, int K>
+__device__ __forceinline__ void bitonic_level_f64(double (&v)[E], int lane) {
+  if constexpr (K <= E) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int o = e ^ (K - 1);
+      if (e < o) {
+        const double a = v[e], b = v[o];
+        v[e] = key_min(a, b);
+        v[o] = key_max(a, b);
+      }
+    }
+  } else {
+    const bool upper = (lane & (K / E / 2)) != 0;
+    double got[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) got[e] = from_lane_mirror<K / E>(v[E - 1 - e], lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = ((got[e] < v[e]) != upper) ? got[e] : v[e];
+  }
+  if constexpr (K >= 4) bitonic_clean_f64<E, K / 4>(v, lane);
+  if constexpr (K < 64 * E) bitonic_level_f64<E, 2 * K>(v, lane);
+}
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort_f64(double (&v)[E], int lane) {
+  bitonic_level_f64<E, 2>(v, lane);
 }
 
 // Loads `len` (<= 64 E) payloads starting at `start` as doubles (padding: +infinity) and sorts them; lane L ends with
