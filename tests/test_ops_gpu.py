@@ -157,6 +157,40 @@ def test_binning_with_depths_outside_the_register_sorts_range(gpu, orc, case):
     assert (srt.cpu().numpy()[:len(want_sorted)] == want_sorted).all()
 
 
+def test_binning_list_lengths_around_the_sort_network_sizes_with_tied_depths(gpu, orc):
+    """One tile per list length around every size class of the per-tile sort (64 E entries in registers for E = 1..16,
+    the workgroup kernels beyond 1024) and only five distinct depths, so that most of the order is decided by the
+    gaussian id: the DPP / bpermute lane exchanges and the tie-break must give the reference's lists bit for bit."""
+    torch, ops = gpu, pkg("ops")
+    lengths = [1, 63, 64, 65, 127, 128, 129, 255, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2049, 4100]
+    ntx, nty = len(lengths), 1
+    rng = np.random.default_rng(11)
+    uv, z = [], []
+    for t, n in enumerate(lengths):
+        uv.append(np.stack([16.0 * t + 2.0 + 12.0 * rng.random(n), 2.0 + 12.0 * rng.random(n)], 1))
+        z.append(rng.choice(np.float32([0.5, 1.25, 2.0, 7.5, 31.0]), n))
+    uv = np.concatenate(uv).astype(np.float32)
+    M = len(uv)
+    order = rng.permutation(M)  # ids unrelated to tiles
+    uv = uv[order]
+    xyz = np.zeros((M, 3), np.float32)
+    xyz[:, 2] = np.concatenate(z)[order]
+    radius = np.tile(np.float32([1.0, 1.0, 0.0, 1.0]), (M, 1))  # one pixel: every gaussian stays inside its tile
+    want_sorted, want_ranges, cap = orc.get_sorted_gaussian_list(uv, xyz, radius, ntx, nty)
+    assert list(np.diff(want_ranges)) == lengths
+    d_uv, d_xyz, d_r = _dev(torch, uv), _dev(torch, xyz), _dev(torch, radius)
+    count = ops.get_sorted_gaussian_list(d_uv, d_xyz, d_r, ntx, nty, M, 0, None, None)
+    assert count == cap
+    srt = torch.full((count,), -1, dtype=torch.int32, device="cuda")
+    ranges = torch.full((ntx * nty + 1,), -1, dtype=torch.int32, device="cuda")
+    ops.get_sorted_gaussian_list(d_uv, d_xyz, d_r, ntx, nty, M, count, srt, ranges)
+    assert (ranges.cpu().numpy() == want_ranges).all()
+    got = srt.cpu().numpy()[:len(want_sorted)]
+    for t in range(ntx):
+        a, b = want_ranges[t], want_ranges[t + 1]
+        assert (got[a:b] == want_sorted[a:b]).all(), f"tile {t} ({lengths[t]} entries)"
+
+
 def test_known_answer_binning(gpu):  # reference tests/cuda_forward_test.cpp:422-538
     torch, ops = gpu, pkg("ops")
     uv = _dev(torch, np.array([24, 24, 32, 24, 40, 40], np.float32))
