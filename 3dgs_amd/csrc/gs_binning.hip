@@ -376,6 +376,20 @@ __device__ __forceinline__ bool sort_run_in_registers(const unsigned long long *
   return true;
 }
 
+// one register-sorted run parked in LDS as payloads again; false: a key has no order-preserving double
+template <int E>
+__device__ __forceinline__ bool sort_run_to_lds(const unsigned long long *__restrict__ payload, int run_len, int lane,
+                                                unsigned long long *dst) {
+  double v[E];
+  if (!sort_run_in_registers<E>(payload, 0, run_len, lane, v)) return false;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int p = lane * E + e;
+    if (p < run_len) dst[p] = (unsigned long long)__double_as_longlong(v[e]) ^ 0x8000000000000000ull;
+  }
+  return true;
+}
+
 // false: the tile holds a key that has no order-preserving double (the caller hands the tile to the integer kernel)
 template <int E>
 __device__ __forceinline__ bool sort_tile_in_registers(const unsigned long long *__restrict__ payload, int start, int len,
@@ -457,18 +471,14 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
       __syncthreads();
       const int run_len = min(kWaveSortMax, len - wave * kWaveSortMax);
       if (len > kWaveSortMax && run_len > 0) {
-        constexpr int E = kWaveSortMax / 64;
-        double v[E];
-        if (sort_run_in_registers<E>(payload, start + wave * kWaveSortMax, run_len, lane, v)) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const int p = lane * E + e;
-            if (p < run_len)
-              buf[wave * kWaveSortMax + p] = (unsigned long long)__double_as_longlong(v[e]) ^ 0x8000000000000000ull;
-          }
-        } else if (lane == 0) {
-          s_runs_ok = 0;
-        }
+        // the last run of a list is shorter than the others: the smallest network that holds it
+        const unsigned long long *src = payload + start + wave * kWaveSortMax;
+        unsigned long long *dst = buf + wave * kWaveSortMax;
+        const bool ok = run_len <= 128   ? sort_run_to_lds<2>(src, run_len, lane, dst)
+                        : run_len <= 256 ? sort_run_to_lds<4>(src, run_len, lane, dst)
+                        : run_len <= 512 ? sort_run_to_lds<8>(src, run_len, lane, dst)
+                                         : sort_run_to_lds<kWaveSortMax / 64>(src, run_len, lane, dst);
+        if (!ok && lane == 0) s_runs_ok = 0;
       }
       __syncthreads();
       if (len > kWaveSortMax && s_runs_ok) {
