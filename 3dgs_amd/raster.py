@@ -34,6 +34,52 @@ def _view(ptr, shape, typestr, owner):
     return torch.as_tensor(_DevView(ptr, shape, typestr, owner), device="cuda")
 
 
+_EAGER_VIEWS = bool(int(__import__("os").environ.get("GSPLAT_EAGER_VIEWS", "0")))  # debugging: build every view at once
+
+
+class _LazyViews(dict):
+    """The forward's result: counts are plain entries, every array is turned into a tensor view the first time it is
+    asked for.  A view costs ~15 us of host time (torch queries the pointer), sixteen of them per call were most of the
+    host's work between the forward's record and the launch of whatever consumes the image -- and a training loop
+    reads two of them."""
+
+    def __init__(self, plain, specs, owner):
+        super().__init__(plain)
+        self._specs, self._owner = specs, owner
+
+    def __missing__(self, key):
+        ptr, shape, typestr = self._specs.pop(key)  # KeyError for unknown names, as a dict
+        value = _view(ptr, shape, typestr, self._owner)
+        self[key] = value
+        return value
+
+    def _all(self):
+        for key in list(self._specs):
+            self[key]
+        return self
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._specs
+
+    def __iter__(self):
+        return dict.__iter__(self._all())
+
+    def __len__(self):
+        return dict.__len__(self._all())
+
+    def keys(self):
+        return dict.keys(self._all())
+
+    def items(self):
+        return dict.items(self._all())
+
+    def values(self):
+        return dict.values(self._all())
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
 
@@ -138,20 +184,17 @@ class RasterContext:
         N, M, S = g.num_gaussians, int(fv.num_culled), int(fv.num_splats)
         W, H = c.width, c.height
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        o = self
-        out = dict(
-            num_culled=M, num_pairs=int(fv.num_pairs), num_splats=S,
-            mask=_view(fv.mask, (N,), "|u1", o), uv_all=_view(fv.uv, (N, 2), "<f4", o),
-            xyz_c_all=_view(fv.xyz_c, (N, 3), "<f4", o), compact_to_global=_view(fv.compact_to_global, (M,), "<i4", o),
-            sigma=_view(fv.sigma, (M, 6), "<f4", o), conic=_view(fv.conic, (M, 3), "<f4", o),
-            J=_view(fv.J, (M, 6), "<f4", o), rgb=_view(fv.precomputed_rgb, (M, 3), "<f4", o),
-            radius=_view(fv.radius, (M, 4), "<f4", o), uv=_view(fv.uv_selected, (M, 2), "<f4", o),
-            xyz_c=_view(fv.xyz_c_selected, (M, 3), "<f4", o), sorted=_view(fv.sorted_gaussians, (S,), "<i4", o),
-            ranges=_view(fv.splat_start_end_idx_by_tile_idx, (T + 1,), "<i4", o),
-            image=_view(fv.image, (H, W, 3), "<f4", o), T=_view(fv.weight_per_pixel, (H, W), "<f4", o),
-            n=_view(fv.splats_per_pixel, (H, W), "<i4", o))
+        out = _LazyViews(
+            dict(num_culled=M, num_pairs=int(fv.num_pairs), num_splats=S),
+            dict(mask=(fv.mask, (N,), "|u1"), uv_all=(fv.uv, (N, 2), "<f4"), xyz_c_all=(fv.xyz_c, (N, 3), "<f4"),
+                 compact_to_global=(fv.compact_to_global, (M,), "<i4"), sigma=(fv.sigma, (M, 6), "<f4"),
+                 conic=(fv.conic, (M, 3), "<f4"), J=(fv.J, (M, 6), "<f4"), rgb=(fv.precomputed_rgb, (M, 3), "<f4"),
+                 radius=(fv.radius, (M, 4), "<f4"), uv=(fv.uv_selected, (M, 2), "<f4"),
+                 xyz_c=(fv.xyz_c_selected, (M, 3), "<f4"), sorted=(fv.sorted_gaussians, (S,), "<i4"),
+                 ranges=(fv.splat_start_end_idx_by_tile_idx, (T + 1,), "<i4"), image=(fv.image, (H, W, 3), "<f4"),
+                 T=(fv.weight_per_pixel, (H, W), "<f4"), n=(fv.splats_per_pixel, (H, W), "<i4")), self)
         self._last = (g.num_gaussians, M, l_max)
-        return out
+        return out._all() if _EAGER_VIEWS else out
 
     def alloc_gradients(self, M, l_max, intermediates=False, device="cuda"):
         """Leaf gradients in compacted order; intermediates=True adds the reference's six intermediate gradient arrays
