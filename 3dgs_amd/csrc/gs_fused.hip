@@ -52,7 +52,7 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st,
-                      const unsigned short *masks_in);
+                      const unsigned short *masks_in, hipEvent_t ev_start, hipEvent_t ev_stop);
 }  // namespace gs
 
 struct gsplat_context {
@@ -1165,13 +1165,15 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
     c->mark(5, true, st);
   }
   c->rows_zeroed = false;
-  c->mark(6, false, st);
+  // stage 6 is this one launch: when it is timed, the launch itself stamps the two events (see launch_render_bwd)
+  const bool timed = (c->timing >> 6) & 1u;
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,
-                                 c->blockmasks.as<unsigned short>());
+                                 c->blockmasks.as<unsigned short>(), timed ? c->ev[c->slot][12] : nullptr,
+                                 timed ? c->ev[c->slot][13] : nullptr);
   if (rc) return rc;
-  c->mark(6, true, st);
+  if (timed) c->pending[c->slot][6] = 1;
   if (rgb_global) {
     scatter_rgb_rows_kernel<<<gs::div_up((long long)c->N * 3, kBlock), kBlock, 0, st>>>(
         c->mask.as<unsigned char>(), c->rank.as<int>(), c->N, c->grad_rows.as<float>(), rgb_global);

@@ -25,6 +25,7 @@
 //     nine lanes of one register), merged across the tile's blocks with ONE ds_add_f64 per trip, converted once per
 //     gaussian and flushed per batch to HBM as whole 64-byte gradient rows (or into the reference's four gradient
 //     arrays).
+#include <hip/hip_ext.h>
 #include "gs_common.h"
 #include "gs_render.h"
 
@@ -580,12 +581,19 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
 
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
-                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in) {
+                      float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in,
+                      hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   GradOut out = {rows, g_rgb, g_opacity, g_uv, g_conic};
-  if (recs && rows) {
+  if (recs && rows && ev_start && ev_stop) {
+    // timed launch (the context's per-stage timing): the events take the begin and end timestamps of THIS dispatch from
+    // its completion signal.  Two hipEventRecord calls around the launch are barrier packets of their own and kept the
+    // GPU idle for ~11 us before and ~6 us after the kernel in every step they were on.
+    hipExtLaunchKernelGGL((render_bwd_kernel<true, true, GS_BWD_BATCH>), grid, block, 0, st, ev_start, ev_stop, 0, recs, none,
+                          sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+  } else if (recs && rows) {
     render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   } else if (recs) {
     render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
@@ -640,7 +648,8 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
   gs::RawSplats raw = {uvs, opacity, conic, rgb};
   return gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, (hipStream_t)stream, nullptr);
+                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, (hipStream_t)stream, nullptr, nullptr,
+                               nullptr);
 }
 
 }  // extern "C"
