@@ -766,6 +766,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
     float u = 0.0f, v = 0.0f;
     unsigned long long pay = 0ull;
     bool big = false;
+    Obb bob = {};          // of a lane whose rectangle goes to the cooperative loop: its OBB ...
+    TileRect bsp = {0, 0, 0, 0};  // ... and the span of tiles to test
     if (j < hi) {
       rd = reinterpret_cast<const float4 *>(radius)[j];
       u = uv[2 * j]; v = uv[2 * j + 1];
@@ -784,21 +786,34 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
           }
         } else {
           big = true;
+          bob = make_obb(u, v, rd.x, rd.y, rd.z, rd.w);
+          bsp = obb_span(bob, r);
         }
       }
     }
+    // (the owner built its OBB and span once, with all the other large splats of the wave in the same instructions; the
+    // twelve numbers the tile test reads and the span reach the other lanes by v_readlane.  Every lane rebuilding them
+    // from six shuffled inputs cost ~150 instructions and seven LDS round trips per large splat.)
     for (unsigned long long todo = __ballot(big); todo != 0ull; todo &= todo - 1ull) {
       const int owner = __builtin_ctzll(todo);
-      const float ou = __shfl(u, owner, 64), ov = __shfl(v, owner, 64);
-      const float o0 = __shfl(rd.x, owner, 64), o1 = __shfl(rd.y, owner, 64), o2 = __shfl(rd.z, owner, 64), o3 = __shfl(rd.w, owner, 64);
-      const unsigned long long opay = __shfl(pay, owner, 64);
-      const TileRect r = coarse_rect(ou, ov, o0, ntx, nty);
-      const Obb ob = make_obb(ou, ov, o0, o1, o2, o3);
-      const TileRect sp = obb_span(ob, r);
-      const int sh = sp.y1 - sp.y0, total = (sp.x1 - sp.x0) * sh;
+      Obb ob;
+      ob.mnx = lane_value(bob.mnx, owner); ob.mxx = lane_value(bob.mxx, owner);
+      ob.mny = lane_value(bob.mny, owner); ob.mxy = lane_value(bob.mxy, owner);
+      ob.a2x = lane_value(bob.a2x, owner); ob.a2y = lane_value(bob.a2y, owner);
+      ob.mn2 = lane_value(bob.mn2, owner); ob.mx2 = lane_value(bob.mx2, owner);
+      ob.a3x = lane_value(bob.a3x, owner); ob.a3y = lane_value(bob.a3y, owner);
+      ob.mn3 = lane_value(bob.mn3, owner); ob.mx3 = lane_value(bob.mx3, owner);
+      const int x0 = lane_value(bsp.x0, owner), x1 = lane_value(bsp.x1, owner);
+      const int y0 = lane_value(bsp.y0, owner), y1 = lane_value(bsp.y1, owner);
+      const unsigned long long opay =
+          ((unsigned long long)(unsigned int)lane_value((int)(pay >> 32), owner) << 32) |
+          (unsigned long long)(unsigned int)lane_value((int)(pay & 0xFFFFFFFFull), owner);
+      const int sh = y1 - y0, total = (x1 - x0) * sh;
+      SpanWalk wk = span_walk(lane, max(sh, 1));
       for (int p = lane; p < total; p += 64) {
-        const int tx = sp.x0 + p / sh, ty = sp.y0 + p % sh;
+        const int tx = x0 + wk.col, ty = y0 + wk.row;
         if (obb_hits_tile(ob, tx, ty)) place(ty * ntx + tx, opay);
+        span_step(wk);
       }
     }
   }

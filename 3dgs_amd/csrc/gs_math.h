@@ -340,6 +340,35 @@ __device__ __forceinline__ TileRect obb_span(const Obb &o, const TileRect &r) {
   return s;
 }
 
+// A value of one lane, for a lane index that is uniform across the wave: v_readlane instead of a ds_bpermute round
+// trip through the LDS.
+__device__ __forceinline__ float lane_value(float x, int uniform_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), uniform_lane));
+}
+__device__ __forceinline__ int lane_value(int x, int uniform_lane) { return __builtin_amdgcn_readlane(x, uniform_lane); }
+
+// 64 lanes walking the tiles p = lane, lane + 64, ... of a span `sh` tiles high in column-major order (tile p is column
+// p / sh, row p % sh): the quotients come from two float divisions per walk and a carry per step instead of an integer
+// division per tile.  (lane / sh and 64 / sh are exact through IEEE float division: for integers a <= 64, sh <= 2^14
+// the quotient is either an integer or at least 1/sh away from one.)
+struct SpanWalk {
+  int col, row, dcol, drow, sh;
+};
+__device__ __forceinline__ SpanWalk span_walk(int lane, int sh) {
+  SpanWalk w;
+  w.sh = sh;
+  w.col = (int)((float)lane / (float)sh);
+  w.row = lane - w.col * sh;
+  w.dcol = (int)(64.0f / (float)sh);
+  w.drow = 64 - w.dcol * sh;
+  return w;
+}
+__device__ __forceinline__ void span_step(SpanWalk &w) {
+  w.col += w.dcol;
+  w.row += w.drow;
+  if (w.row >= w.sh) { w.row -= w.sh; ++w.col; }
+}
+
 // monotone map float -> uint32 (ascending float order == ascending unsigned order)
 __device__ __forceinline__ unsigned int float_sort_bits(float z) {
   const unsigned int b = __float_as_uint(z);
