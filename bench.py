@@ -228,23 +228,31 @@ def main():
     exchange_ms = {}
     ctx = raster.RasterContext(N, W, H)
     if world > 1 and do_bwd and want == "auto":
+        errors = {}
         for mode in ("full", "factored", "split"):
-            st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode, ctx=ctx)
-            for _ in range(3):
-                st.step(dc, dgi)
-            torch.cuda.synchronize()
-            dist.barrier()
-            ta = time.perf_counter()
-            for _ in range(10):
-                st.step(dc, dgi)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t = torch.tensor([(time.perf_counter() - ta) / 10 * 1e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            exchange_ms[mode] = round(float(t.item()), 4)
-            del st
+            try:  # a payload whose collectives this node's backend rejects is reported and left out, not fatal
+                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode, ctx=ctx)
+                for _ in range(3):
+                    st.step(dc, dgi)
+                torch.cuda.synchronize()
+                dist.barrier()
+                ta = time.perf_counter()
+                for _ in range(10):
+                    st.step(dc, dgi)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t = torch.tensor([(time.perf_counter() - ta) / 10 * 1e3], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exchange_ms[mode] = round(float(t.item()), 4)
+            except Exception as e:  # noqa: BLE001 -- whatever the backend raises
+                errors[mode] = f"{type(e).__name__}: {e}"[:200]
+                print(f"bench.py: exchange payload '{mode}' failed on rank {rank}: {errors[mode]}", file=sys.stderr, flush=True)
+            st = None
             torch.cuda.empty_cache()
+        if not exchange_ms:
+            raise RuntimeError(f"no exchange payload works on this node: {errors}")
         want = min(exchange_ms, key=exchange_ms.get)  # the same on every rank: the times were MAX-reduced
+        exchange_ms.update({m: "failed: " + msg for m, msg in errors.items()})
     step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want if want != "auto" else "split", ctx=ctx)
 
     def one_step():
