@@ -20,15 +20,40 @@ class GsplatError(RuntimeError):
 
 
 def build(force=False):
-    """Compile every HIP source for gfx950 with hipcc (works without a GPU)."""
+    """Compile every HIP source for gfx950 with hipcc (works without a GPU).  Serialised across processes by a file
+    lock: N ranks importing the package at once (bench.py's children, torchrun, pytest-xdist) would otherwise run
+    `make` in the same directory together, and one could dlopen a half-linked library."""
+    import fcntl
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(_CSRC, "host", "gs_dataset.cpp"))
     srcs.append(os.path.join(_HERE, "..", "include", "gsplat_hip.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if stale:
-        subprocess.check_call(["make", "-C", _CSRC, "-j", "5", "-s"] + (["-B"] if force else []))
+
+    def stale():
+        return force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+
+    if stale():
+        with open(os.path.join(_CSRC, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():  # another process may have built it while this one waited
+                    subprocess.check_call(["make", "-C", _CSRC, "-j", "5", "-s"] + (["-B"] if force else []))
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the device sources the library is built from: ties a stored profile
+    (profiles/traffic.json) to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(_CSRC)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode())
+            with open(os.path.join(_CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -144,12 +169,21 @@ def load():
         return _lib
     path = os.environ.get("GSPLAT_LIB")  # tooling (tools/ab, diagnostic builds): load exactly this prebuilt variant
     if not path:
-        # cheap when the library is fresh (mtime scan); on a box without hipcc a prebuilt, up-to-date library is used as is
-        try:
-            build()
-        except (OSError, subprocess.CalledProcessError):
+        # GSPLAT_NO_BUILD=1: load the library as it is (rank processes whose launcher has already built it; runs under
+        # rocprofv3, where this process has an initialised GPU and must not spawn compilers).  Otherwise build(): cheap
+        # when the library is fresh (mtime scan).
+        if os.environ.get("GSPLAT_NO_BUILD") == "1":
             if not os.path.exists(LIB_PATH):
-                raise
+                raise OSError(f"{LIB_PATH} is missing and GSPLAT_NO_BUILD=1 forbids building it")
+        else:
+            try:
+                build()
+            except (OSError, subprocess.CalledProcessError) as e:
+                if not os.path.exists(LIB_PATH):
+                    raise
+                import sys
+                print(f"[3dgs_amd] WARNING: rebuilding libgsplat_hip.so failed ({e}); loading the EXISTING library, "
+                      "which may be older than the sources (the ABI version is checked below)", file=sys.stderr, flush=True)
         path = LIB_PATH
     # torch owns device memory and ships its own HIP runtime: import it first so that this library binds to the
     # same runtime instance (two runtimes in one process do not see each other's allocations)

@@ -923,6 +923,7 @@ extern "C" int gsplat_get_sorted_gaussian_list(const float *uv, const float *xyz
   GS_REQUIRE(((uintptr_t)radius & 15) == 0, "radius must be 16-byte aligned (float4)");
   hipStream_t st = (hipStream_t)stream;
   const int num_tiles = n_tiles_x * n_tiles_y;
+  ScratchLock lock;  // library scratch and the pinned count words are process-wide
   int rc = host_words().ensure();
   if (rc) return rc;
   DeviceBuffer &misc = scratch(SCR_MISC);

@@ -84,6 +84,7 @@ static inline unsigned int div_up(long long a, long long b) { return (unsigned i
 struct DeviceBuffer {
   void *ptr = nullptr;
   size_t bytes = 0;
+  unsigned long long generation = 0;  // bumped by every allocation and release: state cached about the CONTENTS keys on it
   int reserve(size_t want);
   void release();
   template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
@@ -97,6 +98,15 @@ enum ScratchSlot {
   SCR_NUM
 };
 DeviceBuffer &scratch(ScratchSlot slot);
+// The scratch slots are process-wide: entry points that a multi-threaded host may call concurrently (the loss of a
+// training loop with several in-process ranks) hold this lock from their first scratch access to their last launch /
+// read-back.  Recursive, so that helpers may take it again.
+struct ScratchLock {
+  ScratchLock();
+  ~ScratchLock();
+  ScratchLock(const ScratchLock &) = delete;
+  ScratchLock &operator=(const ScratchLock &) = delete;
+};
 
 // pinned host words for count read-backs
 struct HostWords {

@@ -1,6 +1,8 @@
 // gs_common.hip -- status/error text, device-pointer validation, scratch arena.
 #include "gs_common.h"
 
+#include <mutex>
+
 namespace gs {
 
 static thread_local char g_err[512] = "";
@@ -41,6 +43,7 @@ int DeviceBuffer::reserve(size_t want) {
     ptr = nullptr;
     bytes = 0;
   }
+  ++generation;
   hipError_t e = hipMalloc(&ptr, grow);
   if (e != hipSuccess) {
     ptr = nullptr;
@@ -55,10 +58,14 @@ void DeviceBuffer::release() {
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr;
   bytes = 0;
+  ++generation;
 }
 
 static DeviceBuffer g_scratch[SCR_NUM];
 DeviceBuffer &scratch(ScratchSlot slot) { return g_scratch[slot]; }
+static std::recursive_mutex g_scratch_mutex;
+ScratchLock::ScratchLock() { g_scratch_mutex.lock(); }
+ScratchLock::~ScratchLock() { g_scratch_mutex.unlock(); }
 
 static HostWords g_words;
 int HostWords::ensure() {
@@ -75,6 +82,7 @@ extern "C" {
 const char *gsplat_last_error(void) { return gs::g_err; }
 int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
 int gsplat_release_scratch(void) {
+  gs::ScratchLock lock;
   (void)hipDeviceSynchronize();
   for (int i = 0; i < gs::SCR_NUM; ++i) gs::g_scratch[i].release();
   return GSPLAT_OK;

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__res
   }
 }
 
-int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
+int reserve_instances(gsplat_context *c, size_t S, int num_tiles, hipStream_t st) {
   int rc;
   const void *pay_before = c->pay_a.ptr, *sorted_before = c->sorted.ptr;
   if ((rc = c->keys_a.reserve((S + 1) * sizeof(unsigned int)))) return rc;
@@ -767,8 +767,10 @@ int reserve_instances(gsplat_context *c, size_t S, int num_tiles) {
   // Fresh instance buffers start as zeros.  The sparse forward queues its sorts and render_fwd before the host has
   // seen S; when S outgrows the room those kernels run on truncated lists whose slots may not have been written by
   // this forward -- whatever they hold must still be a valid gaussian id (0, or one of an earlier forward).
-  if (c->pay_a.ptr != pay_before) GS_HIP(hipMemset(c->pay_a.ptr, 0, c->pay_a.bytes));
-  if (c->sorted.ptr != sorted_before) GS_HIP(hipMemset(c->sorted.ptr, 0, c->sorted.bytes));
+  // The fill goes on the CALLER's stream: on the NULL stream nothing would order it against the placement and the sorts
+  // that a non-blocking stream (a torch side stream) runs right behind it, and the zeros could land on top of them.
+  if (c->pay_a.ptr != pay_before) GS_HIP(hipMemsetAsync(c->pay_a.ptr, 0, c->pay_a.bytes, st));
+  if (c->sorted.ptr != sorted_before) GS_HIP(hipMemsetAsync(c->sorted.ptr, 0, c->sorted.bytes, st));
   if ((rc = c->blockmasks.reserve((S + 1) * sizeof(unsigned short)))) return rc;
   if ((rc = c->temp.reserve(gs::binning_temp_bytes((size_t)c->max_gaussians, S ? S : 1, num_tiles)))) return rc;
   return GSPLAT_OK;
@@ -893,7 +895,11 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
     const size_t sb2 = gs::binning_temp_bytes(N, 4 * N, (int)T);
     rc = c->temp.reserve(sb1 > sb2 ? sb1 : sb2);
   }
-  if (!rc) rc = reserve_instances(c, 4 * N, (int)T);
+  if (!rc) rc = reserve_instances(c, 4 * N, (int)T, (hipStream_t)0);
+  if (!rc && hipStreamSynchronize((hipStream_t)0) != hipSuccess) {  // the fills above: done before any stream uses the context
+    gs::set_error("gsplat_context_create: hipStreamSynchronize failed");
+    rc = GSPLAT_ERR_HIP;
+  }
   if (!rc) {
     void *h = nullptr, *d = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -1003,7 +1009,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       return std::min(std::min(c->pay_a.bytes / sizeof(unsigned long long), c->sorted.bytes / sizeof(int)),
                       std::min(c->blockmasks.bytes / sizeof(unsigned short), c->keys_a.bytes / sizeof(unsigned int)));
     };
-    if (room_of() < 2 && (rc = reserve_instances(c, 4 * (size_t)N, num_tiles))) return rc;
+    if (room_of() < 2 && (rc = reserve_instances(c, 4 * (size_t)N, num_tiles, st))) return rc;
     spec_cap = room_of() - 1;
     c->mark(1, true, st);
     c->mark(2, false, st);
@@ -1107,13 +1113,13 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     const bool fits = S <= spec_cap;
     if (!fits || !(spec_hint < 0 || list_class(longest) <= list_class(spec_hint))) {
       // grow (synchronises); the placement queued below writes the true ranges
-      if (!fits && (rc = reserve_instances(c, S + S / 4, num_tiles))) return rc;
+      if (!fits && (rc = reserve_instances(c, S + S / 4, num_tiles, st))) return rc;
       // the long-tile counter lives at the head of keys_a: zeroed by bin_offsets, then used by the queued sorts
       GS_HIP(hipMemsetAsync(c->keys_a.ptr, 0, sizeof(int), st));
       if ((rc = queue_tail(S, longest, false))) return rc;
     }
   } else {
-    if ((rc = reserve_instances(c, S, num_tiles))) return rc;
+    if ((rc = reserve_instances(c, S, num_tiles, st))) return rc;
     rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                               c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
                               c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),

@@ -228,6 +228,7 @@ int gsplat_knn_mean_distance(const double *points_xyz, int N, int k, float *mean
   GS_REQUIRE_DEV(points_xyz); GS_REQUIRE_DEV(mean_dist);
   hipStream_t st = (hipStream_t)stream;
   const int want = k + 1;
+  gs::ScratchLock lock;  // library scratch and the pinned count words are process-wide
   int rc = gs::host_words().ensure();
   if (rc) return rc;
   gs::DeviceBuffer &misc = gs::scratch(gs::SCR_MISC);
@@ -283,6 +284,7 @@ int gsplat_initialize_gaussians(const double *points_xyz, const unsigned char *p
   if (N == 0) return GSPLAT_OK;
   GS_REQUIRE_DEV(points_xyz); GS_REQUIRE_DEV(points_rgb); GS_REQUIRE_DEV(xyz); GS_REQUIRE_DEV(rgb);
   GS_REQUIRE_DEV(opacity); GS_REQUIRE_DEV(scale); GS_REQUIRE_DEV(quaternion);
+  gs::ScratchLock lock;
   gs::DeviceBuffer &md = gs::scratch(gs::SCR_LOSS_MU);  // N mean distances
   int rc = md.reserve((size_t)N * sizeof(float));
   if (rc) return rc;

@@ -443,6 +443,7 @@ int gsplat_fused_loss(const float *predicted_data, const float *gt_data, int row
   GS_REQUIRE(rows > 0 && cols > 0, "image size must be positive");
   hipStream_t st = (hipStream_t)stream;
   const size_t bytes = (size_t)rows * cols * 3 * sizeof(float);
+  gs::ScratchLock lock;  // scratch and the counters' state are process-wide; held through the read-back
   gs::DeviceBuffer &mu = gs::scratch(gs::SCR_LOSS_MU), &s1 = gs::scratch(gs::SCR_LOSS_S1),
                    &s12 = gs::scratch(gs::SCR_LOSS_S12), &acc = gs::scratch(gs::SCR_LOSS_ACC);
   int rc;
@@ -450,17 +451,19 @@ int gsplat_fused_loss(const float *predicted_data, const float *gt_data, int row
       (rc = acc.reserve(3 * kSpread * sizeof(float))))
     return rc;
   // the spread counters alternate between two sets: the backward kernel of one call clears the set of the next, which
-  // saves a memset launch per training iteration (the first set of the buffer belongs to gsplat_compute_psnr)
-  static int flip = 0;
-  static bool primed = false;
-  static hipStream_t primed_stream = nullptr;
-  static void *primed_ptr = nullptr;
-  if (!primed || primed_stream != st || primed_ptr != acc.ptr) {
+  // saves a memset launch per training iteration (the first set of the buffer belongs to gsplat_compute_psnr).  What is
+  // known about the counters' contents lives in `primed`: it names the stream and the allocation (generation: a
+  // released and re-reserved buffer may come back at the same address) the last call left them clean on, and it is
+  // void while a call is between its two launches -- a call that errors out in between leaves the next one to clear.
+  struct Primed { bool ok = false; hipStream_t stream = nullptr; void *ptr = nullptr; unsigned long long gen = 0; int flip = 0; };
+  static Primed primed;
+  if (!primed.ok || primed.stream != st || primed.ptr != acc.ptr || primed.gen != acc.generation) {
     GS_HIP(hipMemsetAsync(acc.as<float>() + kSpread, 0, 2 * kSpread * sizeof(float), st));
-    primed = true; primed_stream = st; primed_ptr = acc.ptr;
+    primed.stream = st; primed.ptr = acc.ptr; primed.gen = acc.generation; primed.flip = 0;
   }
+  primed.ok = false;
+  const int flip = primed.flip;
   float *cur = acc.as<float>() + (1 + flip) * kSpread, *next = acc.as<float>() + (2 - flip) * kSpread;
-  flip ^= 1;
   const int ntx = (cols + kTW - 1) / kTW, nty = (rows + kTH - 1) / kTH;
   const dim3 grid((unsigned)(((ntx * nty + 7) / 8) * 8)), block(256);  // whole rounds of the eight XCDs: tile_of()
   loss_forward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data, cur,
@@ -469,6 +472,8 @@ int gsplat_fused_loss(const float *predicted_data, const float *gt_data, int row
   loss_backward_kernel<<<grid, block, 0, st>>>(rows, cols, ntx, nty, ssim_weight, predicted_data, gt_data,
                                                mu.as<float>(), s1.as<float>(), s12.as<float>(), image_grad, next);
   GS_LAUNCH_CHECK();
+  primed.flip = flip ^ 1;
+  primed.ok = true;  // both launches are queued: `next` will be clean for the next call on this stream
   if (loss_out) {  // the reference returns the value, i.e. blocks (cuda/loss.cu:468-470)
     double total;
     if ((rc = read_spread_sum(cur, st, &total))) return rc;
@@ -483,6 +488,7 @@ int gsplat_compute_psnr(const float *predicted_data, const float *gt_data, int r
   GS_REQUIRE(psnr_out != nullptr, "psnr_out is null");
   GS_REQUIRE(rows > 0 && cols > 0, "image size must be positive");
   hipStream_t st = (hipStream_t)stream;
+  gs::ScratchLock lock;
   gs::DeviceBuffer &acc = gs::scratch(gs::SCR_LOSS_ACC);
   int rc = acc.reserve(3 * kSpread * sizeof(float));  // [0, kSpread): this function's; the rest: gsplat_fused_loss
   if (rc) return rc;

@@ -393,6 +393,7 @@ int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int
   if (N == 0) return GSPLAT_OK;  // empty input is legal (tests/cuda_data_test.cpp CompactMaskedArrayEmpty)
   GS_REQUIRE_DEV(src); GS_REQUIRE_DEV(mask); GS_REQUIRE_DEV(dst);
   hipStream_t st = (hipStream_t)stream;
+  gs::ScratchLock lock;  // library scratch and the pinned count words are process-wide
   gs::DeviceBuffer &ranks = gs::scratch(gs::SCR_OFFSETS);
   int rc = ranks.reserve((size_t)(N + 1) * sizeof(int));
   if (rc) return rc;
@@ -417,6 +418,7 @@ int gsplat_scatter_masked_array(const float *src, const unsigned char *mask, int
   if (src == nullptr) return GSPLAT_OK;  // nothing selected (cuda_data.cuh:154-157)
   GS_REQUIRE_DEV(src);
   hipStream_t st = (hipStream_t)stream;
+  gs::ScratchLock lock;  // library scratch and the pinned count words are process-wide
   gs::DeviceBuffer &ranks = gs::scratch(gs::SCR_OFFSETS);
   int rc = ranks.reserve((size_t)(N + 1) * sizeof(int));
   if (rc) return rc;

@@ -515,9 +515,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const float sxy = (float)(X * (Y * S1 - Sy) - Y * Sx + acc[7]);                // sum gp dx dy
       const float syy = (float)(Y * (Y * S1 - 2.0 * Sy) + acc[8]);                   // sum gp dy^2
       const float ca = a.z * kConicDiag, cb = a.w * kConicOff, cc = b.x * kConicDiag;
-      // cuda/render_backward.cu:170 gates on any(d/d logit != 0), d/d logit = gp * (1 - opa): a fully opaque
-      // gaussian (sigmoid(opacity) == 1) gets no gradient at all
-      const float keep = opa == 1.0f ? 0.0f : 1.0f;
+      // cuda/render_backward.cu:170 gates ALL nine adds on any(d/d logit != 0), d/d logit = sum gp * (1 - opa) per
+      // thread: a fully opaque gaussian (sigmoid(opacity) == 1) gets no gradient at all, and neither does one whose gp
+      // is zero on every pixel of the tile (d/d alpha exactly 0: e.g. a zero pixel gradient, or a colour equal to the
+      // colour behind it over a zero background) -- its colour sums may be non-zero and are dropped with the rest.
+      // "gp zero everywhere" is read off the six moments (sums of zeros are exact zeros; non-zero gp that cancel in all
+      // six at once do not occur).
+      const bool any_gp = (S1 != 0.0) | (Sx != 0.0) | (Sy != 0.0) | (acc[6] != 0.0) | (acc[7] != 0.0) | (acc[8] != 0.0);
+      const float keep = (opa == 1.0f || !any_gp) ? 0.0f : 1.0f;
       float *res = &s_res[t * 9];
       res[0] = keep * (float)acc[0];
       res[1] = keep * (float)acc[1];

@@ -42,19 +42,145 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+class _Done:
+    """Handle of a collective that has already been issued in stream order."""
+
+    def wait(self):
+        return True
+
+
+class TorchComm:
+    """The exchange's collectives on torch.distributed's default group (RCCL over xGMI on the GPUs, gloo in the CPU
+    tests and the one-GPU rehearsals); a single process is a group of one."""
+
+    def __init__(self):
+        on = dist.is_initialized()
+        self.world = dist.get_world_size() if on else 1
+        self.rank = dist.get_rank() if on else 0
+
+    def all_reduce(self, t, async_op=False):
+        if self.world == 1:
+            return _Done()
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op) or _Done()
+
+    def all_gather_blocks(self, out, block, async_op=False):
+        """out[world, ...] <- every rank's `block`.  One collective; RCCL/NCCL gathers straight into the contiguous
+        buffer, gloo (CPU tests, single-GPU rehearsal) takes the list form."""
+        if self.world == 1:
+            out[0].copy_(block)
+            return _Done()
+        if dist.get_backend() == "nccl":
+            return dist.all_gather_into_tensor(out, block, async_op=async_op) or _Done()
+        return dist.all_gather(list(out.unbind(0)), block, async_op=async_op) or _Done()
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def all_reduce_max(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
+    def backend(self):
+        return dist.get_backend() if self.world > 1 else "none"
+
+
+class ThreadGroup:
+    """W ranks as W THREADS of one process sharing one GPU: the rehearsal of rank counts that cannot be started as
+    processes on a one-GPU box (the pool admits six GPU processes per box; the 8-rank shape of BASELINE config 5 is
+    eight).  Every rank-thread owns its RasterContext, its parameter replica and its exchange buffers exactly as a
+    rank process does; only the collectives differ: a rendezvous on a threading.Barrier, the reduction done once in
+    rank order and copied to every rank (what a ring all-reduce also guarantees: bitwise the same sums everywhere).
+    All threads issue on the device's default stream, so GPU order = host issue order and the barriers order it."""
+
+    def __init__(self, world):
+        import threading
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+        self._result = None
+
+    def comm(self, rank):
+        return ThreadComm(self, rank)
+
+    def run(self, fn):
+        """fn(comm) on every rank-thread; returns the list of results, re-raises the first failure (the barrier is
+        broken so that the other ranks do not wait for a rank that died)."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                out[r] = fn(self.comm(r))
+            except BaseException as e:  # noqa: BLE001
+                err[r] = e
+                self._barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,), name=f"rank{r}") for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        failed = [e for e in err if e is not None]
+        if failed:  # the rank that really failed, not the ranks its broken barrier released
+            raise ([e for e in failed if not isinstance(e, threading.BrokenBarrierError)] or failed)[0]
+        return out
+
+
+class ThreadComm:
+    def __init__(self, group, rank):
+        self.group, self.rank, self.world = group, int(rank), group.world
+
+    def all_reduce(self, t, async_op=False):
+        g = self.group
+        g._slots[self.rank] = t
+        g._barrier.wait()                 # every rank's producers are queued on the stream
+        if self.rank == 0:
+            acc = g._slots[0].clone()
+            for r in range(1, self.world):
+                acc += g._slots[r]        # rank order: one well-defined sum
+            g._result = acc
+        g._barrier.wait()
+        t.copy_(g._result)
+        g._barrier.wait()                 # everyone has queued its copy before the next collective replaces _result
+        return _Done()
+
+    def all_gather_blocks(self, out, block, async_op=False):
+        g = self.group
+        g._slots[self.rank] = block
+        g._barrier.wait()
+        for r in range(self.world):
+            out[r].copy_(g._slots[r])
+        g._barrier.wait()
+        return _Done()
+
+    def barrier(self):
+        self.group._barrier.wait()
+
+    def all_reduce_max(self, t):
+        g = self.group
+        g._slots[self.rank] = t
+        g._barrier.wait()
+        if self.rank == 0:
+            g._result = torch.stack([x.to(g._slots[0].device) for x in g._slots]).amax(0)
+        g._barrier.wait()
+        t.copy_(g._result)
+        g._barrier.wait()
+        return t
+
+    def backend(self):
+        return "threads"
+
+
 def all_reduce_gradients(packed):
     """Sum the packed per-gaussian gradient rows over all ranks, in place (no-op for a single process)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    TorchComm().all_reduce(packed)
     return packed
 
 
 def all_gather_blocks(out, block, async_op=False):
-    """out[world, ...] <- every rank's `block`.  One collective; RCCL/NCCL gathers straight into the contiguous
-    buffer, gloo (CPU tests, single-GPU rehearsal) takes the list form."""
-    if dist.get_backend() == "nccl":
-        return dist.all_gather_into_tensor(out, block, async_op=async_op)
-    return dist.all_gather(list(out.unbind(0)), block, async_op=async_op)
+    return TorchComm().all_gather_blocks(out, block, async_op=async_op)
 
 
 def unpack(packed, l_max):
@@ -86,7 +212,8 @@ class ViewShardedStep:
     no extra launch on the wire.
     """
 
-    def __init__(self, params, l_max, width, height, config, bg, exchange="split", with_uv_norm=False, ctx=None):
+    def __init__(self, params, l_max, width, height, config, bg, exchange="split", with_uv_norm=False, ctx=None,
+                 comm=None):
         from . import raster
         self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
@@ -94,8 +221,8 @@ class ViewShardedStep:
         self.ctx = ctx if ctx is not None else raster.RasterContext(N, width, height)
         self.width_cols = wc = raster.packed_gradient_width(l_max)
         dev = params["xyz"].device
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.comm = comm if comm is not None else TorchComm()  # ThreadComm: in-process ranks (ThreadGroup)
+        self.world, self.rank = self.comm.world, self.comm.rank
         if exchange not in ("split", "factored", "full"):
             raise ValueError(f"unknown exchange {exchange!r}")
         self.exchange = exchange
@@ -151,14 +278,14 @@ class ViewShardedStep:
                 if gather is None:
                     self.rgb[:N].zero_()
                     self._set_campos(cam)
-                    gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+                    gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
             elif gather is None:
                 self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, self.rgb)
                 self._set_campos(cam)
-                gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+                gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
             else:
                 self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, None)
-            reduce = dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM, async_op=True)
+            reduce = self.comm.all_reduce(self._reduce_buf, async_op=True)
             # the SH columns only need the gathered g_rgb: rebuild them while the all-reduce is in flight
             gather.wait()
             self.raster.unpack_gradients_split(self.params["xyz"], None, self.rgb_all, 3 * (N + 1), self.l_max,
@@ -171,13 +298,13 @@ class ViewShardedStep:
                 self.raster.pack_gradients_factored(self.ctx, self.grads, N, self.rank, self.world, f)
             f[N].zero_()
             f[N, 12 + 3 * self.rank: 15 + 3 * self.rank] = self._campos_tensor(cam)
-            all_reduce_gradients(self._reduce_buf)
+            self.comm.all_reduce(self._reduce_buf)
             self.raster.unpack_gradients_factored(self.params["xyz"], f[N, 12:], f, self.l_max, N,
                                                   self.world, self.packed)
         else:
             if not self._blind:
                 self.ctx.pack_gradients_global(self.grads, self.l_max, N, self.packed)
-            all_reduce_gradients(self._reduce_buf)
+            self.comm.all_reduce(self._reduce_buf)
         return self.packed
 
     def _campos_tensor(self, cam):
@@ -212,7 +339,7 @@ class ViewShardedStep:
             if overlap:
                 # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
                 self.ctx.backward_render(grad_image, bg, self.rgb)
-                self._rgb_gather = all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+                self._rgb_gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
                 self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
             else:
                 self.ctx.backward_pass(self.params, cam, grad_image, bg, self.l_max, self.grads)

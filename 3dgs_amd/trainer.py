@@ -14,10 +14,9 @@ import os
 
 import numpy as np
 import torch
-import torch.distributed as tdist
 
 from . import ops, raster
-from .dist import ViewShardedStep
+from .dist import TorchComm, ViewShardedStep
 from .optimizer import AdamOptimizer, DEFAULT_LR
 
 GROUPS = ("xyz", "rgb", "sh", "opacity", "scale", "quaternion")
@@ -50,7 +49,7 @@ class Trainer:
     """params: dict of device tensors (xyz rgb opacity scale quaternion, optionally sh) as gsplat_initialize_gaussians
     returns them; views: list of (camera dict for raster.device_camera, ground-truth image tensor [H,W,3] on device)."""
 
-    def __init__(self, params, views, config=None, scene_extent=1.0, seed=0, exchange="split"):
+    def __init__(self, params, views, config=None, scene_extent=1.0, seed=0, exchange="split", comm=None):
         """With an initialised torch.distributed group of W > 1 ranks the loop is view-sharded: every
         rank holds the same parameters and the same seed, one iteration = W training views (rank r takes the r-th of
         the iteration's W draws), the per-gaussian gradients and |grad_uv| are summed over the ranks
@@ -58,8 +57,9 @@ class Trainer:
         replicas stay bit-identical without ever exchanging parameters."""
         self.cfg = dict(DEFAULT_CONFIG, **(config or {}))
         self.views = views
-        self.world = tdist.get_world_size() if tdist.is_initialized() else 1
-        self.rank = tdist.get_rank() if tdist.is_initialized() else 0
+        # the ranks of the group: torch.distributed's default group, or in-process rank threads (dist.ThreadGroup)
+        self.comm = comm if comm is not None else TorchComm()
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.exchange = exchange
         self._sharded = None  # (key, ViewShardedStep) for the current gaussian count / SH degree
         self._grad_image = {}  # (H, W) -> dL/dimage buffer, allocated once per image size
@@ -159,7 +159,7 @@ class Trainer:
             ctx = self._context_for(n)
             p = dict(self.params)
             self._sharded = (key, ViewShardedStep(p, self.l_max, ctx.max_width, ctx.max_height, c, 0.0,
-                                                  exchange=self.exchange, with_uv_norm=True, ctx=ctx))
+                                                  exchange=self.exchange, with_uv_norm=True, ctx=ctx, comm=self.comm))
         step = self._sharded[1]
         H, W = int(cam["height"]), int(cam["width"])
         out = {}

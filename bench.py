@@ -46,37 +46,93 @@ def parse_args():
 
 # ------------------------------------------------------------------------------------------------ launcher
 def launch_ranks(args):
-    """Parent of a multi-GPU run: never imports torch, never touches a GPU.  Starts one child per rank with the
-    torch.distributed environment, forwards rank 0's JSON line, fails if any rank fails."""
+    """Parent of a multi-GPU run: never imports torch, never touches a GPU.  Builds the library ONCE (the children load
+    it with GSPLAT_NO_BUILD=1: N ranks running `make` in one directory at the same time could dlopen a half-linked
+    file), starts one child per rank with the torch.distributed environment, forwards rank 0's JSON line.  All children
+    are polled under ONE overall deadline (GSPLAT_BENCH_DEADLINE_S, default 1500 s); the first child that exits
+    non-zero, or the deadline, ends the run: the remaining children are killed (these exact processes) and the launcher
+    returns 1, so that a rank stuck in a collective its peers never joined cannot hold the GPUs."""
+    import tempfile
     n = args.gpus
+    importlib.import_module("3dgs_amd._lib").build()  # make only: no torch, no GPU in this process
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_NO_BUILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
-    out0 = procs[0].communicate()[0] or ""
-    codes = []
-    deadline = time.time() + 120  # the ranks leave together (final barrier); a straggler means a failure
-    for p in procs:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()  # this exact child
-            codes.append(-9)
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else None, text=True))
+    deadline = time.time() + float(os.environ.get("GSPLAT_BENCH_DEADLINE_S", "1500"))
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = f"rank(s) {bad} failed" if bad else "deadline passed"
+            grace = time.time() + (3.0 if bad else 0.0)  # ranks that fail for the same reason report it themselves
+            for r, p in enumerate(procs):  # these exact children
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=max(0.0, grace - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    text = out0.read()
+    out0.close()
+    sys.stdout.write(text)
     sys.stdout.flush()
-    if any(c != 0 for c in codes):
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    if failed or any(c != 0 for c in codes):
+        print(f"bench.py: {failed or 'a rank failed'}; rank exit codes {codes}", file=sys.stderr)
         return 1
-    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    line = [ln for ln in text.splitlines() if ln.startswith("{")]
     if not line or json.loads(line[-1]).get("n_gpus") != n:
         print(f"bench.py: rank 0 did not report n_gpus={n}", file=sys.stderr)
         return 1
     return 0
+
+
+def agree_on_payload(comm, mode, ok, timeout_s=120.0):
+    """Every rank reports through the group's key-value store (NOT a collective) whether payload `mode` worked for it,
+    and reads all reports.  True: worked everywhere; False: failed everywhere (the mode is dropped on every rank).
+    A mixed outcome, or a rank that never reports because it is still inside a collective the failing rank left, is
+    fatal: after an asymmetric failure the ranks' collectives no longer pair up, so the run exits non-zero (the
+    launcher / torchrun then ends the other ranks) instead of limping on with mismatched collectives."""
+    rank, world = comm.rank, comm.world
+    if comm.backend() == "threads":  # in-process ranks: a shared table; a rank that died has broken the barrier
+        votes = comm.group.__dict__.setdefault("_votes", {})
+        votes[(mode, rank)] = ok
+        comm.barrier()
+        got = [votes[(mode, r)] for r in range(world)]
+        if all(got) or not any(got):
+            return all(got)
+        raise RuntimeError(f"payload '{mode}' failed on some ranks only: {got}")
+    from datetime import timedelta
+    from torch.distributed.distributed_c10d import _get_default_store
+    store = _get_default_store()
+    store.set(f"gsplat/exchange/{mode}/{rank}", "ok" if ok else "fail")
+    keys = [f"gsplat/exchange/{mode}/{r}" for r in range(world)]
+    try:
+        store.wait(keys, timedelta(seconds=timeout_s))
+    except Exception as e:  # noqa: BLE001 -- a peer never reported
+        print(f"bench.py: rank {rank}: payload '{mode}': a peer did not report within {timeout_s:.0f} s ({e}); "
+              "asymmetric failure, giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+    votes = [store.get(k).decode() for k in keys]
+    if all(v == "ok" for v in votes):
+        return True
+    if all(v == "fail" for v in votes):
+        return False
+    print(f"bench.py: rank {rank}: payload '{mode}' failed on some ranks only ({votes}); giving up", file=sys.stderr, flush=True)
+    os._exit(3)
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -184,30 +240,49 @@ def cpu_baseline(scene, args, params, cam, gi, cfg, N, W, H, L, do_bwd):
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
-    if args.gpus > 1 and env_world is None:
+    threads = os.environ.get("GSPLAT_BENCH_THREAD_RANKS") == "1" and args.gpus > 1 and env_world is None
+    if args.gpus > 1 and env_world is None and not threads:
         sys.exit(launch_ranks(args))
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}")
+    hang = os.environ.get("GSPLAT_BENCH_SELFTEST", "")  # tests/test_bench_cpu.py: a rank that never returns
+    if hang.startswith("hang:") and hang[5:] in ("all", os.environ.get("RANK", "0")):
+        time.sleep(3600)
 
+    import torch
+    gdist = importlib.import_module("3dgs_amd.dist")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if threads:
+        # GSPLAT_BENCH_THREAD_RANKS=1: the N ranks are THREADS of this process on one GPU (dist.ThreadGroup): a rehearsal
+        # of rank counts a one-GPU box cannot hold as processes (its process guard admits six; config 5 has eight
+        # ranks).  Same code per rank, collectives by rendezvous; the times say nothing about a multi-GPU node.
+        importlib.import_module("3dgs_amd._lib").load()
+        gdist.ThreadGroup(args.gpus).run(lambda comm: run_rank(args, comm, 0))
+        return
+    rank, world, local_rank = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
+    comm = gdist.TorchComm()
+    ndev = torch.cuda.device_count()
+    if world > 1 and comm.backend() == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {ndev} "
+                         f"(GSPLAT_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
+    run_rank(args, comm, local_rank % ndev if world > 1 else 0)
+    if world > 1:
+        comm.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def run_rank(args, comm, device_index):
     import numpy as np  # noqa: F401
     import torch
     scene = importlib.import_module("3dgs_amd.scene")
     raster = importlib.import_module("3dgs_amd.raster")
     gdist = importlib.import_module("3dgs_amd.dist")
-    import torch.distributed as dist
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    rank, world, local_rank = gdist.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
-    ndev = torch.cuda.device_count()
-    backend = dist.get_backend() if world > 1 else "none"
-    if world > 1 and backend == "nccl" and ndev < world:
-        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {ndev} "
-                         f"(GSPLAT_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
-    torch.cuda.set_device(local_rank % ndev if world > 1 else 0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    rank, world, backend = comm.rank, comm.world, comm.backend()
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
 
     N, W, H, L, do_bwd = scene.WORKLOADS[args.workload]
     cfg = scene.CONFIG
@@ -230,30 +305,37 @@ def main():
     if world > 1 and do_bwd and want == "auto":
         errors = {}
         for mode in ("full", "factored", "split"):
+            ms_local, err = None, None
             try:  # a payload whose collectives this node's backend rejects is reported and left out, not fatal
-                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode, ctx=ctx)
+                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode, ctx=ctx, comm=comm)
                 for _ in range(3):
                     st.step(dc, dgi)
                 torch.cuda.synchronize()
-                dist.barrier()
+                comm.barrier()
                 ta = time.perf_counter()
                 for _ in range(10):
                     st.step(dc, dgi)
                 torch.cuda.synchronize()
-                dist.barrier()
-                t = torch.tensor([(time.perf_counter() - ta) / 10 * 1e3], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                exchange_ms[mode] = round(float(t.item()), 4)
+                comm.barrier()
+                ms_local = (time.perf_counter() - ta) / 10 * 1e3
             except Exception as e:  # noqa: BLE001 -- whatever the backend raises
-                errors[mode] = f"{type(e).__name__}: {e}"[:200]
-                print(f"bench.py: exchange payload '{mode}' failed on rank {rank}: {errors[mode]}", file=sys.stderr, flush=True)
+                err = f"{type(e).__name__}: {e}"[:200]
+                print(f"bench.py: exchange payload '{mode}' failed on rank {rank}: {err}", file=sys.stderr, flush=True)
             st = None
+            # dropping a payload is a decision of ALL ranks (store votes, no collective): see agree_on_payload
+            if agree_on_payload(comm, mode, err is None):
+                t = torch.tensor([ms_local], dtype=torch.float64, device=dev)
+                comm.all_reduce_max(t)
+                exchange_ms[mode] = round(float(t.item()), 4)
+            else:
+                errors[mode] = err
             torch.cuda.empty_cache()
         if not exchange_ms:
             raise RuntimeError(f"no exchange payload works on this node: {errors}")
         want = min(exchange_ms, key=exchange_ms.get)  # the same on every rank: the times were MAX-reduced
         exchange_ms.update({m: "failed: " + msg for m, msg in errors.items()})
-    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want if want != "auto" else "split", ctx=ctx)
+    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want if want != "auto" else "split", ctx=ctx,
+                                 comm=comm)
 
     def one_step():
         if do_bwd:
@@ -276,28 +358,28 @@ def main():
     dom = "render_backward" if do_bwd else "render_forward"
     step.ctx.set_timing(True, stages=[dom])
     if world > 1:
-        dist.barrier()
+        comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        comm.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm.all_reduce_max(t)
         elapsed = float(t.item())
     dom_ms = step.ctx.get_timing()[dom][0]
     step.ctx.set_timing(False)
 
     if rank != 0:
-        gc.enable()
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        if backend != "threads":
+            gc.enable()
         return
+    if backend == "threads":
+        comm = None  # rank 0 reports alone; the other rank threads have left
 
     # ---- roofline of the dominant kernel (compositing backward): HBM on algorithmic bytes, and the bound the kernel
     # actually runs against, VALU issue (wave-level VALU instructions per launch from the SQ_INSTS_VALU pass kept in
@@ -306,15 +388,24 @@ def main():
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = valu_insts = valu_busy = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")  # filled from the rocprofv3 --pmc passes (profiles/README.md)
+    profile_note = None
     if os.path.exists(tfile) and args.workload == "config3":
         try:
             tj = json.load(open(tfile))
-            traffic, valu_insts, valu_busy = tj.get(dom), tj.get(dom + "_valu_insts"), tj.get(dom + "_valu_busy")
+            # counters are per-launch properties of ONE build: only reported when the profile was taken on these sources
+            have = importlib.import_module("3dgs_amd._lib").source_hash()
+            if tj.get("source_sha16") == have:
+                traffic, valu_insts, valu_busy = tj.get(dom), tj.get(dom + "_valu_insts"), tj.get(dom + "_valu_busy")
+            else:
+                profile_note = (f"profile stale: profiles/traffic.json was measured on sources {tj.get('source_sha16')}, "
+                                f"this library is built from {have}; traffic / VALU counters not reported")
         except Exception:
             traffic = valu_insts = valu_busy = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                 "avg_launch_ms": dom_ms}
+    if profile_note:
+        roofline["note"] = profile_note
     roofline_valu = None
     if valu_insts and dom_ms > 0:
         ginst = valu_insts / (dom_ms * 1e-3) / 1e9
@@ -425,9 +516,6 @@ def main():
         "setup_s": round(gen_s, 1),
     }
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

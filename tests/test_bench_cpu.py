@@ -32,3 +32,21 @@ def test_launcher_starts_the_ranks_and_fails_when_they_fail():
     assert out.returncode != 0
     assert "rank exit codes [1, 1]" in out.stderr
     assert out.stderr.count("needs a GPU") == 2
+
+
+def test_launcher_kills_the_other_ranks_when_one_fails_or_the_deadline_passes():
+    """a rank stuck in a collective its peers never joined must not hold the GPUs.  Rank 1 hangs (a selftest
+    hook in bench.py), rank 0 fails ('needs a GPU' here; any non-zero exit on a GPU box): the launcher kills rank 1 and
+    returns 1 within seconds.  With every rank hanging, the overall deadline ends the run."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        return  # rank 0 would run the benchmark
+    t0 = time.time()
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"GSPLAT_BENCH_SELFTEST": "hang:1"})
+    assert out.returncode == 1 and time.time() - t0 < 120
+    assert "rank(s) [0] failed" in out.stderr and "-9]" in out.stderr
+    t0 = time.time()
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"GSPLAT_BENCH_SELFTEST": "hang:all", "GSPLAT_BENCH_DEADLINE_S": "2"})
+    assert out.returncode == 1 and time.time() - t0 < 60
+    assert "deadline passed" in out.stderr and "[-9, -9]" in out.stderr

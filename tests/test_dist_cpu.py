@@ -140,3 +140,49 @@ def test_view_schedule_is_shared_and_sharded(tmp_path):
     for r in range(world):
         assert (p[0][r] == d[0][:, r]).all()
     assert d[0].min() >= 0 and d[0].max() <= 6 and len(np.unique(d[0])) > 3
+
+
+def test_thread_ranks_eight_way_collectives_and_schedule():
+    """The 8-rank shape of BASELINE config 5 with in-process rank threads (dist.ThreadGroup), on CPU tensors: the
+    all-reduce leaves bitwise the same rank-ordered sum on every rank, the block all-gather puts rank r's block in
+    out[r], MAX-reduce and barrier work, a failing rank releases the others, and the 8-way view schedule hands every
+    rank its own draw of the shared sequence."""
+    gdist, trainer_mod = pkg("dist"), pkg("trainer")
+    world, N = 8, 257
+    grp = gdist.ThreadGroup(world)
+    rngs = [np.random.default_rng(100 + r) for r in range(world)]
+    locals_ = [torch.from_numpy(rngs[r].normal(size=(N, 12)).astype(np.float32)) for r in range(world)]
+
+    def body(comm):
+        assert comm.world == world and comm.backend() == "threads"
+        t = locals_[comm.rank].clone()
+        comm.all_reduce(t).wait()
+        blocks = torch.zeros(world, N + 1, 3)
+        comm.all_gather_blocks(blocks, torch.full((N + 1, 3), float(comm.rank + 1)), async_op=True).wait()
+        mx = comm.all_reduce_max(torch.tensor([float(comm.rank)], dtype=torch.float64))
+        comm.barrier()
+        rng = np.random.default_rng(11)
+        draws = [trainer_mod.draw_view_indices(rng, it, world, 185) for it in range(10)]
+        return t, blocks, float(mx.item()), draws
+
+    out = grp.run(body)
+    want = locals_[0].clone()
+    for r in range(1, world):
+        want += locals_[r]
+    for r in range(world):
+        t, blocks, mx, draws = out[r]
+        assert t.equal(want) and mx == world - 1.0
+        for q in range(world):
+            assert (blocks[q] == float(q + 1)).all()
+        assert draws == out[0][3] and len(draws[0]) == world and draws[0][:2] == [0, 1]
+    assert len({tuple(d) for d in out[0][3]}) == 10
+
+    def failing(comm):
+        if comm.rank == 5:
+            raise ValueError("rank 5 broke")
+        comm.all_reduce(torch.zeros(3))
+
+    with pytest.raises(ValueError, match="rank 5 broke"):
+        gdist.ThreadGroup(world).run(failing)
+    lib = pkg("_lib").load()
+    assert lib.gsplat_factored_gradient_width(world) == 12 + 3 * world

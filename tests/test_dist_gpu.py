@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -48,20 +48,23 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_view_sharded_step_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_view_sharded_step_two_ranks_one_gpu(tmp_path, world):
+    """world 4: the largest group of rank PROCESSES a one-GPU box admits next to the test process itself (its process
+    guard allows six GPU processes); the 8-rank shape runs as rank threads below."""
     import torch.multiprocessing as mp
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     for ex in ("split", "factored", "full"):
-        assert (r[0][ex] == r[1][ex]).all(), f"{ex}: ranks disagree"
+        for k in range(1, world):
+            assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
     full = r[0]["full"]
     scale = np.abs(full).mean()
     for ex in ("split", "factored"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()  # views that saw each gaussian
-    assert (full[:, -1] == 2).any() and (full[:, -1] == 0).any()
+    assert (full[:, -1] == world).any() and (full[:, -1] == 0).any()
 
 
 def _train_worker(rank, world, port, out_dir, exchange):
@@ -109,27 +112,127 @@ def _train_worker(rank, world, port, out_dir, exchange):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["split", "full"])
-def test_view_sharded_training_two_ranks_one_gpu(tmp_path, exchange):
-    """80 view-sharded training iterations (two views per iteration) with SH growth at 25/50 and density control at
-    40/60: both replicas must end with BIT-IDENTICAL parameters, moments and densification statistics without ever
-    exchanging parameters, the loss must fall and the gaussian count change."""
-    import torch.multiprocessing as mp
-    world = 2
-    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
-    r = [np.load(tmp_path / f"train_{exchange}_{k}.npz") for k in range(world)]
-    for k in r[0].files:
+def _check_replicas(r, world):
+    for k in r[0].files if hasattr(r[0], "files") else r[0].keys():
         if k == "meta":  # per-rank figures (each rank logs the loss of its own view)
             continue
-        assert r[0][k].shape == r[1][k].shape and (r[0][k] == r[1][k]).all(), f"{k}: replicas diverged"
-    assert (r[0]["meta"][[2, 3, 7]] == r[1]["meta"][[2, 3, 7]]).all()  # gaussian count, SH degree, distinct counts
+        for q in range(1, world):
+            assert r[0][k].shape == r[q][k].shape and (r[0][k] == r[q][k]).all(), f"{k}: replicas 0 and {q} diverged"
+    for q in range(1, world):
+        assert (r[0]["meta"][[2, 3, 7]] == r[q]["meta"][[2, 3, 7]]).all()  # gaussian count, SH degree, distinct counts
+
+
+@pytest.mark.parametrize("exchange,world", [("split", 2), ("full", 2), ("split", 4)])
+def test_view_sharded_training_two_ranks_one_gpu(tmp_path, exchange, world):
+    """80 view-sharded training iterations (W views per iteration) with SH growth at 25/50 and density control at
+    40/60: all replicas must end with BIT-IDENTICAL parameters, moments and densification statistics without ever
+    exchanging parameters, the loss must fall and the gaussian count change."""
+    import torch.multiprocessing as mp
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"train_{exchange}_{k}.npz") for k in range(world)]
+    _check_replicas(r, world)
     psnr0, psnr1, n_end, l_max, n_start, loss_head, loss_tail, n_counts = r[0]["meta"]
     assert np.isfinite(r[0]["xyz"]).all() and loss_tail < 0.85 * loss_head, (loss_head, loss_tail)
     assert psnr1 > psnr0 + 1.0, (psnr0, psnr1)
     assert n_counts > 1 and n_end != n_start, "density control never changed the gaussian count"
     assert l_max == 2 and r[0]["sh"].shape[1:] == (8, 3)
     dur = r[0]["grad_accum_dur"]
-    assert dur.max() <= 2 * 20 and dur.max() > 1, dur.max()  # two views per iteration since the last reset
+    assert dur.max() <= world * 20 and dur.max() > 1, dur.max()  # W views per iteration since the last reset
+
+
+def test_view_sharded_step_eight_thread_ranks(gpu, scene):
+    """The 8-rank shape (BASELINE config 5) on one GPU, as rank THREADS (dist.ThreadGroup; eight rank processes exceed
+    the box's process guard): eight contexts on one device, factored rows of 12 + 3*8 floats, rgb_all[8, N+1, 3], every
+    payload twice.  All ranks must hold the same packed rows, split == factored bit for bit, both within rounding of
+    the full rows, and the visibility column must count up to eight views."""
+    torch, raster, gdist = gpu, pkg("raster"), pkg("dist")
+    world = 8
+    N, W, H, L = 4000, 160, 96, 3
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::9, 2] *= -1
+    dp = raster.device_params(params)
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    c = scene.CONFIG
+
+    def body(comm):
+        cam = raster.device_camera(scene.make_camera(W, H, view_index=comm.rank + 1))
+        out = {}
+        for ex in ("split", "factored", "full"):
+            step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange=ex, comm=comm)
+            assert step.world == world and step.fw == 12 + 3 * world
+            if ex == "split":
+                assert tuple(step.rgb_all.shape) == (world, N + 1, 3)
+            step.step(cam, gi)
+            step.step(cam, gi)
+            torch.cuda.synchronize()
+            out[ex] = step.packed.cpu().numpy().copy()
+            comm.barrier()
+        return out
+
+    r = gdist.ThreadGroup(world).run(body)
+    for ex in ("split", "factored", "full"):
+        for k in range(1, world):
+            assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
+    full = r[0]["full"]
+    assert (r[0]["split"] == r[0]["factored"]).all()
+    scale = np.abs(full).mean()
+    for ex in ("split", "factored"):
+        err = np.abs(r[0][ex] - full)
+        assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
+        assert (r[0][ex][:, -1] == full[:, -1]).all()
+    assert (full[:, -1] == world).any() and (full[:, -1] == 0).any()
+
+
+def test_view_sharded_training_eight_thread_ranks_one_gpu(gpu, scene):
+    """48 iterations x 8 views with SH growth at 15/30 and density control at 20/40, as eight rank threads on one GPU:
+    the eight replicas (own context, own parameters, own optimizer state each) must end BIT-IDENTICAL, the 8-way view
+    schedule must have fed every rank, the loss must fall and the gaussian count change."""
+    torch, raster, ops, gdist, trainer_mod = gpu, pkg("raster"), pkg("ops"), pkg("dist"), pkg("trainer")
+    world = 8
+    N, W, H = 3000, 160, 96
+    truth = scene.make_gaussians(N, W, H, 0)
+    truth["scale"] += 0.9
+    dpt = raster.device_params(truth)
+    ctx = raster.RasterContext(N, W, H)
+    views = []
+    for v in range(12):
+        cam = raster.device_camera(scene.make_camera(W, H, v))
+        views.append((cam, ctx.rasterize_image(dpt, cam, scene.CONFIG, 0.0, 0)["image"].clone()))
+    idx = np.random.default_rng(2).choice(N, N // 3, replace=False)
+    pts = torch.from_numpy(truth["xyz"][idx].astype(np.float64)).cuda()
+    col = torch.from_numpy(np.clip((truth["rgb"][idx] * 0.28209479 + 0.5) * 255, 0, 255).astype(np.uint8)).cuda()
+    init = ops.initialize_gaussians(pts, col)
+    torch.cuda.synchronize()
+    cfg = dict(num_iters=48, add_sh_band_interval=15, max_sh_band=2, adaptive_control_start=10,
+               adaptive_control_interval=20, adaptive_control_end=45, reset_opacity_start=10 ** 9,
+               uv_grad_threshold=1e-6, max_gaussians=20000, use_background=False)
+
+    def body(comm):
+        mine = {k: v.clone() for k, v in init.items()}
+        t = trainer_mod.Trainer(mine, views, cfg, scene_extent=5.0, seed=3, exchange="split", comm=comm)
+        assert t.world == world and t.rank == comm.rank
+        psnr0 = t.evaluate()
+        hist = t.train(48)
+        psnr1 = t.evaluate()
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in t.params.items()}
+        out["uv_grad_accum"] = t.opt.uv_grad_accum.cpu().numpy()
+        out["grad_accum_dur"] = t.opt.grad_accum_dur.cpu().numpy()
+        out["exp_avg_xyz"] = t.opt.exp_avg["xyz"].cpu().numpy()
+        out["meta"] = np.array([psnr0, psnr1, t.num_gaussians, t.l_max, N // 3, np.mean([h[1] for h in hist[:8]]),
+                                np.mean([h[1] for h in hist[-8:]]), len({h[2] for h in hist})])
+        comm.barrier()
+        return out
+
+    r = gdist.ThreadGroup(world).run(body)
+    _check_replicas(r, world)
+    psnr0, psnr1, n_end, l_max, n_start, loss_head, loss_tail, n_counts = r[0]["meta"]
+    assert np.isfinite(r[0]["xyz"]).all() and loss_tail < 0.9 * loss_head, (loss_head, loss_tail)
+    assert psnr1 > psnr0 + 1.0, (psnr0, psnr1)
+    assert n_counts > 1 and n_end != n_start, "density control never changed the gaussian count"
+    assert l_max == 2 and r[0]["sh"].shape[1:] == (8, 3)
+    dur = r[0]["grad_accum_dur"]
+    assert 8 < dur.max() <= world * 20, dur.max()  # eight views per iteration since the last reset
 
 
 def test_split_exchange_on_rccl_one_rank():
@@ -145,18 +248,24 @@ def test_split_exchange_on_rccl_one_rank():
     assert out.returncode == 0 and "nccl one-rank rehearsal: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself (gloo lets both share this GPU; the
-    RCCL run needs one device per rank) and rank 0 reports n_gpus 2 with the times of all three exchange payloads."""
+@pytest.mark.parametrize("world,threads", [(2, False), (4, False), (8, True)])
+def test_bench_launches_its_own_ranks(world, threads):
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts N ranks itself (gloo lets them share this GPU; the
+    RCCL run needs one device per rank) and rank 0 reports n_gpus N with the times of all three exchange payloads.
+    N = 8 runs as rank threads of one process (GSPLAT_BENCH_THREAD_RANKS=1): eight rank processes exceed this box's
+    process guard; the driver's 8-GPU run uses processes over RCCL."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSPLAT_EXCHANGE")}
     env.update(GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "4",
+    if threads:
+        env["GSPLAT_BENCH_THREAD_RANKS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "small", "--steps", "4",
                           "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["views_per_step"] == 2 and line["scaling"] == "weak"
+    assert line["n_gpus"] == world and line["config"]["views_per_step"] == world and line["scaling"] == "weak"
+    assert line["config"]["backend"] == ("threads" if threads else "gloo")
     assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split"}
     assert line["config"]["exchange"].split(":")[0] in ("full", "factored", "split")
     assert line["value"] > 0 and line["steps"] == 4

@@ -259,6 +259,40 @@ def test_render_image_backward(gpu, case):
     assert_grad_close(g_op.cpu().numpy(), 2 * b["opacity"], "grad_opacity accumulated")
 
 
+@pytest.mark.parametrize("bg", [0.0, 0.5])
+def test_render_image_backward_gate(gpu, orc, bg):
+    """cuda/render_backward.cu:170: ALL nine atomics of a (gaussian, tile) pair are skipped unless some thread's
+    d/d logit is non-zero.  Three ways to get there: sigmoid(opacity) == 1.0f (logit 20), a tile whose grad_image is
+    exactly zero, and -- over a zero background -- a colour equal to the colour behind it (d/d alpha == 0 although the
+    colour sums alpha*T*grad are not)."""
+    torch, ops = gpu, pkg("ops")
+    W, H = 48, 16
+    uv = np.array([[8, 8], [6, 9], [24.5, 8], [40, 7.5]], np.float32)
+    opacity = np.array([20.0, 0.5, 1.0, 0.3], np.float32)
+    conic = np.array([[0.05, 0, 0.05], [0.08, 0.01, 0.06], [0.1, 0, 0.1], [0.07, -0.01, 0.09]], np.float32)
+    rgb = np.array([[0.9, 0.2, 0.1], [0.3, 0.8, 0.5], [0.6, 0.6, 0.2], [0.0, 0.0, 0.0]], np.float32)
+    srt, rng = np.array([1, 0, 2, 3], np.int32), np.array([0, 2, 3, 4], np.int32)
+    assert np.float32(1) / (np.float32(1) + np.exp(np.float32(-20))) == np.float32(1)
+    n, T, _ = orc.render_image(uv, opacity, conic, rgb, bg, srt, rng, W, H)
+    gi = np.random.default_rng(5).uniform(-1, 1, (H, W, 3)).astype(np.float32)
+    gi[:, 16:32] = 0.0  # tile 1
+    want = orc.render_image_backward(uv, opacity, conic, rgb, bg, srt, rng, n, T, gi, W, H)
+    got = [torch.zeros(4, 3, device="cuda"), torch.zeros(4, device="cuda"), torch.zeros(4, 2, device="cuda"),
+           torch.zeros(4, 3, device="cuda")]
+    ops.render_image_backward(_dev(torch, uv), _dev(torch, opacity), _dev(torch, conic), _dev(torch, rgb), bg,
+                              _dev(torch, srt), _dev(torch, rng), _dev(torch, n), _dev(torch, T), _dev(torch, gi), W, H, *got)
+    got = [g.cpu().numpy() for g in got]
+    for g, w, what in zip(got, want, ("rgb", "opacity", "uv", "conic")):
+        np.testing.assert_allclose(g, w, rtol=1e-3, atol=1e-6 * np.abs(w).max(), err_msg=what)
+        assert (g[0] == 0).all() and (w[0] == 0).all(), what + ": the fully opaque gaussian gets no gradient"
+        assert (g[2] == 0).all() and (w[2] == 0).all(), what + ": zero pixel gradients add nothing"
+        if bg == 0.0:  # d/d alpha == 0 on every pixel: the reference drops the colour sums too
+            assert (g[3] == 0).all() and (w[3] == 0).all(), what + ": black over black"
+    assert np.abs(want[0][1]).max() > 0
+    if bg != 0.0:
+        assert np.abs(want[0][3]).max() > 0 and np.abs(got[0][3]).max() > 0
+
+
 def test_per_gaussian_backward_chain(gpu, case):
     """conic -> (J, Sigma) -> (xyz_c, quaternion, scale), uv -> xyz_c -> xyz, with the reference's += chaining."""
     torch, ops = gpu, pkg("ops")
