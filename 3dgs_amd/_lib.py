@@ -99,7 +99,7 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
-ABI_VERSION = 2  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
+ABI_VERSION = 3  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -151,6 +151,7 @@ SIGNATURES = {
     "gsplat_backward_pass": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera), _P, _F, _I,
                                   ctypes.POINTER(Gradients), _P]),
     "gsplat_context_set_render_only": (_I, [_P, _I]),
+    "gsplat_context_set_lean_forward": (_I, [_P, _I]),
     "gsplat_context_set_timing": (_I, [_P, _I]),
     "gsplat_context_set_timing_stages": (_I, [_P, ctypes.c_uint]),
     "gsplat_context_get_timing": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), _I]),

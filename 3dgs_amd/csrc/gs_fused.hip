@@ -72,6 +72,8 @@ struct gsplat_context {
   bool rows_ready = false;  // gsplat_backward_render has filled grad_rows for the recorded forward
   bool backward_seen = false, rows_zeroed = false;  // training use: the forward clears grad_rows for the backward
   bool render_only = false;  // gsplat_context_set_render_only: forwards skip what only a backward would read
+  bool lean = false;         // gsplat_context_set_lean_forward: Sigma / J / conic / colour are not materialised
+  gs::DeviceBuffer kept;     // slice-local lists of the kept gaussians (project_cull -> preprocess' compacted walk)
   // the forward's record (gs_common.h: publish_record): pinned host memory the GPU writes and the host polls
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
@@ -109,7 +111,7 @@ struct gsplat_context {
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks};
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -117,7 +119,7 @@ struct gsplat_context {
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks};
+                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept};
     for (auto *p : all) p->release();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const flo
                                                                        unsigned char *__restrict__ mask,
                                                                        int *__restrict__ rank,
                                                                        int *__restrict__ slice_counts,
-                                                                       unsigned long long *__restrict__ pair_counters) {
+                                                                       unsigned long long *__restrict__ pair_counters,
+                                                                       int *__restrict__ kept) {
   extern __shared__ unsigned long long s_ballot[];  // [trips * 16] ballots, then [trips * 16] exclusive counts (int)
   constexpr int kWaves = gs::kBinThreads / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -226,7 +229,13 @@ __global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const flo
   __syncthreads();
   for (int t = 0; t < trips; ++t) {
     const int i = lo + t * gs::kBinThreads + (int)threadIdx.x;
-    if (i < hi) rank[i] = s_before[t * kWaves + w] + __popcll(s_ballot[t * kWaves + w] & ((1ull << lane) - 1ull));
+    if (i < hi) {
+      const unsigned long long bal = s_ballot[t * kWaves + w];
+      const int r = s_before[t * kWaves + w] + __popcll(bal & ((1ull << lane) - 1ull));
+      rank[i] = r;
+      // the slice's kept gaussians as a list (preprocess_kernel's compacted walk; null when the next kernel walks all)
+      if (kept && ((bal >> lane) & 1ull)) kept[lo + r] = i;
+    }
   }
 }
 
@@ -246,103 +255,135 @@ struct PreOut {
 // N*(b+1)/kBinBlocks) (plus index N in the last one, for the counts' terminator).  When `table` is given it also
 // histograms the tiles its gaussians hit in LDS -- the count phase of the counting-sort binning, for free next to
 // the separating-axis tests -- and writes the row table[b][0..T).
-template <int L>
+//   kStoreMid: Sigma, J, conic and the SH colour are stored (ForwardPassData, cuda_data.cuh:70-86).  The fused backward
+//     recomputes the first three and never reads the colour, so a training context that does not hand them to its
+//     caller (gsplat_context_set_lean_forward) skips 72 of the 176 bytes this kernel writes per gaussian.
+//   kCompact: the workgroup walks the KEPT gaussians of its slice through the slice-local list project_cull_kernel left
+//     in `kept` (kept[lo + k] = global index of the slice's k-th kept gaussian) instead of all indices with the culled
+//     lanes idle: a training view that sees half of the scene runs half the trips (r02: 23 % of HBM on such a view).
+// Everything a gaussian stores leaves BEFORE its tile loop, which then holds six numbers per lane: kept across the loop,
+// Sigma, J, conic, colour and the 48-byte record pushed the SH-3 instance past its 128 registers (6 spilled in r02).
+template <int L, bool kStoreMid, bool kCompact>
 __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaussians g, const float *__restrict__ view,
                                                             const unsigned char *__restrict__ mask,
                                                             int *__restrict__ rank,
                                                             const int *__restrict__ slice_counts,
+                                                            const int *__restrict__ kept,
                                                             const float *__restrict__ xyz_c_all,
                                                             const float *__restrict__ uv_all, float fx, float fy,
                                                             float tan_fovx, float tan_fovy, float mh_dist, float cx,
                                                             float cy, float cz, int ntx, int nty, PreOut o,
                                                             int *__restrict__ table) {
   extern __shared__ int s_hist[];
-  __shared__ int s_slices[2];
+  __shared__ int s_slices[3];
   const int N = g.num_gaussians, T = ntx * nty;
   if (threadIdx.x < 64) {  // kept gaussians in the slices before this one, and in all of them (project_cull_kernel)
-    int before = 0, all = 0;
+    int before = 0, all = 0, mine = 0;
 #pragma unroll
     for (int k = 0; k < gs::kBinBlocks / 64; ++k) {
       const int q = (int)threadIdx.x + 64 * k, cnt = slice_counts[q];
       before += q < (int)blockIdx.x ? cnt : 0;
+      mine += q == (int)blockIdx.x ? cnt : 0;
       all += cnt;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); }
-    if (threadIdx.x == 0) { s_slices[0] = before; s_slices[1] = all; }
+    for (int off = 32; off > 0; off >>= 1) {
+      before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); mine += __shfl_xor(mine, off, 64);
+    }
+    if (threadIdx.x == 0) { s_slices[0] = before; s_slices[1] = all; s_slices[2] = mine; }
   }
   if (table)
     for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
   __syncthreads();
-  const int rank_base = s_slices[0], M = s_slices[1];
+  const int rank_base = s_slices[0], M = s_slices[1], slice_kept = s_slices[2];
   const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
   const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks) + (blockIdx.x == gs::kBinBlocks - 1 ? 1 : 0);
   unsigned long long coarse = 0;
   const int lane = threadIdx.x & 63;
-  // wave-uniform trip count: the tiles of LARGE splats are tested by the whole wave together (below)
-  for (int ib = lo + (int)(threadIdx.x - lane); ib < hi; ib += gs::kBinThreads) {
-  const int i = ib + lane;
-  // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
-  // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
-  if (i < hi && i <= N && i >= M) o.counts[i] = 0;
-  int j = 0, hits = 0, span_n = 0;
-  if (i < hi && i <= N) {  // local -> global rank, for every index: kernels after this one read rank[] at slice starts
-    j = i < N ? rank_base + rank[i] : M;
-    rank[i] = j;
-  }
-  unsigned long long hm = 0ull;
-  float bu = 0.0f, bv = 0.0f, br0 = 0.0f, br1 = 0.0f, br2 = 0.0f, br3 = 0.0f;  // what a cooperative test needs of a lane
-  const bool act = i < hi && i < N && mask[i];
-  if (act) {
-  constexpr int n = (L + 1) * (L + 1);
-  const gs::Mat34 vw = gs::load_view(view);
-  // colour
-  float dx, dy, dz, len, rgb[3];
-  gs::view_dir(g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, dx, dy, dz, len);
-  gs::sh_to_rgb<L>(g.sh + (size_t)i * (n - 1) * 3, g.rgb + 3 * i, dx, dy, dz, rgb);
-  // covariance -> conic
-  const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i];
-  const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
-  float sg[6], J[6], con[3], rad[4];
-  gs::sigma_from(rs, sg);
-  const float x = xyz_c_all[3 * i], y = xyz_c_all[3 * i + 1], z = xyz_c_all[3 * i + 2];
-  const float u = uv_all[2 * i], v = uv_all[2 * i + 1];
-  gs::jacobian(x, y, z, fx, fy, tan_fovx, tan_fovy, J);
-  gs::conic_radius(J, sg, vw, mh_dist, con, rad);
-  // exact tile count
-  const gs::TileRect r = gs::coarse_rect(u, v, rad[0], ntx, nty);
-  if (r.x1 > r.x0 && r.y1 > r.y0) {
-    coarse += (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
-    const gs::Obb ob = gs::make_obb(u, v, rad[0], rad[1], rad[2], rad[3]);
-    const gs::TileRect sp = gs::obb_span(ob, r);
-    const int rh = r.y1 - r.y0;
-    span_n = max(0, sp.x1 - sp.x0) * max(0, sp.y1 - sp.y0);
-    if (span_n <= kCoopTiles) {
-      for (int tx = sp.x0; tx < sp.x1; ++tx)
-        for (int ty = sp.y0; ty < sp.y1; ++ty) {
-          const bool h = gs::obb_hits_tile(ob, tx, ty);
-          const int bit = (tx - r.x0) * rh + (ty - r.y0);  // position in the full coarse rectangle
-          hits += h ? 1 : 0;
-          hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the binning kernels when the rectangle has <= 64 tiles
-          if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
-        }
-    } else {
-      bu = u; bv = v; br0 = rad[0]; br1 = rad[1]; br2 = rad[2]; br3 = rad[3];
+  if constexpr (kCompact) {
+    // what the walk over all indices does on the side: counts[M..N] must read 0 in the scan that may follow, rank[] must
+    // hold the exclusive scan at the slice starts (bin_scatter_kernel) and at N (the total)
+    for (int i = max(lo, M) + (int)threadIdx.x; i < hi && i <= N; i += gs::kBinThreads) o.counts[i] = 0;
+    if (threadIdx.x == 0) {
+      rank[lo] = rank_base;
+      if (blockIdx.x == gs::kBinBlocks - 1) rank[N] = M;
     }
   }
-  // stores (compacted order); counts and hitmask follow the cooperative tests
-  o.c2g[j] = i;
-  o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
-  o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
-  if (o.sigma) {  // null in a render-only context: only the backward and the caller read these four
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { o.sigma[6 * j + k] = sg[k]; o.J[6 * j + k] = J[k]; }
-    o.conic[3 * j] = con[0]; o.conic[3 * j + 1] = con[1]; o.conic[3 * j + 2] = con[2];
-    o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
+  // wave-uniform trip count: the tiles of LARGE splats are tested by the whole wave together (below)
+  const int first = kCompact ? 0 : lo, last = kCompact ? slice_kept : hi;
+  for (int ib = first + (int)(threadIdx.x - lane); ib < last; ib += gs::kBinThreads) {
+  const int e = ib + lane;  // kCompact: position in the slice's kept list; else the global index
+  int i = e, j = 0;
+  bool act;
+  if constexpr (kCompact) {
+    act = e < slice_kept;
+    i = act ? kept[lo + e] : lo;
+    j = rank_base + e;
+    if (act) rank[i] = j;
+  } else {
+    // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
+    // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
+    if (i < hi && i <= N && i >= M) o.counts[i] = 0;
+    if (i < hi && i <= N) {  // local -> global rank, for every index: kernels after this one read rank[] at slice starts
+      j = i < N ? rank_base + rank[i] : M;
+      rank[i] = j;
+    }
+    act = i < hi && i < N && mask[i];
   }
-  reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
-  const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
-  o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
+  int hits = 0, span_n = 0;
+  unsigned long long hm = 0ull;
+  float bu = 0.0f, bv = 0.0f, br0 = 0.0f, br1 = 0.0f, br2 = 0.0f, br3 = 0.0f;  // what the tile tests need of a lane
+  if (act) {
+    constexpr int n = (L + 1) * (L + 1);
+    const gs::Mat34 vw = gs::load_view(view);
+    // colour
+    float dx, dy, dz, len, rgb[3];
+    gs::view_dir(g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, dx, dy, dz, len);
+    gs::sh_to_rgb<L>(g.sh + (size_t)i * (n - 1) * 3, g.rgb + 3 * i, dx, dy, dz, rgb);
+    // covariance -> conic
+    const float4 q = reinterpret_cast<const float4 *>(g.quaternion)[i];
+    const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
+    float sg[6], J[6], con[3], rad[4];
+    gs::sigma_from(rs, sg);
+    const float x = xyz_c_all[3 * i], y = xyz_c_all[3 * i + 1], z = xyz_c_all[3 * i + 2];
+    const float u = uv_all[2 * i], v = uv_all[2 * i + 1];
+    gs::jacobian(x, y, z, fx, fy, tan_fovx, tan_fovy, J);
+    gs::conic_radius(J, sg, vw, mh_dist, con, rad);
+    // stores (compacted order); counts and hitmask follow the tile tests
+    o.c2g[j] = i;
+    o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
+    o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
+    if constexpr (kStoreMid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { o.sigma[6 * j + k] = sg[k]; o.J[6 * j + k] = J[k]; }
+      o.conic[3 * j] = con[0]; o.conic[3 * j + 1] = con[1]; o.conic[3 * j + 2] = con[2];
+      o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
+    }
+    reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
+    const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
+    o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1; o.recs[3 * j + 2] = rec.r2;
+    bu = u; bv = v; br0 = rad[0]; br1 = rad[1]; br2 = rad[2]; br3 = rad[3];
+  }
+  if (act) {
+    // exact tile count
+    const gs::TileRect r = gs::coarse_rect(bu, bv, br0, ntx, nty);
+    if (r.x1 > r.x0 && r.y1 > r.y0) {
+      coarse += (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
+      const gs::Obb ob = gs::make_obb(bu, bv, br0, br1, br2, br3);
+      const gs::TileRect sp = gs::obb_span(ob, r);
+      const int rh = r.y1 - r.y0;
+      span_n = max(0, sp.x1 - sp.x0) * max(0, sp.y1 - sp.y0);
+      if (span_n <= kCoopTiles) {
+        for (int tx = sp.x0; tx < sp.x1; ++tx)
+          for (int ty = sp.y0; ty < sp.y1; ++ty) {
+            const bool h = gs::obb_hits_tile(ob, tx, ty);
+            const int bit = (tx - r.x0) * rh + (ty - r.y0);  // position in the full coarse rectangle
+            hits += h ? 1 : 0;
+            hm |= (h && bit < 64) ? (1ull << bit) : 0ull;  // read by the binning kernels when the rectangle has <= 64 tiles
+            if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
+          }
+      }
+    }
   }
   // Large splats (more than kCoopTiles candidate tiles after the axis-aligned clipping: a capture early in training has
   // gaussians over hundreds or thousands of tiles): one lane walking them alone decided the kernel's duration.  The
@@ -961,19 +1002,25 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->fwd_calls++;
   GS_REQUIRE(N <= (64 << 20), "more than 64 Mi gaussians: the cull's per-slice ballots would not fit its LDS");
   c->mark(0, false, st);
+  // A view that culled a fifth of the scene or more last time gets the compacted walk in preprocess_kernel (the previous
+  // forward of this context decides: views of a training run look alike; the first call walks all indices).
+  const bool compact = c->N == N && c->M > 0 && (long long)c->M * 5 < (long long)N * 4;
+  int rc = GSPLAT_OK;
+  if (compact && (rc = c->kept.reserve((size_t)c->max_gaussians * sizeof(int)))) return rc;
   {
     const size_t trips = ((size_t)N / gs::kBinBlocks + 1 + gs::kBinThreads - 1) / gs::kBinThreads + 1;
     project_cull_kernel<<<gs::kBinBlocks, gs::kBinThreads, trips * (gs::kBinThreads / 64) * 12, st>>>(
         g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh, cfg->cull_mask_padding, c->xyz_c_all.as<float>(),
-        c->uv_all.as<float>(), c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->pair_counters());
+        c->uv_all.as<float>(), c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->pair_counters(),
+        compact ? c->kept.as<int>() : nullptr);
     GS_LAUNCH_CHECK();
   }
-  int rc = GSPLAT_OK;
   c->mark(0, true, st);
   c->mark(1, false, st);
   const bool ro = c->render_only;
-  PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), ro ? nullptr : c->sigma.as<float>(),
-               ro ? nullptr : c->conic.as<float>(), ro ? nullptr : c->J.as<float>(), ro ? nullptr : c->rgb.as<float>(),
+  const bool mid = !ro && !c->lean;  // Sigma, J, conic, colour: stored for the caller / the stand-alone backward operators
+  PreOut po = {c->c2g.as<int>(), c->xyz_c.as<float>(), c->uv.as<float>(), mid ? c->sigma.as<float>() : nullptr,
+               mid ? c->conic.as<float>() : nullptr, mid ? c->J.as<float>() : nullptr, mid ? c->rgb.as<float>() : nullptr,
                c->radius.as<float>(), c->recs.as<float4>(), c->counts.as<int>(),
                c->hitmask.as<unsigned long long>(), c->pair_counters()};
   // Two binning routes, both exact for any scene; the choice only affects speed, so it follows the LAST forward's
@@ -987,11 +1034,16 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     bin_table = c->bin_table.as<int>();
   }
   const size_t hist_bytes = sparse ? (size_t)num_tiles * sizeof(int) : 0;
-#define GS_PRE(LL)                                                                                                     \
-  preprocess_kernel<LL><<<gs::kBinBlocks, gs::kBinThreads, hist_bytes, st>>>(                                          \
-      *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->xyz_c_all.as<float>(),         \
-      c->uv_all.as<float>(),                                                                                            \
+#define GS_PRE3(LL, MID, CMP)                                                                                          \
+  preprocess_kernel<LL, MID, CMP><<<gs::kBinBlocks, gs::kBinThreads, hist_bytes, st>>>(                                \
+      *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->kept.as<int>(),              \
+      c->xyz_c_all.as<float>(), c->uv_all.as<float>(),                                                                  \
       fx, fy, tan_fovx, tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1], cam->campos[2], ntx, nty, po, bin_table)
+#define GS_PRE(LL)                                                                                                     \
+  do {                                                                                                                 \
+    if (mid) { if (compact) GS_PRE3(LL, true, true); else GS_PRE3(LL, true, false); }                                  \
+    else { if (compact) GS_PRE3(LL, false, true); else GS_PRE3(LL, false, false); }                                    \
+  } while (0)
   switch (l_max) {
     case 0: GS_PRE(0); break;
     case 1: GS_PRE(1); break;
@@ -999,6 +1051,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     default: GS_PRE(3); break;
   }
 #undef GS_PRE
+#undef GS_PRE3
   GS_LAUNCH_CHECK();
   size_t inst_cap = 0;
   // the one host read-back of the forward: M, S (and the candidate count)
@@ -1143,8 +1196,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     out->num_culled = (size_t)M; out->num_pairs = (size_t)pairs; out->num_splats = S;
     out->mask = c->mask.as<unsigned char>(); out->uv = c->uv_all.as<float>(); out->xyz_c = c->xyz_c_all.as<float>();
     out->compact_to_global = c->c2g.as<int>();
-    out->sigma = ro ? nullptr : c->sigma.as<float>(); out->conic = ro ? nullptr : c->conic.as<float>();
-    out->J = ro ? nullptr : c->J.as<float>(); out->precomputed_rgb = ro ? nullptr : c->rgb.as<float>();
+    out->sigma = mid ? c->sigma.as<float>() : nullptr; out->conic = mid ? c->conic.as<float>() : nullptr;
+    out->J = mid ? c->J.as<float>() : nullptr; out->precomputed_rgb = mid ? c->rgb.as<float>() : nullptr;
     out->radius = c->radius.as<float>();
     out->uv_selected = c->uv.as<float>(); out->xyz_c_selected = c->xyz_c.as<float>();
     out->sorted_gaussians = c->sorted.as<int>();
@@ -1267,6 +1320,12 @@ int gsplat_context_set_render_only(gsplat_context *c, int enabled) {
   GS_REQUIRE(c != nullptr, "null context");
   c->render_only = enabled != 0;
   if (c->render_only) c->have_forward = false;
+  return GSPLAT_OK;
+}
+
+int gsplat_context_set_lean_forward(gsplat_context *c, int enabled) {
+  GS_REQUIRE(c != nullptr, "null context");
+  c->lean = enabled != 0;
   return GSPLAT_OK;
 }
 

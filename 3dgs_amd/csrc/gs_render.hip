@@ -41,6 +41,12 @@
 #ifndef GS_STAMP
 #define GS_STAMP 0
 #endif
+#ifndef GS_EXTRA_FMA
+#define GS_EXTRA_FMA 0
+#endif
+#ifndef GS_FWD_PREFETCH
+#define GS_FWD_PREFETCH 0
+#endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
 #if GS_STAMP
   const unsigned long long st_t0 = GS_NOW(), st_rt0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long st_last = st_t0, st_bar = 0, st_bar1 = 0, st_bar2 = 0, st_stage = 0, st_lists = 0, st_loop = 0, st_trips = 0, st_batches = 0;
+  unsigned long long st_last = st_t0, st_bar = 0, st_bar1 = 0, st_bar2 = 0, st_stage = 0, st_lists = 0, st_loop = 0, st_trips = 0, st_batches = 0, st_load = 0;
 #endif
   if (tid == 0) {
     s_r0[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -182,6 +188,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   unsigned long long satmask = __ballot(!inside);  // lanes whose pixel is saturated or outside the image
   int live = satmask != ~0ull ? 1 : 0;
 
+#if GS_FWD_PREFETCH
+  // experiment (r03): the dependent pair of global loads of the staging (sorted id -> 48-byte record) leaves the
+  // critical path: the record of the NEXT batch is requested before the compositing loop of the current one, its id
+  // one batch earlier still.  All of these loads are unconditional (indices clamped into the list, the instance
+  // buffers hold one entry more than S): a load under a branch ends in register copies, and the copies in a wait.
+  constexpr bool kPrefetch = kPacked;
+  int id_next = 0;
+  SplatRec pre;
+  if constexpr (kPrefetch) {
+    const int last = max(total - 1, 0);
+    pre = load_record<true>(sorted[start + min(tid, last)], recs, raw);
+    id_next = sorted[start + min(kBatch + tid, last)];
+  }
+#else
+  [[maybe_unused]] constexpr bool kPrefetch = false;
+#endif
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
     // an opaque per-batch copy of the thread index (see render_bwd_kernel): staging and list-building addresses are
@@ -195,8 +217,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     __syncthreads();
     GS_LAP(st_bar);
     if (t < count) {
-      const int g = sorted[start + base + t];
-      SplatRec s = load_record<kPacked>(g, recs, raw);
+      SplatRec s;
+#if GS_FWD_PREFETCH
+      if constexpr (kPrefetch) s = pre;
+      else
+#endif
+        s = load_record<kPacked>(sorted[start + base + t], recs, raw);
+#if GS_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // split the staging stamp: loads | block test + LDS stores
+      asm volatile("" : "+v"(s.r0.x), "+v"(s.r1.x), "+v"(s.r2.x));
+      GS_LAP(st_load);
+#endif
       const unsigned int hits = block_hits(s, tx0, ty0);
       if (masks_out) masks_out[start + base + t] = (unsigned short)hits;  // the backward stages the same instances
       s.r2.w = __uint_as_float(hits);
@@ -206,6 +237,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     GS_LAP(st_stage);
     __syncthreads();
     GS_LAP(st_bar1);
+#if GS_FWD_PREFETCH
+    if constexpr (kPrefetch) {
+      pre = load_record<true>(id_next, recs, raw);
+      id_next = sorted[start + min(base + 2 * kBatch + tid, max(total - 1, 0))];
+    }
+#endif
     if (live > 0) {
       // rows whose 16 pixels are all saturated (or outside) need no list
       const int big = kBatch;
@@ -281,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   if (lane == 0) {
     unsigned long long *o = gs_stamp_fwd + ((size_t)blockIdx.x * 4 + wave) * GS_STAMP_WORDS;
     o[0] = (unsigned long long)tile; o[1] = st_rt0; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = GS_NOW() - st_t0;
-    o[4] = st_bar; o[5] = st_stage; o[6] = st_lists; o[7] = st_loop; o[8] = 0; o[9] = st_trips; o[10] = st_batches;
+    o[4] = st_bar; o[5] = st_stage; o[6] = st_lists; o[7] = st_loop; o[8] = st_load; o[9] = st_trips; o[10] = st_batches;
     o[11] = 0; o[12] = st_bar1; o[13] = st_bar2; o[14] = 0; o[15] = (unsigned long long)wave;
   }
 #endif
@@ -453,18 +490,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
           const float dx = a.x - fpx, dy = a.y - fpy;
           // opa * exp(power): d alpha / d gg . gg (the reference differentiates through the 0.99 cap as if absent)
-          float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);
-          float alpha = fminf(kAlphaMax, og);
+          float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);  // opa * exp(power), before the 0.99 cap
+#if GS_EXTRA_FMA > 0
+          // slope experiment (tools/experiments/r03_valu_slope.sh): GS_EXTRA_FMA independent plain FMAs per trip whose
+          // results die at once -- pure issue slots, no new dependency, no live register
+#pragma unroll
+          for (int e = 0; e < GS_EXTRA_FMA; ++e) {
+            float sink;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(sink) : "v"(dx), "v"(dy), "v"(a.z));
+          }
+#endif
           // a row past the end of its list reads the sentinel record (alpha 0).  n is 0 for pixels outside the image,
-          // so "inside" needs no separate test.
-          const bool valid = kCheckN ? ((alpha >= kAlphaMin) && (off < n_rel)) : (alpha >= kAlphaMin);
+          // so "inside" needs no separate test.  The 1/255 floor is tested on og itself: min(0.99, og) >= 1/255 says the
+          // same (written as "not below", so that a NaN passes as it does through the reference's fminf), and the cap is
+          // taken after the select -- one select per trip instead of two (r03: every VALU instruction of this loop costs
+          // its full issue slot, tools/experiments/r03_valu_slope.sh).
+          const bool valid = kCheckN ? (!(og < kAlphaMin) && (off < n_rel)) : !(og < kAlphaMin);
           if (__ballot(valid) == 0ull) continue;
 #if GS_ABLATE == 8
           asm volatile("" ::"v"(og));
           continue;
 #endif
-          alpha = valid ? alpha : 0.0f;
           og = valid ? og : 0.0f;
+          float alpha;  // fminf() would first canonicalise the selected value (a v_max_f32 og, og): the instruction saved
+          asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(alpha) : "v"(og));  // min(0.99f, og), kAlphaMax
+          static_assert(kAlphaMax == 0.99f, "the literal above is 0.99f");
           const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
           T *= inv;                                           // transmittance in front of this splat
           const float aT = alpha * T;

@@ -219,6 +219,7 @@ class ViewShardedStep:
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
         self.N = N = int(params["xyz"].shape[0])
         self.ctx = ctx if ctx is not None else raster.RasterContext(N, width, height)
+        self.ctx.set_lean_forward(True)  # only the fused backward follows: Sigma / J / conic / colour are not materialised
         self.width_cols = wc = raster.packed_gradient_width(l_max)
         dev = params["xyz"].device
         self.comm = comm if comm is not None else TorchComm()  # ThreadComm: in-process ranks (ThreadGroup)

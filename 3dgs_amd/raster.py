@@ -135,6 +135,11 @@ class RasterContext:
         """Serving mode: forwards skip the outputs only a backward reads (see gsplat_context_set_render_only)."""
         check(self._lib.gsplat_context_set_render_only(self._h, int(bool(enabled))))
 
+    def set_lean_forward(self, enabled):
+        """Training through backward_pass: the forward stops storing Sigma, J, conic and the SH colour (the fused backward
+        recomputes what it needs); those four views are then absent from the forward's result."""
+        check(self._lib.gsplat_context_set_lean_forward(self._h, int(bool(enabled))))
+
     def set_timing(self, enabled, stages=None):
         """Per-stage HIP-event timing on / off; `stages`: names from STAGES to time only those (each timed stage costs
         two event records per call)."""

@@ -77,6 +77,7 @@ class Trainer:
         W = max(int(c["width"]) for c, _ in views)
         H = max(int(c["height"]) for c, _ in views)
         self.ctx = raster.RasterContext(max(n, 1), W, H)
+        self.ctx.set_lean_forward(True)  # the loop only runs the fused backward, which recomputes Sigma / J / conic
         self.ctx_capacity = n
         self._new_optimizer(None)
         self.history = []
@@ -102,6 +103,7 @@ class Trainer:
             self.ctx_capacity = int(n * 1.5) + 1
             W, H = self.ctx.max_width, self.ctx.max_height
             self.ctx = raster.RasterContext(self.ctx_capacity, W, H)
+            self.ctx.set_lean_forward(True)
         return self.ctx
 
     # ------------------------------------------------------------------ one iteration (cuda/trainer.cu:1338-1362)

@@ -170,6 +170,7 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
     dp, dc = raster.device_params(params, dev), raster.device_camera(cam, dev)
     dgi = torch.as_tensor(scene.make_grad_image(W, H)).to(dev)
     ctx = raster.RasterContext(N, W, H)
+    ctx.set_lean_forward(True)
     grads = ctx.alloc_gradients(N, L)
     for _ in range(5):
         fwd = ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
@@ -349,6 +350,10 @@ def run_rank(args, comm, device_index):
     S_eff = tile_max_sum(torch, fwd["n"], W, H)
     M, S, num_pairs = fwd["num_culled"], fwd["num_splats"], fwd["num_pairs"]
     stages = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, max(5, min(args.steps, 50)), do_bwd)
+    # the same forward with every ForwardPassData array materialised (what the reference's own host would ask for)
+    step.ctx.set_lean_forward(False)
+    stages_full = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, 10, do_bwd)
+    step.ctx.set_lean_forward(True)
 
     for _ in range(args.warmup):
         one_step()
@@ -499,11 +504,15 @@ def run_rank(args, comm, device_index):
                                f"{'forward+backward' if do_bwd else 'forward'}",
                    "views_per_step": world, "parallelism": f"view-sharded dp{world}" if world > 1 else "single GPU",
                    "exchange": step.describe_exchange() if world > 1 else "none", "backend": backend,
+                   "forward_outputs": "lean (gsplat_context_set_lean_forward): Sigma / J / conic / SH colour of "
+                                      "ForwardPassData are not materialised, the fused backward recomputes them; "
+                                      "preprocess with all of them stored: preprocess_ms_all_forward_outputs",
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": num_pairs, "scene_seed": scene.SEED},
         "exchange_ms_per_step": exchange_ms or None,
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+        "preprocess_ms_all_forward_outputs": round(stages_full["preprocess"][0], 4),
         "roofline": roofline,
         "roofline_valu_issue": roofline_valu,
         # the HBM-bound kernels either side of the compositing, from the per-stage pass (algorithmic bytes per

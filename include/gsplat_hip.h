@@ -48,7 +48,7 @@ extern "C" {
 const char *gsplat_last_error(void);
 /* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
  * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
-#define GSPLAT_ABI_VERSION 2
+#define GSPLAT_ABI_VERSION 3
 int gsplat_abi_version(void);
 /* Frees library-owned scratch memory of the current device. */
 int gsplat_release_scratch(void);
@@ -347,6 +347,13 @@ int gsplat_context_set_binning_route(gsplat_context *ctx, int route);
  * block masks -- and the backward entry points answer "no forward pass recorded" until it is switched off again.
  * Image, per-pixel counts / transmittance and the sorted lists are unchanged. */
 int gsplat_context_set_render_only(gsplat_context *ctx, int enabled);
+/* Lean forward (training through the fused entry points): gsplat_backward_pass recomputes Sigma, J and the conic from
+ * the parameters and never reads the evaluated SH colour, so a caller that does not look at those four arrays of
+ * ForwardPassData (cuda_data.cuh:70-86) can switch their stores off: the four pointers of gsplat_forward_view come back
+ * NULL and the per-gaussian forward writes 104 instead of 176 bytes per visible gaussian.  Image, lists, radii and all
+ * gradients are unchanged.  Off by default: the reference's own backward_pass (cuda/trainer.cu:941-1012) hands these
+ * arrays to the stand-alone backward operators. */
+int gsplat_context_set_lean_forward(gsplat_context *ctx, int enabled);
 int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
 /* The same for a subset of the stages (bit k of stage_mask = stage k; 0 switches timing off).  Every timed stage
  * costs two event records per call, about 0.7 % of a 1 ms step each: bench.py times only stage 6 inside its timed

@@ -143,8 +143,8 @@ def test_view_sharded_training_two_ranks_one_gpu(tmp_path, exchange, world):
 def test_view_sharded_step_eight_thread_ranks(gpu, scene):
     """The 8-rank shape (BASELINE config 5) on one GPU, as rank THREADS (dist.ThreadGroup; eight rank processes exceed
     the box's process guard): eight contexts on one device, factored rows of 12 + 3*8 floats, rgb_all[8, N+1, 3], every
-    payload twice.  All ranks must hold the same packed rows, split == factored bit for bit, both within rounding of
-    the full rows, and the visibility column must count up to eight views."""
+    payload twice.  All ranks must hold the same packed rows, split and factored within rounding of the full rows, and
+    the visibility column must count up to eight views."""
     torch, raster, gdist = gpu, pkg("raster"), pkg("dist")
     world = 8
     N, W, H, L = 4000, 160, 96, 3
@@ -174,8 +174,7 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
     full = r[0]["full"]
-    assert (r[0]["split"] == r[0]["factored"]).all()
-    scale = np.abs(full).mean()
+    scale = np.abs(full).mean()  # (each payload ran its own backward: float atomics, so payloads agree to rounding only)
     for ex in ("split", "factored"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())

@@ -286,6 +286,56 @@ def test_backward_gate_opaque_gaussians_and_zero_gradient_tiles(gpu, scene, orc)
         assert (_np(grads[k])[sel] == 0).all(), k + ": fully opaque gaussians get no compositing gradient"
 
 
+def test_lean_forward_and_compacted_walk_change_nothing(gpu, scene, orc):
+    """r03: (i) gsplat_context_set_lean_forward drops the stores of Sigma / J / conic / colour (the fused backward
+    recomputes them): those four views disappear, everything else -- image, lists, radii, gradients -- is what the full
+    forward gives.  (ii) A view that culled more than a fifth of the scene is walked through the slice-local kept lists
+    on the NEXT forward of the context (preprocess_kernel<.., kCompact>): every output must be bit-identical to the
+    walk over all indices, rank[] (read by the pack kernels) included."""
+    torch, raster = gpu, pkg("raster")
+    N, W, H, L = 30000, 320, 192, 3
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][1::2, 2] *= -1.0  # every other gaussian behind the camera, interleaved
+    params["xyz"][5000:9000, 2] = -np.abs(params["xyz"][5000:9000, 2])  # and whole slices of them
+    cam = scene.make_camera(W, H, 2)
+    c = scene.CONFIG
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=8)
+    bref = orc.backward_pass(ref, cam, scene.make_grad_image(W, H), c["bg"], L, threads=8)
+    keys = ("mask", "compact_to_global", "xyz_c", "uv", "radius", "sorted", "ranges", "image", "T", "n")
+    mids = ("sigma", "J", "conic", "rgb")
+    for lean in (False, True):
+        ctx = raster.RasterContext(N, W, H)
+        ctx.set_lean_forward(lean)
+        first = ctx.rasterize_image(dp, dc, c, c["bg"], L)          # walks all indices (no previous forward)
+        assert first["num_culled"] < 0.8 * N
+        if not lean:
+            _check_forward(first, ref)
+        a = {k: _np(first[k]).copy() for k in keys + (() if lean else mids)}
+        packed_a = torch.empty(N, raster.packed_gradient_width(L), device="cuda")
+        grads = ctx.alloc_gradients(first["num_culled"], L)
+        ctx.backward_pass(dp, dc, gi, c["bg"], L, grads)
+        ctx.pack_gradients_global(grads, L, N, packed_a)
+        second = ctx.rasterize_image(dp, dc, c, c["bg"], L)         # compacted walk
+        for k in a:
+            assert (_np(second[k]) == a[k]).all(), f"lean={lean}: {k} differs between the two walks"
+        for k in mids:
+            assert (second[k] is None) == lean, k
+        assert second["num_culled"] == first["num_culled"] and second["num_splats"] == first["num_splats"]
+        assert second["num_pairs"] == first["num_pairs"]
+        grads2 = ctx.alloc_gradients(second["num_culled"], L)
+        ctx.backward_pass(dp, dc, gi, c["bg"], L, grads2)
+        _check_backward(grads2, bref)
+        packed_b = torch.empty_like(packed_a)
+        ctx.pack_gradients_global(grads2, L, N, packed_b)           # rank[] of the compacted walk
+        vis_a, vis_b = _np(packed_a[:, -1]), _np(packed_b[:, -1])
+        assert (vis_a == vis_b).all() and (vis_a == ref["mask"]).all()
+        assert_grad_close(_np(packed_b), _np(packed_a), "packed rows, compacted walk vs walk over all", rel=1e-4)
+        third = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+        assert (_np(third["image"]) == a["image"]).all()
+
+
 def test_repeatable_forward_and_linear_backward(gpu, scene):
     """Idempotence: same inputs -> bit-identical forward.  Linearity: backward(2*g) == 2*backward(g) up to the
     float-atomic summation order."""

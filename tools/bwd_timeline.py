@@ -41,7 +41,7 @@ t0 = rt0.min(); dur_us = (rt1.max() - t0) / 100.0  # s_memrealtime ticks at 100 
 print(f"launch span {dur_us:.1f} us (first wave start -> last wave end)")
 tot = cyc.sum()
 for nm, v in (("barrier waits", bar), ("staging (global loads, LDS stores, acc clear)", stage), ("row-list building", lists),
-              ("trip loop", loop), ("flush", flush)):
+              ("trip loop", loop), ("flush" if which != "fwd" else "staging: waiting for the id + record loads (stamp build waits here)", flush)):
     print(f"  {nm:48s} {100 * v.sum() / tot:5.1f} % of wave cycles")
 for nm, v in (("  barrier at batch top (after flush step 2)", bar0), ("  barrier after staging", bar1), ("  barrier after the loop", bar2), ("  barrier after flush step 1", bar3)):
     print(f"  {nm:48s} {100 * v.sum() / tot:5.1f} %   by wave 0..3: " + " ".join(f"{100 * v[wv == w].sum() / cyc[wv == w].sum():.1f}" for w in range(4)))
