@@ -454,10 +454,15 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
   static_assert(kLds <= kLdsSort, "LDS buffer");
   __shared__ unsigned long long buf[kLds];
   __shared__ int s_runs_ok;
-  const int count = long_tiles[0];
+  // kWaves = 2 works through the wave kernel's hand-over list (long lists AND short ones whose keys have no double
+  // form).  The larger instantiations pick their tiles by length from `ranges` alone -- every list above kWaveSortMax
+  // entries is handed over anyway -- so they do not depend on the wave kernel and run beside it on streams of their own
+  // (SortFork): on a capture with thousands of entries per tile the four kernels used to run one after the other, the
+  // last two for a handful of lists each (r03 garden-shaped workload: 43 + 28 + 41 + 64 + 66 us in a row).
+  const int count = kWaves == 2 ? long_tiles[0] : num_tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
-    const int tile = long_tiles[1 + t];
+    const int tile = kWaves == 2 ? long_tiles[1 + t] : t;
     const int start = ranges[tile], len = ranges[tile + 1] - start;
     // instantiation kWaves takes the handed-over lists of (kWaves / 2, kWaves] runs of kWaveSortMax entries; 2: every
     // list up to two runs (short lists arrive here when a key has no double form); 16: also everything longer, in place
@@ -502,9 +507,40 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
 // `long_tiles` (long_tiles[0] must be 0 on entry) and finished by workgroups of the second kernel
 // `longest`: the longest list when the caller knows it (the fused forward reads it with the counts), else < 0
 static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, int num_tiles, size_t S, int *long_tiles,
-                               int *sorted_out, hipStream_t st, long long longest = -1) {
+                               int *sorted_out, hipStream_t st, long long longest = -1, const SortFork *fork = nullptr) {
   // tiles the wave kernel may hand over: the long lists and any list with a key that has no double form
   const int max_long = (int)std::min<size_t>((size_t)num_tiles, S);
+  // The lists above 2, 4 and 8 runs of kWaveSortMax entries: 256-, 512- and 1024-thread workgroups (4 / 8 / 16 register-
+  // sorted runs merged in 32 / 64 / 128 KB of LDS).  With a SortFork they start on side streams behind the placement,
+  // beside the wave kernel; without (stand-alone operator), behind it on `st`.
+  struct Class { int cls; size_t per; };
+  const Class classes[3] = {{0, 2}, {1, 4}, {2, 8}};
+  bool forked[3] = {false, false, false};
+  auto launch_class = [&](int k, hipStream_t s) {
+    const int cap = (int)std::min<size_t>((size_t)num_tiles, S / (classes[k].per * (size_t)kWaveSortMax));
+    if (k == 0) tile_depth_sort_kernel<4><<<std::min(cap, 5 * 256), 256, 0, s>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
+    if (k == 1) tile_depth_sort_kernel<8><<<std::min(cap, 2 * 256), 512, 0, s>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
+    if (k == 2) tile_depth_sort_kernel<16><<<std::min(cap, 256), 1024, 0, s>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
+  };
+  auto wanted = [&](int k) {
+    const size_t floor_len = classes[k].per * (size_t)kWaveSortMax;
+    return max_long > 0 && S / floor_len > 0 && (longest < 0 || (size_t)longest > floor_len);
+  };
+  if (fork && fork->ready) {
+    bool any = false;
+    for (int k = 0; k < 3; ++k) any = any || wanted(k);
+    if (any) {
+      GS_HIP(hipEventRecord(fork->ev_fork, st));
+      for (int k = 0; k < 3; ++k)
+        if (wanted(k)) {
+          GS_HIP(hipStreamWaitEvent(fork->side[k], fork->ev_fork, 0));
+          launch_class(k, fork->side[k]);
+          GS_LAUNCH_CHECK();
+          GS_HIP(hipEventRecord(fork->ev_join[k], fork->side[k]));
+          forked[k] = true;
+        }
+    }
+  }
   tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
   GS_LAUNCH_CHECK();
   if (max_long > 0) {
@@ -512,21 +548,14 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
     tile_depth_sort_kernel<2><<<std::min(max_long, 10 * 256), 128, 0, st>>>(payload, ranges, num_tiles, sorted_out,
                                                                             long_tiles);
     GS_LAUNCH_CHECK();
-    const int max_longer = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(2 * kWaveSortMax));  // cannot be more
-    if (max_longer > 0 && (longest < 0 || longest > 2 * kWaveSortMax))
-      tile_depth_sort_kernel<4><<<std::min(max_longer, 5 * 256), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out,
-                                                                                long_tiles);
-    GS_LAUNCH_CHECK();
-    // dense captures (thousands of entries per tile): 8 and 16 register-sorted runs merged in 64 / 128 KB of LDS
-    const int max8 = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(4 * kWaveSortMax));
-    if (max8 > 0 && (longest < 0 || longest > 4 * kWaveSortMax))
-      tile_depth_sort_kernel<8><<<std::min(max8, 2 * 256), 512, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
-    GS_LAUNCH_CHECK();
-    const int max16 = (int)std::min<size_t>((size_t)num_tiles, S / (size_t)(8 * kWaveSortMax));
-    if (max16 > 0 && (longest < 0 || longest > 8 * kWaveSortMax))
-      tile_depth_sort_kernel<16><<<std::min(max16, 256), 1024, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
-    GS_LAUNCH_CHECK();
+    for (int k = 0; k < 3; ++k)
+      if (!forked[k] && wanted(k)) {
+        launch_class(k, st);
+        GS_LAUNCH_CHECK();
+      }
   }
+  for (int k = 0; k < 3; ++k)
+    if (forked[k]) GS_HIP(hipStreamWaitEvent(st, fork->ev_join[k], 0));
   return GSPLAT_OK;
 }
 
@@ -850,14 +879,14 @@ int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *r
                              const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
-                             unsigned long long ticket, hipStream_t st) {
+                             unsigned long long ticket, hipStream_t st, const SortFork *fork) {
   const int T = ntx * nty;
   const RecordSource rec = {pub, ticket, m_total, pair_counters};
   bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
                                                                              nty, table, ranges, (long long)S, payload,
                                                                              rec);
   GS_LAUNCH_CHECK();
-  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest);
+  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest, fork);
 }
 
 // The emit step on its own: the fused forward launches it with the buffers' capacity BEFORE it waits for the

@@ -108,6 +108,16 @@ struct ScratchLock {
   ScratchLock &operator=(const ScratchLock &) = delete;
 };
 
+// Side streams of a context for the per-tile sorts of long lists (gs_binning.hip sort_tiles_by_depth): the kernels of the
+// 2049..4096 / ..8192 / ..16384-entry classes run beside the one-wave-per-tile kernel instead of behind it.
+struct SortFork {
+  bool ready = false;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int create();
+  void destroy();
+};
+
 // pinned host words for count read-backs
 struct HostWords {
   int *p = nullptr;

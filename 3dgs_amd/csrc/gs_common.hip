@@ -67,6 +67,31 @@ static std::recursive_mutex g_scratch_mutex;
 ScratchLock::ScratchLock() { g_scratch_mutex.lock(); }
 ScratchLock::~ScratchLock() { g_scratch_mutex.unlock(); }
 
+int SortFork::create() {
+  if (ready) return GSPLAT_OK;
+  if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return GSPLAT_ERR_HIP; }
+  for (int k = 0; k < 3; ++k)
+    if (hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming) != hipSuccess) {
+      set_error("could not create the sort side streams");
+      destroy();
+      return GSPLAT_ERR_HIP;
+    }
+  ready = true;
+  return GSPLAT_OK;
+}
+
+void SortFork::destroy() {
+  for (int k = 0; k < 3; ++k) {
+    if (ev_join[k]) (void)hipEventDestroy(ev_join[k]);
+    if (side[k]) (void)hipStreamDestroy(side[k]);
+    ev_join[k] = nullptr; side[k] = nullptr;
+  }
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  ev_fork = nullptr;
+  ready = false;
+}
+
 static HostWords g_words;
 int HostWords::ensure() {
   if (p) return GSPLAT_OK;

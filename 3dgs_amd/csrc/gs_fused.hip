@@ -35,7 +35,7 @@ int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *r
                              const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
-                             unsigned long long ticket, hipStream_t st);
+                             unsigned long long ticket, hipStream_t st, const SortFork *fork);
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
@@ -74,6 +74,7 @@ struct gsplat_context {
   bool render_only = false;  // gsplat_context_set_render_only: forwards skip what only a backward would read
   bool lean = false;         // gsplat_context_set_lean_forward: Sigma / J / conic / colour are not materialised
   gs::DeviceBuffer kept;     // slice-local lists of the kept gaussians (project_cull -> preprocess' compacted walk)
+  gs::SortFork fork;         // side streams for the per-tile sorts of long lists (created when a forward first needs them)
   // the forward's record (gs_common.h: publish_record): pinned host memory the GPU writes and the host polls
   volatile unsigned long long *h_pub = nullptr;
   unsigned long long *d_pub = nullptr, ticket = 0;
@@ -121,6 +122,7 @@ struct gsplat_context {
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept};
     for (auto *p : all) p->release();
+    fork.destroy();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
     if (h_pub) { (void)hipHostFree((void *)h_pub); h_pub = nullptr; d_pub = nullptr; }
@@ -204,8 +206,10 @@ __global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const flo
       gs::camera_space(v, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], x, y, z);
       gs::to_screen(p, x, y, z, width, height, u, q);
       k = gs::keep(u, q, z, near_thresh, padding, width, height);
-      xyz_c[3 * i] = x; xyz_c[3 * i + 1] = y; xyz_c[3 * i + 2] = z;
-      uv[2 * i] = u; uv[2 * i + 1] = q;
+      if (xyz_c) {  // ForwardPassData's uncompacted d_xyz_c / d_uv; a lean context does not materialise them
+        xyz_c[3 * i] = x; xyz_c[3 * i + 1] = y; xyz_c[3 * i + 2] = z;
+        uv[2 * i] = u; uv[2 * i + 1] = q;
+      }
       mask[i] = k ? 1 : 0;
     }
     const unsigned long long bal = __ballot(k);
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
                                                             int *__restrict__ rank,
                                                             const int *__restrict__ slice_counts,
                                                             const int *__restrict__ kept,
-                                                            const float *__restrict__ xyz_c_all,
-                                                            const float *__restrict__ uv_all, float fx, float fy,
+                                                            const float *__restrict__ proj, int width, int height,
+                                                            float fx, float fy,
                                                             float tan_fovx, float tan_fovy, float mh_dist, float cx,
                                                             float cy, float cz, int ntx, int nty, PreOut o,
                                                             int *__restrict__ table) {
@@ -345,8 +349,16 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
     const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
     float sg[6], J[6], con[3], rad[4];
     gs::sigma_from(rs, sg);
-    const float x = xyz_c_all[3 * i], y = xyz_c_all[3 * i + 1], z = xyz_c_all[3 * i + 2];
-    const float u = uv_all[2 * i], v = uv_all[2 * i + 1];
+    // camera-space position and pixel coordinates: recomputed with project_cull_kernel's functions on the same inputs
+    // (bit for bit its values) from a second, cache-resident read of the position, instead of a 20-byte round trip
+    // through the uncompacted arrays
+    float x, y, z, u, v;
+    {
+      int i2 = i;
+      asm volatile("" : "+v"(i2));  // an opaque copy: the first read's registers are not kept alive across the SH sum
+      gs::camera_space(vw, g.xyz[3 * i2], g.xyz[3 * i2 + 1], g.xyz[3 * i2 + 2], x, y, z);
+      gs::to_screen(gs::load_proj(proj), x, y, z, width, height, u, v);
+    }
     gs::jacobian(x, y, z, fx, fy, tan_fovx, tan_fovy, J);
     gs::conic_radius(J, sg, vw, mh_dist, con, rad);
     // stores (compacted order); counts and hitmask follow the tile tests
@@ -1010,8 +1022,9 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   {
     const size_t trips = ((size_t)N / gs::kBinBlocks + 1 + gs::kBinThreads - 1) / gs::kBinThreads + 1;
     project_cull_kernel<<<gs::kBinBlocks, gs::kBinThreads, trips * (gs::kBinThreads / 64) * 12, st>>>(
-        g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh, cfg->cull_mask_padding, c->xyz_c_all.as<float>(),
-        c->uv_all.as<float>(), c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->pair_counters(),
+        g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh, cfg->cull_mask_padding,
+        c->lean ? nullptr : c->xyz_c_all.as<float>(), c->lean ? nullptr : c->uv_all.as<float>(),
+        c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->pair_counters(),
         compact ? c->kept.as<int>() : nullptr);
     GS_LAUNCH_CHECK();
   }
@@ -1037,8 +1050,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
 #define GS_PRE3(LL, MID, CMP)                                                                                          \
   preprocess_kernel<LL, MID, CMP><<<gs::kBinBlocks, gs::kBinThreads, hist_bytes, st>>>(                                \
       *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->kept.as<int>(),              \
-      c->xyz_c_all.as<float>(), c->uv_all.as<float>(),                                                                  \
-      fx, fy, tan_fovx, tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1], cam->campos[2], ntx, nty, po, bin_table)
+      cam->proj, W, H, fx, fy, tan_fovx, tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1], cam->campos[2], ntx, nty, po, bin_table)
 #define GS_PRE(LL)                                                                                                     \
   do {                                                                                                                 \
     if (mid) { if (compact) GS_PRE3(LL, true, true); else GS_PRE3(LL, true, false); }                                  \
@@ -1098,11 +1110,15 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : 1;
   };
   auto queue_tail = [&](size_t cap, long long longest_hint, bool publish) -> int {  // the placement publishes the record
+    if ((longest_hint < 0 || longest_hint > 2048) && !c->fork.ready) {  // lists beyond two register-sorted runs: see SortFork
+      const int fr = c->fork.create();
+      if (fr) return fr;
+    }
     int r = gs::binning_scatter_and_sort(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(),
                                          c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
                                          c->bin_table.as<int>(), c->ranges.as<int>(), cap, c->pay_a.as<unsigned long long>(),
                                          c->keys_a.as<int>(), c->sorted.as<int>(), longest_hint, c->rank.as<int>() + N,
-                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st);
+                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st, &c->fork);
     if (r) return r;
     c->mark(2, true, st);
     c->mark(4, false, st);
@@ -1194,7 +1210,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->have_forward = !ro;  // a render-only forward leaves nothing for a backward
   if (out) {
     out->num_culled = (size_t)M; out->num_pairs = (size_t)pairs; out->num_splats = S;
-    out->mask = c->mask.as<unsigned char>(); out->uv = c->uv_all.as<float>(); out->xyz_c = c->xyz_c_all.as<float>();
+    out->mask = c->mask.as<unsigned char>();
+    out->uv = c->lean ? nullptr : c->uv_all.as<float>(); out->xyz_c = c->lean ? nullptr : c->xyz_c_all.as<float>();
     out->compact_to_global = c->c2g.as<int>();
     out->sigma = mid ? c->sigma.as<float>() : nullptr; out->conic = mid ? c->conic.as<float>() : nullptr;
     out->J = mid ? c->J.as<float>() : nullptr; out->precomputed_rgb = mid ? c->rgb.as<float>() : nullptr;

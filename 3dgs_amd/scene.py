@@ -81,18 +81,26 @@ def make_camera(width, height, view_index=0):
                 view=view, proj=proj, campos=campos)
 
 
-def make_gaussians(num, width, height, l_max, seed=SEED, splat_scale=1.0):
+def make_gaussians(num, width, height, l_max, seed=SEED, splat_scale=1.0, cluster=None, opacity_range=(-2.0, 3.0)):
     """Gaussian parameters in the reference's device layout (cuda_data.cuh:11-16).  splat_scale multiplies the
-    median projected size (1.5 px by default: the benchmark scene; real captures early in training are far larger)."""
+    median projected size (1.5 px by default: the benchmark scene; real captures early in training are far larger).
+    cluster = (fraction, centre_u, centre_v, sigma) in units of the image width / height: that fraction of the gaussians
+    (chosen per index) is drawn around one image point instead of uniformly -- an object in the middle of a capture,
+    whose tiles hold ten times the average list."""
     fx = width / (2.0 * math.tan(math.radians(30.0)))
     u = (uniform24(seed, 1, num) * 1.10 - 0.05) * width
     v = (uniform24(seed, 2, num) * 1.10 - 0.05) * height
+    if cluster is not None:
+        frac, cu, cv, sig = cluster
+        inside = uniform24(seed, 4, num) < frac
+        u = np.where(inside, (cu + sig * normal(seed, 5, num)) * width, u)
+        v = np.where(inside, cv * height + sig * normal(seed, 6, num) * width, v)
     z = 2.0 + 10.0 * uniform24(seed, 3, num)
     xyz = np.stack([(u - width / 2.0) * z / fx, (v - height / 2.0) * z / fx, z], 1).astype(np.float32)
     s0 = splat_scale * 1.5 * 7.0 / fx
     scale = np.log(s0 * np.exp(0.35 * normal(seed, 10, 3 * num))).reshape(num, 3).astype(np.float32)
     quaternion = normal(seed, 20, 4 * num).reshape(num, 4).astype(np.float32)
-    opacity = (-2.0 + 5.0 * uniform24(seed, 30, num)).astype(np.float32)
+    opacity = (opacity_range[0] + (opacity_range[1] - opacity_range[0]) * uniform24(seed, 30, num)).astype(np.float32)
     rgb = (-1.5 + 3.0 * uniform24(seed, 40, 3 * num)).reshape(num, 3).astype(np.float32)
     n_rest = (l_max + 1) ** 2 - 1
     sh = (0.1 * normal(seed, 50, 3 * n_rest * num)).reshape(num, n_rest, 3).astype(np.float32) if n_rest else \
@@ -100,11 +108,11 @@ def make_gaussians(num, width, height, l_max, seed=SEED, splat_scale=1.0):
     return dict(xyz=xyz, rgb=rgb, sh=sh, opacity=opacity, scale=scale, quaternion=quaternion)
 
 
-def cull_half(params, seed=SEED):
+def cull_half(params, seed=SEED, fraction=0.5):
     """About half of the gaussians moved behind the camera (z -> -z), chosen per index by the counter-based generator:
     culled and visible rows interleave at random, as in a real training view, instead of the benchmark scene's M = N."""
     out = {k: v.copy() for k, v in params.items()}
-    behind = uniform24(seed, 70, len(out["xyz"])) < 0.5
+    behind = uniform24(seed, 70, len(out["xyz"])) < fraction
     out["xyz"][behind, 2] *= -1.0
     return out
 
@@ -156,12 +164,28 @@ WORKLOADS = {
     # after 7 000 iterations: 145 k visible gaussians, 54 candidate tiles and 12.6 instances per gaussian, tile lists of
     # 420 entries on average): few, large splats at the Mip-NeRF 360 1/4 resolution
     "bigsplats": (150_000, 1297, 840, 3, True),
+    # not a BASELINE config: the density of a real capture late in training (the generated garden dataset with 1.2 M SfM
+    # points, DESIGN section 9: 1.26 M gaussians at 1297x840, tile lists of ~1100 entries on average and ~10 000 in the
+    # tiles of the object in the middle), in Morton order as a training run keeps them
+    "garden1200k": (1_260_000, 1297, 840, 3, True),
 }
+
+
+def make_garden_like(N, W, H, L, seed=SEED, splat_scale=1.8, cluster_fraction=0.15, cull=0.40, opacity_range=(-5.0, 0.5)):
+    """The shape of a view of the generated garden capture late in training (DESIGN section 9, 1.2 M SfM points): a third
+    of the gaussians outside the view, larger and more transparent splats than the benchmark scene (about six tile
+    instances per visible gaussian, pixels that saturate late), an object in the middle whose tiles hold ~10 000
+    entries against ~1100 on average, Morton order in memory."""
+    p = make_gaussians(N, W, H, L, seed, splat_scale=splat_scale, cluster=(cluster_fraction, 0.5, 0.55, 0.05),
+                       opacity_range=opacity_range)
+    return morton_order(cull_half(p, seed, cull))
 
 
 def make_workload_gaussians(name, seed=SEED):
     """The gaussians of a named workload, with its variant applied (half culled, Morton order, large splats)."""
     N, W, H, L, _ = WORKLOADS[name]
+    if name == "garden1200k":
+        return make_garden_like(N, W, H, L, seed)
     params = make_gaussians(N, W, H, L, seed, splat_scale=5.0 if name == "bigsplats" else 1.0)
     if name == "config3_halfculled":
         params = cull_half(params, seed)

@@ -350,7 +350,8 @@ int gsplat_context_set_render_only(gsplat_context *ctx, int enabled);
 /* Lean forward (training through the fused entry points): gsplat_backward_pass recomputes Sigma, J and the conic from
  * the parameters and never reads the evaluated SH colour, so a caller that does not look at those four arrays of
  * ForwardPassData (cuda_data.cuh:70-86) can switch their stores off: the four pointers of gsplat_forward_view come back
- * NULL and the per-gaussian forward writes 104 instead of 176 bytes per visible gaussian.  Image, lists, radii and all
+ * NULL, and so do the uncompacted `uv` / `xyz_c` (the compacted uv_selected / xyz_c_selected stay); the per-gaussian
+ * forward then writes 104 instead of 176 bytes per visible gaussian and the cull 5 instead of 25 per gaussian.  Image, lists, radii and all
  * gradients are unchanged.  Off by default: the reference's own backward_pass (cuda/trainer.cu:941-1012) hands these
  * arrays to the stand-alone backward operators. */
 int gsplat_context_set_lean_forward(gsplat_context *ctx, int enabled);

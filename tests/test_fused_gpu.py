@@ -313,6 +313,13 @@ def test_lean_forward_and_compacted_walk_change_nothing(gpu, scene, orc):
         if not lean:
             _check_forward(first, ref)
         a = {k: _np(first[k]).copy() for k in keys + (() if lean else mids)}
+        if not lean:
+            full = a
+            assert first["uv_all"] is not None and first["xyz_c_all"] is not None
+        else:  # the lean forward recomputes positions instead of reading them back: the same bits
+            for k in keys:
+                assert (a[k] == full[k]).all(), f"{k}: lean forward differs from the full one"
+            assert first["uv_all"] is None and first["xyz_c_all"] is None
         packed_a = torch.empty(N, raster.packed_gradient_width(L), device="cuda")
         grads = ctx.alloc_gradients(first["num_culled"], L)
         ctx.backward_pass(dp, dc, gi, c["bg"], L, grads)
