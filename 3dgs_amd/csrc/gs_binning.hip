@@ -698,7 +698,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
                                                                   const int *__restrict__ table,
                                                                   int *__restrict__ ranges, long long capacity,
                                                                   unsigned long long *__restrict__ payload,
-                                                                  RecordSource rec) {
+                                                                  RecordSource rec, bool compact_walk) {
   extern __shared__ int s_cur[];
   __shared__ int s_wave[kBinThreads / 64], s_long[kBinThreads / 64];
   const int T = ntx * nty;
@@ -779,8 +779,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
     if (blockIdx.x == 0 && threadIdx.x == kBinThreads - 1) ranges[T] = min(S, room);
   }
   __syncthreads();
-  // the compacted gaussians of this workgroup's slice of global indices (rank = exclusive scan of the cull mask)
-  const int lo = rank[(long long)N * blockIdx.x / kBinBlocks], hi = rank[(long long)N * (blockIdx.x + 1) / kBinBlocks];
+  // This workgroup's gaussians: the chunks preprocess_kernel counted into this workgroup's histogram row (gs_common.h:
+  // chunk c of 64 entries belongs to workgroup c % kBinBlocks, wave (c / kBinBlocks) % 16) -- chunks of the compacted
+  // slots when that kernel walked those, else chunks of global indices, whose compacted slots are the run
+  // [rank[64 c], rank[64 c + 64]) (rank = exclusive scan of the cull mask, rank[N] = M).
+  const int M = rank[N];
+  const int walk_chunks = bin_chunks(compact_walk ? M : N);
   auto place = [&](int tile, unsigned long long pay) {
     const int pos = atomicAdd(&s_cur[tile], 1);
     if (pos < capacity) payload[pos] = pay;
@@ -789,8 +793,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
   // one lane walking thousands of tiles alone decided this kernel's duration on scenes with large splats, so the wave
   // takes those one at a time, every lane testing every 64th tile of the rectangle's clipped span (the same functions
   // on the same broadcast inputs as the count in preprocess_kernel: the same instances).
-  for (int jb = lo + (int)(threadIdx.x - lane); jb < hi; jb += kBinThreads) {
-    const int j = jb + lane;
+  for (int c = (int)blockIdx.x + kBinBlocks * (int)(threadIdx.x >> 6); c < walk_chunks; c += kBinBlocks * (kBinThreads / 64)) {
+    int j, hi;
+    if (compact_walk) {
+      j = c * kBinChunk + lane;
+      hi = M;
+    } else {
+      j = rank[c * kBinChunk] + lane;
+      hi = rank[min(c * kBinChunk + kBinChunk, N)];
+    }
     float4 rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float u = 0.0f, v = 0.0f;
     unsigned long long pay = 0ull;
@@ -879,12 +890,12 @@ int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *r
                              const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
-                             unsigned long long ticket, hipStream_t st, const SortFork *fork) {
+                             unsigned long long ticket, hipStream_t st, const SortFork *fork, bool compact_walk) {
   const int T = ntx * nty;
   const RecordSource rec = {pub, ticket, m_total, pair_counters};
   bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
                                                                              nty, table, ranges, (long long)S, payload,
-                                                                             rec);
+                                                                             rec, compact_walk);
   GS_LAUNCH_CHECK();
   return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest, fork);
 }

@@ -55,6 +55,20 @@ int check_device_ptr(const void *p, const char *name, const char *fn);
 // Counting-sort binning (gs_binning.hip) and the per-gaussian forward (gs_fused.hip) split the gaussians into the same
 // kBinBlocks contiguous slices: workgroup b of either kernel owns global indices [N*b/kBinBlocks, N*(b+1)/kBinBlocks).
 constexpr int kBinBlocks = 256, kBinThreads = 1024;
+// r03: the gaussians are dealt to those workgroups in CHUNKS of 64 consecutive entries (one wave trip), round robin:
+// chunk c belongs to workgroup c % kBinBlocks, and inside it to wave (c / kBinBlocks) % 16.  A training run keeps its
+// gaussians in Morton order, where contiguous index ranges differ several times in tile instances per gaussian (near /
+// far, inside / outside the view): with one contiguous slice per workgroup the slowest slice decided both kernels
+// (garden-shaped workload: 5.6x the mean; config 3 in Morton order: 3.1x; dealt in chunks: 1.1x).
+// Only the cull's compaction ranks need contiguous slices (a local scan); those are kBinBlocks runs of whole chunks.
+constexpr int kBinChunk = 64;
+__host__ __device__ inline int bin_chunks(int n) { return (n + kBinChunk - 1) / kBinChunk; }
+// first chunk of the cull's slice s when the index space has C chunks
+__host__ __device__ inline int bin_slice_first_chunk(int C, int s) { return (int)((long long)C * s / kBinBlocks); }
+// the slice that holds chunk c: the largest s with bin_slice_first_chunk(C, s) <= c
+__host__ __device__ inline int bin_slice_of_chunk(int C, int c) {
+  return (int)((((long long)c + 1) * kBinBlocks - 1) / C);
+}
 // The forward's host record: pinned, mapped host memory the GPU writes and the host polls.  Five 64-bit words, each
 // {value << 32 | low half of the forward's ticket}: M, S, candidate pairs (low, high), longest tile list.  A word is
 // one aligned 8-byte store, so it cannot tear, and the host takes the record when all five carry its ticket -- no

@@ -35,7 +35,7 @@ int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *r
                              const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
-                             unsigned long long ticket, hipStream_t st, const SortFork *fork);
+                             unsigned long long ticket, hipStream_t st, const SortFork *fork, bool compact_walk);
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
@@ -171,10 +171,10 @@ __device__ __forceinline__ void rows_from_lds(float *__restrict__ dst, const flo
 }
 
 // ---- A: world -> camera -> pixel -> keep-mask, for all N, and the compaction ranks
-// Launched like preprocess_kernel: kBinBlocks workgroups of kBinThreads, workgroup b owns the global indices
-// [N*b/kBinBlocks, N*(b+1)/kBinBlocks).  rank[i] leaves this kernel as the exclusive count of kept gaussians INSIDE
-// the slice and slice_counts[b] as the slice's total; preprocess_kernel (same slices) adds the counts of the slices
-// before its own and stores the global rank.  That replaces a two-kernel rocPRIM scan over N + 1 flags (12 us of
+// kBinBlocks workgroups of kBinThreads; workgroup b owns the global indices of the chunks [C*b/kBinBlocks,
+// C*(b+1)/kBinBlocks) (gs_common.h: bin_slice_first_chunk).  rank[i] leaves this kernel as the exclusive count of kept
+// gaussians INSIDE the slice and slice_counts[b] as the slice's total; preprocess_kernel adds the counts of the slices
+// before the gaussian's own and stores the global rank.  That replaces a two-kernel rocPRIM scan over N + 1 flags (12 us of
 // launch + drain on the forward's critical path and 12 MB of traffic) by two barriers in a kernel that is here anyway.
 // Pass 1 has no barrier, so the loads of all trips overlap; it leaves one ballot per (trip, wave) in LDS, wave 0 scans
 // their counts, pass 2 only stores.
@@ -191,8 +191,9 @@ __global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const flo
   extern __shared__ unsigned long long s_ballot[];  // [trips * 16] ballots, then [trips * 16] exclusive counts (int)
   constexpr int kWaves = gs::kBinThreads / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
-  const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks);
+  const int C = gs::bin_chunks(N);
+  const int lo = gs::kBinChunk * gs::bin_slice_first_chunk(C, blockIdx.x);
+  const int hi = min(N, gs::kBinChunk * gs::bin_slice_first_chunk(C, blockIdx.x + 1));
   const int trips = (hi - lo + gs::kBinThreads - 1) / gs::kBinThreads;
   int *s_before = reinterpret_cast<int *>(s_ballot + trips * kWaves);
   if (blockIdx.x == 0 && threadIdx.x < 64) pair_counters[threadIdx.x] = 0ull;  // consumed by preprocess_kernel
@@ -255,16 +256,16 @@ struct PreOut {
 };
 
 // ---- B: everything per kept gaussian, written at its compacted slot
-// Launched as kBinBlocks workgroups of kBinThreads: workgroup b owns the global indices [N*b/kBinBlocks,
-// N*(b+1)/kBinBlocks) (plus index N in the last one, for the counts' terminator).  When `table` is given it also
-// histograms the tiles its gaussians hit in LDS -- the count phase of the counting-sort binning, for free next to
-// the separating-axis tests -- and writes the row table[b][0..T).
+// Launched as kBinBlocks workgroups of kBinThreads; workgroup b owns every kBinBlocks-th chunk of 64 entries
+// (gs_common.h: kBinChunk).  When `table` is given it also histograms the tiles its gaussians hit in LDS -- the count
+// phase of the counting-sort binning, for free next to the separating-axis tests -- and writes the row table[b][0..T).
 //   kStoreMid: Sigma, J, conic and the SH colour are stored (ForwardPassData, cuda_data.cuh:70-86).  The fused backward
 //     recomputes the first three and never reads the colour, so a training context that does not hand them to its
 //     caller (gsplat_context_set_lean_forward) skips 72 of the 176 bytes this kernel writes per gaussian.
-//   kCompact: the workgroup walks the KEPT gaussians of its slice through the slice-local list project_cull_kernel left
-//     in `kept` (kept[lo + k] = global index of the slice's k-th kept gaussian) instead of all indices with the culled
-//     lanes idle: a training view that sees half of the scene runs half the trips (r02: 23 % of HBM on such a view).
+//   kCompact: the chunks are chunks of the M compacted slots, resolved through the slice-local lists project_cull_kernel
+//     left in `kept` (kept[first index of slice s + k] = global index of the slice's k-th kept gaussian), instead of
+//     chunks of all indices with the culled lanes idle: a view that culls every other gaussian runs half the trips
+//     (r02: 23 % of HBM on such a view).
 // Everything a gaussian stores leaves BEFORE its tile loop, which then holds six numbers per lane: kept across the loop,
 // Sigma, J, conic, colour and the 48-byte record pushed the SH-3 instance past its 128 registers (6 spilled in r02).
 template <int L, bool kStoreMid, bool kCompact>
@@ -279,60 +280,70 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
                                                             float cy, float cz, int ntx, int nty, PreOut o,
                                                             int *__restrict__ table) {
   extern __shared__ int s_hist[];
-  __shared__ int s_slices[3];
+  __shared__ int s_base[gs::kBinBlocks + 1];  // kept gaussians before each of the cull's slices; [kBinBlocks]: all of them
+  __shared__ int s_wsum[4];
   const int N = g.num_gaussians, T = ntx * nty;
-  if (threadIdx.x < 64) {  // kept gaussians in the slices before this one, and in all of them (project_cull_kernel)
-    int before = 0, all = 0, mine = 0;
+  static_assert(gs::kBinBlocks == 256, "the scan below is written for four waves of slice counts");
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int cnt = 0, incl = 0;
+    if (threadIdx.x < gs::kBinBlocks) {
+      cnt = slice_counts[threadIdx.x];
+      incl = cnt;
 #pragma unroll
-    for (int k = 0; k < gs::kBinBlocks / 64; ++k) {
-      const int q = (int)threadIdx.x + 64 * k, cnt = slice_counts[q];
-      before += q < (int)blockIdx.x ? cnt : 0;
-      mine += q == (int)blockIdx.x ? cnt : 0;
-      all += cnt;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+      }
+      if (lane == 63) s_wsum[w] = incl;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); mine += __shfl_xor(mine, off, 64);
+    if (table)
+      for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
+    __syncthreads();
+    if (threadIdx.x < gs::kBinBlocks) {
+      int before = 0;
+      for (int q = 0; q < w; ++q) before += s_wsum[q];
+      s_base[threadIdx.x] = before + incl - cnt;
+      if (threadIdx.x == gs::kBinBlocks - 1) s_base[gs::kBinBlocks] = before + incl;
     }
-    if (threadIdx.x == 0) { s_slices[0] = before; s_slices[1] = all; s_slices[2] = mine; }
+    __syncthreads();
   }
-  if (table)
-    for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
-  __syncthreads();
-  const int rank_base = s_slices[0], M = s_slices[1], slice_kept = s_slices[2];
-  const int lo = (int)((long long)N * blockIdx.x / gs::kBinBlocks);
-  const int hi = (int)((long long)N * (blockIdx.x + 1) / gs::kBinBlocks) + (blockIdx.x == gs::kBinBlocks - 1 ? 1 : 0);
+  const int M = s_base[gs::kBinBlocks];
+  const int C = gs::bin_chunks(N);  // chunks of the index space: the cull's slices are runs of them
   unsigned long long coarse = 0;
   const int lane = threadIdx.x & 63;
-  if constexpr (kCompact) {
-    // what the walk over all indices does on the side: counts[M..N] must read 0 in the scan that may follow, rank[] must
-    // hold the exclusive scan at the slice starts (bin_scatter_kernel) and at N (the total)
-    for (int i = max(lo, M) + (int)threadIdx.x; i < hi && i <= N; i += gs::kBinThreads) o.counts[i] = 0;
-    if (threadIdx.x == 0) {
-      rank[lo] = rank_base;
-      if (blockIdx.x == gs::kBinBlocks - 1) rank[N] = M;
-    }
-  }
-  // wave-uniform trip count: the tiles of LARGE splats are tested by the whole wave together (below)
-  const int first = kCompact ? 0 : lo, last = kCompact ? slice_kept : hi;
-  for (int ib = first + (int)(threadIdx.x - lane); ib < last; ib += gs::kBinThreads) {
-  const int e = ib + lane;  // kCompact: position in the slice's kept list; else the global index
-  int i = e, j = 0;
+  // what a walk over all indices in order did on the side: counts[M..N] must read 0 in the scan that may follow, and
+  // rank[N] holds the total
+  for (long long i = (long long)M + (long long)blockIdx.x * gs::kBinThreads + threadIdx.x; i <= N;
+       i += (long long)gs::kBinBlocks * gs::kBinThreads)
+    o.counts[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) rank[N] = M;
+  // This workgroup's chunks, one wave trip each (gs_common.h): chunk c of the walked space -- all N indices, or the M
+  // compacted slots (kCompact) -- belongs to workgroup c % kBinBlocks and to its wave (c / kBinBlocks) % 16.  The trip
+  // count is wave-uniform: the tiles of LARGE splats are tested by the whole wave together (below).
+  const int walk_chunks = gs::bin_chunks(kCompact ? M : N);
+  for (int c = (int)blockIdx.x + gs::kBinBlocks * (int)(threadIdx.x >> 6); c < walk_chunks;
+       c += gs::kBinBlocks * (gs::kBinThreads / 64)) {
+  const int e = c * gs::kBinChunk + lane;  // kCompact: the compacted slot; else the global index
+  int i = e, j = e;
   bool act;
   if constexpr (kCompact) {
-    act = e < slice_kept;
-    i = act ? kept[lo + e] : lo;
-    j = rank_base + e;
+    act = e < M;
+    // the slice of the cull that holds compacted slot e: the last s with s_base[s] <= e (binary search in LDS)
+    int sl = 0;
+#pragma unroll
+    for (int step = gs::kBinBlocks / 2; step > 0; step >>= 1) sl += (s_base[sl + step] <= e) ? step : 0;
+    i = act ? kept[gs::kBinChunk * gs::bin_slice_first_chunk(C, sl) + (e - s_base[sl])] : 0;
     if (act) rank[i] = j;
   } else {
-    // counts[M..N] must read 0 in the scan that follows: slot k >= M is written by thread k only, slot j < M only by
-    // the visible gaussian of rank j, so no memset and no race (M = rank[N], the total of the mask scan)
-    if (i < hi && i <= N && i >= M) o.counts[i] = 0;
-    if (i < hi && i <= N) {  // local -> global rank, for every index: kernels after this one read rank[] at slice starts
-      j = i < N ? rank_base + rank[i] : M;
+    // local -> global rank, for every index (the pack kernels read it through the mask, bin_scatter_kernel at the
+    // chunk starts): a chunk lies inside one slice of the cull
+    const int sl = gs::bin_slice_of_chunk(C, c);
+    if (i < N) {
+      j = s_base[sl] + rank[i];
       rank[i] = j;
     }
-    act = i < hi && i < N && mask[i];
+    act = i < N && mask[i];
   }
   int hits = 0, span_n = 0;
   unsigned long long hm = 0ull;
@@ -1020,7 +1031,9 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   int rc = GSPLAT_OK;
   if (compact && (rc = c->kept.reserve((size_t)c->max_gaussians * sizeof(int)))) return rc;
   {
-    const size_t trips = ((size_t)N / gs::kBinBlocks + 1 + gs::kBinThreads - 1) / gs::kBinThreads + 1;
+    // LDS of the cull: one ballot + one count per (trip, wave) of the largest slice (a run of whole 64-entry chunks)
+    const size_t slice_max = ((size_t)gs::bin_chunks(N) / gs::kBinBlocks + 2) * gs::kBinChunk;
+    const size_t trips = (slice_max + gs::kBinThreads - 1) / gs::kBinThreads + 1;
     project_cull_kernel<<<gs::kBinBlocks, gs::kBinThreads, trips * (gs::kBinThreads / 64) * 12, st>>>(
         g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh, cfg->cull_mask_padding,
         c->lean ? nullptr : c->xyz_c_all.as<float>(), c->lean ? nullptr : c->uv_all.as<float>(),
@@ -1118,7 +1131,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
                                          c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
                                          c->bin_table.as<int>(), c->ranges.as<int>(), cap, c->pay_a.as<unsigned long long>(),
                                          c->keys_a.as<int>(), c->sorted.as<int>(), longest_hint, c->rank.as<int>() + N,
-                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st, &c->fork);
+                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st, &c->fork, compact);
     if (r) return r;
     c->mark(2, true, st);
     c->mark(4, false, st);
