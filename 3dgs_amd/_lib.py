@@ -125,6 +125,8 @@ SIGNATURES = {
     "gsplat_context_set_binning_route": (_I, [_P, _I]),
     "gsplat_backward_render": (_I, [_P, _P, _F, _P, _P]),
     "gsplat_backward_gaussians": (_I, [_P, _P, _P, _I, _P, _P]),
+    "gsplat_backward_gaussians_range": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
+    "gsplat_pack_gradients_split_range": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "gsplat_pack_gradients_split": (_I, [_P, _P, _I, _P, _P, _P]),
     "gsplat_unpack_gradients_split": (_I, [_P, _P, _P, _S, _I, _I, _I, _P, _P]),
     "gsplat_fused_loss": (_I, [_P, _P, _I, _I, _F, _P, ctypes.POINTER(ctypes.c_float), _P]),

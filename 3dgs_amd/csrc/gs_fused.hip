@@ -478,15 +478,24 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
                                                                 const float4 *__restrict__ rows_in, float fx, float fy,
                                                                 float tan_fovx, float tan_fovy, float fwd_tan_fovx,
                                                                 float fwd_tan_fovy, float mh_dist, float cx, float cy,
-                                                                float cz, int width, int height, BwdOut o) {
-  const int j = blockIdx.x * kBlock + threadIdx.x;
+                                                                float cz, int width, int height, BwdOut o,
+                                                                const int *__restrict__ rank, int i_lo, int i_hi) {
+  // rank != null: only the gaussians with global index in [i_lo, i_hi), i.e. the compacted slots [rank[i_lo], rank[i_hi])
+  // (chunked backward of a view-sharded step: the exchange of one chunk runs while the next is computed); the grid covers
+  // the largest possible chunk, blocks past its end leave at once
+  int j_first = 0;
+  if (rank) {
+    j_first = rank[i_lo];
+    M = rank[i_hi];
+  }
+  const int j = j_first + blockIdx.x * kBlock + threadIdx.x;
   constexpr int n = (L + 1) * (L + 1), kRest = (n - 1) * 3;
   // The SH rows (kRest floats per gaussian, 180 B at degree 3) go through LDS: a lane reading ITS row touches 64
   // different cache lines per wave instruction; the wave's 64 rows as one linear span touch 8.  Same for the
   // gradient rows on the way out.  Each wave stages only its own rows (no workgroup barrier).
   __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 ? kBlock * kRest : 4];
   const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
-  const int jw = blockIdx.x * kBlock + wave_first;  // first compacted slot of this wave
+  const int jw = j_first + blockIdx.x * kBlock + wave_first;  // first compacted slot of this wave
   if (jw >= M) return;
   const int rows = min(64, M - jw);
   const bool live = j < M;
@@ -725,10 +734,10 @@ __global__ __launch_bounds__(kBlock) void pack_uv_norm_kernel(const unsigned cha
 
 // Split exchange: the 12 direction-independent columns (SUM all-reduce) and this view's g_rgb (all-gather).
 __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char *__restrict__ mask,
-                                                            const int *__restrict__ rank_of, int N,
+                                                            const int *__restrict__ rank_of, int i_first, int N,
                                                             gsplat_gradients gr, float *__restrict__ common,
                                                             float *__restrict__ rgb) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;  // one gaussian per thread: three 16-byte stores per row
+  const int i = i_first + blockIdx.x * kBlock + threadIdx.x;  // one gaussian per thread: three 16-byte stores per row
   if (i >= N) return;
   f4u r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = r0, r2 = r0;
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
@@ -878,19 +887,26 @@ int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, 
   return GSPLAT_OK;
 }
 
-int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians, float *common,
-                                float *rgb, void *stream) {
+int gsplat_pack_gradients_split_range(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians,
+                                      int first_gaussian, int end_gaussian, float *common, float *rgb, void *stream) {
   GS_REQUIRE(c && grads, "null argument struct");
   GS_REQUIRE(c->have_forward && num_gaussians == c->N, "does not match the recorded forward");
+  GS_REQUIRE(0 <= first_gaussian && first_gaussian <= end_gaussian && end_gaussian <= num_gaussians, "bad gaussian range");
   GS_REQUIRE_DEV(common);
   if (rgb) {
     GS_REQUIRE_DEV(rgb);
     GS_REQUIRE_DEV(grads->grad_precompute_rgb);  // backward must have been asked for this intermediate
   }
-  pack_split_kernel<<<gs::div_up((long long)num_gaussians, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-      c->mask.as<unsigned char>(), c->rank.as<int>(), num_gaussians, *grads, common, rgb);
+  if (end_gaussian == first_gaussian) return GSPLAT_OK;
+  pack_split_kernel<<<gs::div_up((long long)(end_gaussian - first_gaussian), kBlock), kBlock, 0, (hipStream_t)stream>>>(
+      c->mask.as<unsigned char>(), c->rank.as<int>(), first_gaussian, end_gaussian, *grads, common, rgb);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
+}
+
+int gsplat_pack_gradients_split(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians, float *common,
+                                float *rgb, void *stream) {
+  return gsplat_pack_gradients_split_range(c, grads, num_gaussians, 0, num_gaussians, common, rgb, stream);
 }
 
 int gsplat_pack_uv_grad_norm(gsplat_context *c, const gsplat_gradients *grads, int num_gaussians, float *uv_norm,
@@ -1274,7 +1290,13 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
 
 int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                               const gsplat_gradients *out, void *stream) {
+  return gsplat_backward_gaussians_range(c, g, cam, l_max, out, 0, g ? g->num_gaussians : 0, stream);
+}
+
+int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
+                                    const gsplat_gradients *out, int first_gaussian, int end_gaussian, void *stream) {
   GS_REQUIRE(c && g && cam && out, "null argument struct");
+  GS_REQUIRE(0 <= first_gaussian && first_gaussian <= end_gaussian && end_gaussian <= g->num_gaussians, "bad gaussian range");
   GS_REQUIRE(c->have_forward && c->rows_ready, "gsplat_backward_render has not run for this forward pass");
   GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N && cam->width == c->width && cam->height == c->height,
              "backward arguments do not match the recorded forward pass");
@@ -1292,13 +1314,20 @@ int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, cons
   const float fwd_tan_fovx = c->tan_fovx, fwd_tan_fovy = c->tan_fovy;  // the recorded forward's (cuda/raster.cu:92-93)
   BwdOut bo = {out->grad_xyz, out->grad_rgb, out->grad_sh, out->grad_opacity, out->grad_scale, out->grad_quaternion,
                out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb};
-  const dim3 grid(gs::div_up(M, kBlock)), block(kBlock);
+  // a range of global indices holds at most that many visible gaussians (and never more than M); the kernel reads the
+  // range's compacted slots from rank[] on the device
+  const bool whole = first_gaussian == 0 && end_gaussian == g->num_gaussians;
+  const int span = whole ? M : std::min(M, end_gaussian - first_gaussian);
+  if (span == 0) return GSPLAT_OK;
+  const int *rank_arg = whole ? nullptr : c->rank.as<int>();
+  const dim3 grid(gs::div_up(span, kBlock)), block(kBlock);
   c->mark(7, false, st);
 #define GS_BWD(LL)                                                                                                     \
   preprocess_bwd_kernel<LL><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),                     \
                                                     c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
                                                     tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
-                                                    cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo)
+                                                    cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
+                                                    rank_arg, first_gaussian, end_gaussian)
   switch (l_max) {
     case 0: GS_BWD(0); break;
     case 1: GS_BWD(1); break;

@@ -183,6 +183,50 @@ def all_gather_blocks(out, block, async_op=False):
     return TorchComm().all_gather_blocks(out, block, async_op=async_op)
 
 
+XGMI_LINK_GBS = 153.0  # MI355X_MICROARCH.md: 7 xGMI links per GPU, ~153 GB/s each, point to point
+
+
+def exchange_model(world, num_gaussians, l_max, payload, with_uv_norm=False, chunks=1, link_gbs=XGMI_LINK_GBS):
+    """What one step's exchange moves per rank and what that costs on xGMI, for checking a measured run against.
+    Two bounds per collective: "ring" (RCCL's ring: every byte of a rank leaves through ONE link) and "direct" (every
+    peer over its own link, what the fully connected 8-GPU mesh allows: reduce-scatter + all-gather with 1/W of the
+    buffer per peer).  all-reduce of B bytes: a rank sends 2 (W-1)/W B; ring time = that / link, direct = 2 B / W / link.
+    all-gather of b bytes per rank: sends (W-1) b; ring = that / link, direct = b / link.  Times in ms; launch and
+    synchronisation latencies (tens of microseconds per collective, more with `chunks`) are not in the model."""
+    W, N = int(world), int(num_gaussians)
+    n = (l_max + 1) ** 2
+    tail = 4 * N if with_uv_norm else 0
+    if payload == "full":
+        coll = [("all_reduce", 4 * N * (12 + 3 * n) + tail)]
+    elif payload == "factored":
+        coll = [("all_reduce", 4 * (N + 1) * (12 + 3 * W) + tail)]
+    elif payload == "split":
+        coll = [("all_gather", 4 * (N + 1) * 3), ("all_reduce", 4 * N * 12 + tail)]
+    else:
+        raise ValueError(payload)
+    out = dict(world=W, payload=payload, chunks=int(chunks), collectives=[], sent_bytes_per_rank=0, ring_ms=0.0, direct_ms=0.0)
+    per_ms = link_gbs * 1e6  # bytes per millisecond on one link
+    for kind, b in coll:
+        if kind == "all_reduce":
+            sent, ring, direct = 2 * (W - 1) / W * b, 2 * (W - 1) / W * b / per_ms, 2 * b / W / per_ms
+        else:
+            sent, ring, direct = (W - 1) * b, (W - 1) * b / per_ms, (b / per_ms if W > 1 else 0.0)
+        out["collectives"].append(dict(kind=kind, buffer_bytes=int(b), sent_bytes_per_rank=int(sent), ring_ms=round(ring, 4),
+                                       direct_ms=round(direct, 4)))
+        out["sent_bytes_per_rank"] += int(sent)
+    # the split payload's two collectives run concurrently (different buffers, the gather starts first)
+    if payload == "split":
+        out["ring_ms"] = round(sum(c["ring_ms"] for c in out["collectives"]), 4)       # same links: they add up
+        out["direct_ms"] = round(sum(c["direct_ms"] for c in out["collectives"]), 4)
+        # with `chunks` ranges only the last range's share of the all-reduce is behind the backward
+        ar = out["collectives"][1]
+        out["exposed_direct_ms_after_backward"] = round(ar["direct_ms"] / max(1, int(chunks)), 4)
+        out["exposed_ring_ms_after_backward"] = round(ar["ring_ms"] / max(1, int(chunks)), 4)
+    else:
+        out["ring_ms"], out["direct_ms"] = out["collectives"][0]["ring_ms"], out["collectives"][0]["direct_ms"]
+    return out
+
+
 def unpack(packed, l_max):
     """Views into the reduced buffer: dict name -> [N, ...] tensor (global gaussian order)."""
     cols, _ = packed_layout(l_max)
@@ -213,7 +257,7 @@ class ViewShardedStep:
     """
 
     def __init__(self, params, l_max, width, height, config, bg, exchange="split", with_uv_norm=False, ctx=None,
-                 comm=None):
+                 comm=None, chunks=None):
         from . import raster
         self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
@@ -227,6 +271,10 @@ class ViewShardedStep:
         if exchange not in ("split", "factored", "full"):
             raise ValueError(f"unknown exchange {exchange!r}")
         self.exchange = exchange
+        # chunks > 1 (split exchange, more than one rank): the per-gaussian backward runs in that many ranges of global
+        # indices and the all-reduce of one range's twelve common columns is in flight while the next range is computed
+        # (GSPLAT_EXCHANGE_CHUNKS; default 1: one all-reduce behind the whole backward).  Same packed rows either way.
+        self.chunks = max(1, int(chunks if chunks is not None else os.environ.get("GSPLAT_EXCHANGE_CHUNKS", "1")))
         self.with_uv_norm = bool(with_uv_norm)
         tail = N if with_uv_norm else 0
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
@@ -257,11 +305,13 @@ class ViewShardedStep:
             self.grads["uv"] = torch.empty(N, 2, dtype=torch.float32, device=dev)
         self._campos_of = None  # the camera whose position is already in the exchange buffers
         self._blind = False     # this rank's view saw no gaussian in the current step
+        self._chunk_reduces = None  # chunked step: the all-reduces of the common rows started during the backward
 
     def describe_exchange(self):
         mb = lambda t: f"{t.numel() * 4 / 1e6:.0f} MB"
         if self.exchange == "split":
-            return f"split: all-reduce of {mb(self._reduce_buf)} + all-gather of {mb(self.rgb)} per rank"
+            how = f" in {self.chunks} ranges behind the ranges of the per-gaussian backward" if self.chunks > 1 else ""
+            return f"split: all-reduce of {mb(self._reduce_buf)}{how} + all-gather of {mb(self.rgb)} per rank"
         return f"{self.exchange}: one all-reduce of {mb(self._reduce_buf)}"
 
     def exchange_gradients(self, cam):
@@ -280,18 +330,30 @@ class ViewShardedStep:
                     self.rgb[:N].zero_()
                     self._set_campos(cam)
                     gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+                if self.chunks > 1:  # the other ranks reduce range by range: join every one of those collectives
+                    self._chunk_reduces = [self.comm.all_reduce(self.common[lo:hi], async_op=True)
+                                           for lo, hi in self.chunk_bounds() if hi > lo]
             elif gather is None:
                 self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, self.rgb)
                 self._set_campos(cam)
                 gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
-            else:
+            elif self._chunk_reduces is None:
                 self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, None)
-            reduce = self.comm.all_reduce(self._reduce_buf, async_op=True)
+            if self._chunk_reduces is not None:
+                # chunked step: the common rows are already on their way range by range; what is left is the tail
+                # (the |grad_uv| norms, which need every range's uv gradient)
+                reduces = self._chunk_reduces
+                self._chunk_reduces = None
+                if self.with_uv_norm:
+                    reduces.append(self.comm.all_reduce(self.uv_norm_sum, async_op=True))
+            else:
+                reduces = [self.comm.all_reduce(self._reduce_buf, async_op=True)]
             # the SH columns only need the gathered g_rgb: rebuild them while the all-reduce is in flight
             gather.wait()
             self.raster.unpack_gradients_split(self.params["xyz"], None, self.rgb_all, 3 * (N + 1), self.l_max,
                                                N, self.world, self.packed)
-            reduce.wait()
+            for r in reduces:
+                r.wait()
             self.raster.unpack_gradients_split(None, self.common, None, 0, self.l_max, N, self.world, self.packed)
         elif self.exchange == "factored":
             f = self.factored
@@ -307,6 +369,24 @@ class ViewShardedStep:
                 self.ctx.pack_gradients_global(self.grads, self.l_max, N, self.packed)
             self.comm.all_reduce(self._reduce_buf)
         return self.packed
+
+    def chunk_bounds(self):
+        """Global-index ranges of the chunked exchange: the same on every rank (they depend on N only)."""
+        N, K = self.N, self.chunks
+        return [(N * k // K, N * (k + 1) // K) for k in range(K)]
+
+    def backward_gaussians_chunked(self, cam):
+        """Per-gaussian backward range by range; behind each range its rows of `common` are packed and their all-reduce
+        is started, so that only the last range's exchange is exposed.  Every rank issues the same collectives in the
+        same order (a rank without gaussians in a range packs zeros)."""
+        N = self.N
+        self._chunk_reduces = []
+        for lo, hi in self.chunk_bounds():
+            if hi == lo:
+                continue
+            self.ctx.backward_gaussians_range(self.params, cam, self.l_max, self.grads, lo, hi)
+            self.raster.pack_gradients_split_range(self.ctx, self.grads, N, lo, hi, self.common, None)
+            self._chunk_reduces.append(self.comm.all_reduce(self.common[lo:hi], async_op=True))
 
     def _campos_tensor(self, cam):
         dev_pos = cam.get("campos_dev")  # raster.device_camera uploads it once per view
@@ -341,7 +421,10 @@ class ViewShardedStep:
                 # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
                 self.ctx.backward_render(grad_image, bg, self.rgb)
                 self._rgb_gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
-                self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
+                if self.chunks > 1:
+                    self.backward_gaussians_chunked(cam)
+                else:
+                    self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
             else:
                 self.ctx.backward_pass(self.params, cam, grad_image, bg, self.l_max, self.grads)
         if self.world > 1:

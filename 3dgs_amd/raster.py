@@ -244,6 +244,15 @@ class RasterContext:
         check(self._lib.gsplat_backward_gaussians(self._h, ctypes.byref(g), ctypes.byref(c), int(l_max), ctypes.byref(gs), st))
         return grads
 
+    def backward_gaussians_range(self, params, cam, l_max, grads, first, end):
+        """The per-gaussian chain for the gaussians with global index in [first, end) (chunked exchange)."""
+        g, c = self._structs(params, cam, l_max)
+        gs = self._grad_struct(grads)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_backward_gaussians_range(self._h, ctypes.byref(g), ctypes.byref(c), int(l_max),
+                                                        ctypes.byref(gs), int(first), int(end), st))
+        return grads
+
     def pack_gradients_global(self, grads, l_max, num_gaussians, packed):
         gs = self._grad_struct(grads)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -271,6 +280,13 @@ def pack_gradients_split(ctx, grads, num_gaussians, common, rgb):
     gs = RasterContext._grad_struct(grads)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     check(_lib.load().gsplat_pack_gradients_split(ctx._h, ctypes.byref(gs), int(num_gaussians), _ptr(common), _ptr(rgb), st))
+
+
+def pack_gradients_split_range(ctx, grads, num_gaussians, first, end, common, rgb=None):
+    gs = RasterContext._grad_struct(grads)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_lib.load().gsplat_pack_gradients_split_range(ctx._h, ctypes.byref(gs), int(num_gaussians), int(first), int(end),
+                                                        _ptr(common), _ptr(rgb), st))
 
 
 def pack_uv_grad_norm(ctx, grads, num_gaussians, uv_norm):

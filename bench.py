@@ -184,7 +184,9 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
         ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    out = {"N": N, "M": M, "S": S, "num_pairs": fwd["num_pairs"], "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
+    lens = (fwd["ranges"][1:] - fwd["ranges"][:-1])
+    out = {"N": N, "M": M, "S": S, "num_pairs": fwd["num_pairs"], "tile_list_mean": round(float(lens.float().mean().item()), 1),
+           "tile_list_max": int(lens.max().item()), "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
            "preprocess": hbm_entry("preprocess", 288 * M + 13 * N, st["preprocess"][0]),
            "preprocess_backward": hbm_entry("preprocess_backward", 560 * M, st["preprocess_backward"][0])}
     ctx.close()
@@ -305,10 +307,11 @@ def run_rank(args, comm, device_index):
     ctx = raster.RasterContext(N, W, H)
     if world > 1 and do_bwd and want == "auto":
         errors = {}
-        for mode in ("full", "factored", "split"):
+        for mode in ("full", "factored", "split", "split_chunks4"):
             ms_local, err = None, None
             try:  # a payload whose collectives this node's backend rejects is reported and left out, not fatal
-                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode, ctx=ctx, comm=comm)
+                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode.split("_")[0], ctx=ctx, comm=comm,
+                                           chunks=4 if mode.endswith("chunks4") else 1)
                 for _ in range(3):
                     st.step(dc, dgi)
                 torch.cuda.synchronize()
@@ -335,8 +338,9 @@ def run_rank(args, comm, device_index):
             raise RuntimeError(f"no exchange payload works on this node: {errors}")
         want = min(exchange_ms, key=exchange_ms.get)  # the same on every rank: the times were MAX-reduced
         exchange_ms.update({m: "failed: " + msg for m, msg in errors.items()})
-    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want if want != "auto" else "split", ctx=ctx,
-                                 comm=comm)
+    want = want if want != "auto" else "split"
+    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want.split("_")[0], ctx=ctx, comm=comm,
+                                 chunks=4 if want.endswith("chunks4") else None)
 
     def one_step():
         if do_bwd:
@@ -477,7 +481,7 @@ def run_rank(args, comm, device_index):
     extra = None
     if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
         extra = {}
-        for name in ("config3_halfculled", "config3_morton", "dense4m", "bigsplats"):
+        for name in ("config3_halfculled", "config3_morton", "dense4m", "bigsplats", "garden1200k"):
             try:
                 extra[name] = extra_workload(torch, scene, raster, name, dev)
             except Exception as e:  # never lose the headline line to a side measurement
@@ -509,6 +513,11 @@ def run_rank(args, comm, device_index):
                                       "preprocess with all of them stored: preprocess_ms_all_forward_outputs",
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": num_pairs, "scene_seed": scene.SEED},
         "exchange_ms_per_step": exchange_ms or None,
+        # what the exchange of this workload moves and costs on xGMI by the link arithmetic of 3dgs_amd/dist.py
+        # exchange_model (ring / direct bounds per collective), for the payload in use at this world size and for the
+        # 8-rank shape; the driver's measured multi-GPU step times can be checked against it
+        "exchange_model": ({"this_run": gdist.exchange_model(world, N, L, step.exchange, chunks=step.chunks)} if world > 1 else {})
+        | {f"{p}_at_8_ranks": gdist.exchange_model(8, N, L, p) for p in ("full", "factored", "split")},
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},

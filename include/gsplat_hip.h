@@ -331,6 +331,13 @@ int gsplat_backward_render(gsplat_context *ctx, const float *grad_image, float b
                            void *stream);
 int gsplat_backward_gaussians(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
                               int l_max, const gsplat_gradients *out, void *stream);
+/* The per-gaussian chain for the gaussians with GLOBAL index in [first_gaussian, end_gaussian) only (their compacted
+ * slots are contiguous: the compaction keeps the order).  A view-sharded step calls it chunk by chunk and starts the
+ * all-reduce of one chunk's twelve common columns (gsplat_pack_gradients_split_range) while the next chunk is computed;
+ * the union of the chunks is exactly gsplat_backward_gaussians. */
+int gsplat_backward_gaussians_range(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
+                                    int l_max, const gsplat_gradients *out, int first_gaussian, int end_gaussian,
+                                    void *stream);
 
 /* Binning route of the fused forward.  0 (default): automatic -- the LDS counting sort + per-tile depth sort, or, when
  * the previous forward had more than ~768 list entries per tile (dense real scenes) or the tile grid exceeds 16384
@@ -391,6 +398,9 @@ int gsplat_unpack_gradients_factored(const float *xyz, const float *campos_all, 
  * all-reduce of `common` is still in flight), rgb_all == NULL places only the twelve reduced columns. */
 int gsplat_pack_gradients_split(gsplat_context *ctx, const gsplat_gradients *grads, int num_gaussians, float *common,
                                 float *rgb, void *stream);
+/* Rows [first_gaussian, end_gaussian) of `common` (and of `rgb` when given) only: the chunked exchange. */
+int gsplat_pack_gradients_split_range(gsplat_context *ctx, const gsplat_gradients *grads, int num_gaussians,
+                                      int first_gaussian, int end_gaussian, float *common, float *rgb, void *stream);
 int gsplat_unpack_gradients_split(const float *xyz, const float *common, const float *rgb_all, size_t rank_stride,
                                   int l_max, int num_gaussians, int world_size, float *packed, void *stream);
 

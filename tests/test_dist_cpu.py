@@ -186,3 +186,17 @@ def test_thread_ranks_eight_way_collectives_and_schedule():
         gdist.ThreadGroup(world).run(failing)
     lib = pkg("_lib").load()
     assert lib.gsplat_factored_gradient_width(world) == 12 + 3 * world
+
+
+def test_exchange_model_bytes():
+    """The per-rank bytes of DESIGN section 6 (8 ranks, 1e6 gaussians, SH 3): full 420 MB, factored 252 MB, split 168 MB."""
+    gdist = pkg("dist")
+    m = {p: gdist.exchange_model(8, 1_000_000, 3, p) for p in ("full", "factored", "split")}
+    assert abs(m["full"]["sent_bytes_per_rank"] / 1e6 - 420) < 1
+    assert abs(m["factored"]["sent_bytes_per_rank"] / 1e6 - 252) < 1
+    assert abs(m["split"]["sent_bytes_per_rank"] / 1e6 - 168) < 1
+    assert m["split"]["direct_ms"] < m["factored"]["direct_ms"] < m["full"]["direct_ms"]
+    assert m["split"]["ring_ms"] > 5 * m["split"]["direct_ms"]
+    four = gdist.exchange_model(8, 1_000_000, 3, "split", chunks=4)
+    assert abs(four["exposed_direct_ms_after_backward"] * 4 - four["collectives"][1]["direct_ms"]) < 1e-3
+    assert gdist.exchange_model(1, 1000, 3, "split")["sent_bytes_per_rank"] == 0

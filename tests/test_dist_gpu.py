@@ -19,6 +19,41 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=None):
+    """The chunked exchange (per-gaussian backward in ranges of global indices, one all-reduce per range started while
+    the next range is computed) against the single all-reduce ON THE SAME compositing-backward rows: identical packed
+    rows and |grad_uv| sums -- bit for bit where the sum over the ranks is formed in the same order either way (two
+    ranks, rank threads), to rounding otherwise."""
+    step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange="split", with_uv_norm=True, comm=comm, chunks=5)
+    assert len(step.chunk_bounds()) == 5 and step.chunk_bounds()[-1][1] == step.N
+    step.step(cam, gi)
+    torch.cuda.synchronize()
+    chunked, uv_chunked = step.packed.clone(), step.uv_norm_sum.clone()
+    grads_chunked = {k: v.clone() for k, v in step.grads.items()}
+    # the same rows once more, unchunked (the context still holds this forward's compositing-backward result)
+    step.chunks = 1
+    for v in step.grads.values():
+        v.fill_(float("nan"))
+    step.ctx.backward_gaussians(step.params, cam, L, step.grads)
+    step.exchange_gradients(cam)
+    torch.cuda.synchronize()
+    M = step.ctx._last[1]
+    for k, v in step.grads.items():
+        a, b = grads_chunked[k][:M], v[:M]
+        assert torch.equal(a, b), f"per-view grad_{k}: the ranges do not add up to the whole backward"
+    if step.world <= 2 or comm is not None:
+        assert torch.equal(chunked, step.packed), "chunked exchange differs from the single all-reduce"
+        assert torch.equal(uv_chunked, step.uv_norm_sum)
+    else:
+        # more than two rank processes: the backend forms a ring's sums in an order that depends on where an element
+        # sits in the message, so ranges and the whole buffer may round differently -- every replica still receives
+        # the same bits (checked by the caller), which is what the training loop relies on
+        scale = step.packed.abs().max().item()
+        assert (chunked - step.packed).abs().max().item() <= 1e-5 * scale
+        assert torch.allclose(uv_chunked, step.uv_norm_sum, rtol=1e-5, atol=1e-12)
+    return chunked.cpu().numpy()
+
+
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -43,6 +78,7 @@ def _worker(rank, world, port, out_dir):
         step.step(cam, gi)  # twice: buffers are reused
         torch.cuda.synchronize()
         out[ex] = step.packed.cpu().numpy().copy()
+    out["chunked"] = _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -55,12 +91,12 @@ def test_view_sharded_step_two_ranks_one_gpu(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
-    for ex in ("split", "factored", "full"):
+    for ex in ("split", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
     full = r[0]["full"]
     scale = np.abs(full).mean()
-    for ex in ("split", "factored"):
+    for ex in ("split", "factored", "chunked"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()  # views that saw each gaussian
@@ -167,15 +203,17 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
             torch.cuda.synchronize()
             out[ex] = step.packed.cpu().numpy().copy()
             comm.barrier()
+        out["chunked"] = _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=comm)
+        comm.barrier()
         return out
 
     r = gdist.ThreadGroup(world).run(body)
-    for ex in ("split", "factored", "full"):
+    for ex in ("split", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
     full = r[0]["full"]
     scale = np.abs(full).mean()  # (each payload ran its own backward: float atomics, so payloads agree to rounding only)
-    for ex in ("split", "factored"):
+    for ex in ("split", "factored", "chunked"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()
@@ -265,6 +303,7 @@ def test_bench_launches_its_own_ranks(world, threads):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == world and line["config"]["views_per_step"] == world and line["scaling"] == "weak"
     assert line["config"]["backend"] == ("threads" if threads else "gloo")
-    assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split"}
+    assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split", "split_chunks4"}
+    assert line["exchange_model"]["this_run"]["world"] == world and "split_at_8_ranks" in line["exchange_model"]
     assert line["config"]["exchange"].split(":")[0] in ("full", "factored", "split")
     assert line["value"] > 0 and line["steps"] == 4

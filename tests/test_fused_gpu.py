@@ -343,6 +343,45 @@ def test_lean_forward_and_compacted_walk_change_nothing(gpu, scene, orc):
         assert (_np(third["image"]) == a["image"]).all()
 
 
+def test_backward_in_ranges_of_global_indices(gpu, scene):
+    """gsplat_backward_gaussians_range over any partition of [0, N) -- uneven, with an empty range and a range whose
+    gaussians are all culled -- writes exactly what gsplat_backward_gaussians writes, and the rows of `common` packed
+    range by range are the rows packed at once (the chunked exchange of a view-sharded step)."""
+    torch, raster = gpu, pkg("raster")
+    N, W, H, L = 6000, 200, 120, 3
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::3, 2] *= -1.0
+    params["xyz"][2000:3100, 2] = -np.abs(params["xyz"][2000:3100, 2])  # a whole range behind the camera
+    cam = scene.make_camera(W, H, 1)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    M = fwd["num_culled"]
+    ctx.backward_render(torch.as_tensor(scene.make_grad_image(W, H)).cuda(), c["bg"])
+    whole = ctx.alloc_gradients(N, L, intermediates=True)
+    parts = ctx.alloc_gradients(N, L, intermediates=True)
+    for g in list(whole.values()) + list(parts.values()):
+        g.fill_(float("nan"))
+    ctx.backward_gaussians(dp, dc, L, whole)
+    bounds = [0, 1, 1, 700, 2000, 3100, 3163, 5999, N]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ctx.backward_gaussians_range(dp, dc, L, parts, lo, hi)
+    torch.cuda.synchronize()
+    for k in whole:
+        assert torch.isfinite(whole[k][:M]).all(), k
+        assert torch.equal(whole[k][:M], parts[k][:M]), f"grad_{k}: the ranges do not add up to the whole backward"
+    common_a = torch.full((N, 12), float("nan"), device="cuda")
+    common_b = torch.full((N, 12), float("nan"), device="cuda")
+    raster.pack_gradients_split(ctx, whole, N, common_a, None)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        raster.pack_gradients_split_range(ctx, parts, N, lo, hi, common_b, None)
+    assert torch.equal(common_a, common_b)
+    assert (common_a[2000:3100] == 0).all() and (common_a[:, 11].sum().item() == M)
+    with pytest.raises(pkg("_lib").GsplatError):
+        ctx.backward_gaussians_range(dp, dc, L, parts, 10, N + 1)
+
+
 def test_repeatable_forward_and_linear_backward(gpu, scene):
     """Idempotence: same inputs -> bit-identical forward.  Linearity: backward(2*g) == 2*backward(g) up to the
     float-atomic summation order."""
