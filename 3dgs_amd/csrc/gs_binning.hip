@@ -198,6 +198,49 @@ __device__ __forceinline__ void bitonic_sort_block(Buf p, int len, int n2, int t
   __syncthreads();
 }
 
+// Merging the register-sorted runs of a long list in LDS (r03).  `p` holds ceil(len / run) sorted runs of `run` entries
+// (the last one shorter); the runs are merged pairwise, level by level.  At each level a thread owns kPer consecutive
+// OUTPUT positions: it finds where they start in the two runs of its pair (merge path: a binary search along the
+// diagonal i + j = position -- payloads are unique inside a tile, so the split is unique), merges its kPer entries
+// sequentially into registers, and after a barrier writes them back in place.  Per level and entry that is ~3 LDS
+// reads and one write behind two barriers; the bitonic merge levels this replaces (11 to 14 compare-exchange steps per
+// level, each with its own barrier) cost 40 of the 90 us a 16-run list kept its workgroup busy.
+template <int kThreads, int kPer, typename Buf>
+__device__ __forceinline__ void merge_sorted_runs(Buf p, int len, int run, int tid) {
+  for (int w = run; w < len; w <<= 1) {
+    unsigned long long out[kPer];
+    const int o = tid * kPer;  // first output position of this thread
+    if (o < len) {
+      const int pair_lo = (o / (2 * w)) * (2 * w);                   // this pair's A = [pair_lo, a_end), B = [a_end, b_end)
+      const int a_end = min(pair_lo + w, len), b_end = min(pair_lo + 2 * w, len);
+      const int na = a_end - pair_lo, nb = b_end - a_end, d = o - pair_lo;  // d = i + j on the merge path
+      int lo = max(0, d - nb), hi = min(d, na);                       // i in [lo, hi]
+      while (lo < hi) {  // smallest i with A[i] > B[d - 1 - i]  (i.e. everything before the split is smaller)
+        const int i = (lo + hi) >> 1;
+        if (p[pair_lo + i] < p[a_end + (d - 1 - i)]) lo = i + 1; else hi = i;
+      }
+      int i = lo, j = d - lo;
+      unsigned long long a = i < na ? p[pair_lo + i] : ~0ull, b = j < nb ? p[a_end + j] : ~0ull;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const bool take_a = a < b;  // an exhausted run reads as ~0: a payload never is (its depth bits would be NaN)
+        out[k] = take_a ? a : b;
+        if (take_a) { ++i; a = i < na ? p[pair_lo + i] : ~0ull; }
+        else { ++j; b = j < nb ? p[a_end + j] : ~0ull; }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (o < len) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k)
+        if (o + k < len) p[o + k] = out[k];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 // One WAVE per tile, keys in registers: lane L holds the E consecutive entries L*E .. L*E+E-1 of the (virtually
 // +infinity padded) list.  Comparators whose operands sit in the same lane are plain register compare-exchanges;
 // the others fetch the partner lane's entry with a wave shuffle (ds_bpermute: no LDS storage, no bank conflicts) and
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
       }
       __syncthreads();
       if (len > kWaveSortMax && s_runs_ok) {
-        bitonic_sort_block<true, kThreads>(buf, len, n2, tid, 2 * kWaveSortMax);
+        merge_sorted_runs<kThreads, kLds / kThreads>(buf, len, kWaveSortMax, tid);
       } else {
         __syncthreads();
         for (int i = tid; i < len; i += kThreads) buf[i] = payload[start + i];

@@ -44,9 +44,6 @@
 #ifndef GS_EXTRA_FMA
 #define GS_EXTRA_FMA 0
 #endif
-#ifndef GS_FWD_PREFETCH
-#define GS_FWD_PREFETCH 0
-#endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
@@ -188,22 +185,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   unsigned long long satmask = __ballot(!inside);  // lanes whose pixel is saturated or outside the image
   int live = satmask != ~0ull ? 1 : 0;
 
-#if GS_FWD_PREFETCH
-  // experiment (r03): the dependent pair of global loads of the staging (sorted id -> 48-byte record) leaves the
-  // critical path: the record of the NEXT batch is requested before the compositing loop of the current one, its id
-  // one batch earlier still.  All of these loads are unconditional (indices clamped into the list, the instance
-  // buffers hold one entry more than S): a load under a branch ends in register copies, and the copies in a wait.
-  constexpr bool kPrefetch = kPacked;
-  int id_next = 0;
-  SplatRec pre;
-  if constexpr (kPrefetch) {
-    const int last = max(total - 1, 0);
-    pre = load_record<true>(sorted[start + min(tid, last)], recs, raw);
-    id_next = sorted[start + min(kBatch + tid, last)];
-  }
-#else
-  [[maybe_unused]] constexpr bool kPrefetch = false;
-#endif
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
     // an opaque per-batch copy of the thread index (see render_bwd_kernel): staging and list-building addresses are
@@ -217,12 +198,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     __syncthreads();
     GS_LAP(st_bar);
     if (t < count) {
-      SplatRec s;
-#if GS_FWD_PREFETCH
-      if constexpr (kPrefetch) s = pre;
-      else
-#endif
-        s = load_record<kPacked>(sorted[start + base + t], recs, raw);
+      const int g = sorted[start + base + t];
+      SplatRec s = load_record<kPacked>(g, recs, raw);
 #if GS_STAMP
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // split the staging stamp: loads | block test + LDS stores
       asm volatile("" : "+v"(s.r0.x), "+v"(s.r1.x), "+v"(s.r2.x));
@@ -237,12 +214,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     GS_LAP(st_stage);
     __syncthreads();
     GS_LAP(st_bar1);
-#if GS_FWD_PREFETCH
-    if constexpr (kPrefetch) {
-      pre = load_record<true>(id_next, recs, raw);
-      id_next = sorted[start + min(base + 2 * kBatch + tid, max(total - 1, 0))];
-    }
-#endif
     if (live > 0) {
       // rows whose 16 pixels are all saturated (or outside) need no list
       const int big = kBatch;
