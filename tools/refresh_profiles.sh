@@ -1,10 +1,12 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>   e.g. r02
+# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh <tag>   e.g. r03
 # bench line, rocprofv3 kernel-trace summary of the same command, and the PMC passes (counters in their own runs, never
 # combined with tracing); everything lands under gpurun_out/<tag>_*, from where the summaries are copied to profiles/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
+python -c "import importlib; importlib.import_module('3dgs_amd._lib').build()"   # once, before anything touches the GPU
+export GSPLAT_NO_BUILD=1
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 export GSPLAT_BENCH_TRAIN_STEP=0   # the profiled runs: the headline workload's kernels only
 cd /tmp && export TMPDIR=/tmp
