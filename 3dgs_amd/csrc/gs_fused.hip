@@ -360,6 +360,11 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
     const gs::RotScale rs = gs::rot_scale(q.x, q.y, q.z, q.w, g.scale[3 * i], g.scale[3 * i + 1], g.scale[3 * i + 2]);
     float sg[6], J[6], con[3], rad[4];
     gs::sigma_from(rs, sg);
+    if constexpr (kStoreMid) {  // each of the four as soon as it exists: all of them pending at once cost spilled registers
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o.sigma[6 * j + k] = sg[k];
+      o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
+    }
     // camera-space position and pixel coordinates: recomputed with project_cull_kernel's functions on the same inputs
     // (bit for bit its values) from a second, cache-resident read of the position, instead of a 20-byte round trip
     // through the uncompacted arrays
@@ -378,9 +383,8 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
     o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
     if constexpr (kStoreMid) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { o.sigma[6 * j + k] = sg[k]; o.J[6 * j + k] = J[k]; }
+      for (int k = 0; k < 6; ++k) o.J[6 * j + k] = J[k];
       o.conic[3 * j] = con[0]; o.conic[3 * j + 1] = con[1]; o.conic[3 * j + 2] = con[2];
-      o.rgb[3 * j] = rgb[0]; o.rgb[3 * j + 1] = rgb[1]; o.rgb[3 * j + 2] = rgb[2];
     }
     reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
     const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], g.opacity[i], rgb[0], rgb[1], rgb[2]);
