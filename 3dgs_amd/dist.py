@@ -100,6 +100,7 @@ class ThreadGroup:
         self._barrier = threading.Barrier(self.world)
         self._slots = [None] * self.world
         self._result = None
+        self.shared = {}  # for the ranks' own bookkeeping (bench.py: votes on an exchange payload); guard it with barrier()
 
     def comm(self, rank):
         return ThreadComm(self, rank)

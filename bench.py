@@ -108,10 +108,10 @@ def agree_on_payload(comm, mode, ok, timeout_s=120.0):
     launcher / torchrun then ends the other ranks) instead of limping on with mismatched collectives."""
     rank, world = comm.rank, comm.world
     if comm.backend() == "threads":  # in-process ranks: a shared table; a rank that died has broken the barrier
-        votes = comm.group.__dict__.setdefault("_votes", {})
-        votes[(mode, rank)] = ok
+        votes = comm.group.shared
+        votes[("exchange", mode, rank)] = ok
         comm.barrier()
-        got = [votes[(mode, r)] for r in range(world)]
+        got = [votes[("exchange", mode, r)] for r in range(world)]
         if all(got) or not any(got):
             return all(got)
         raise RuntimeError(f"payload '{mode}' failed on some ranks only: {got}")

@@ -22,7 +22,11 @@
  * (cuda/trainer.cu:247-261).  Operators may use library-owned scratch memory that is
  * grown on demand and released by gsplat_release_scratch().
  *
- * Threading: one host thread per device at a time (the reference's trainer thread).
+ * Threading: the stand-alone operators are written for one host thread per device at a time (the reference's trainer
+ * thread).  A gsplat_context is used by one thread at a time; different contexts may be driven by different threads
+ * of one process on the same stream (several in-process ranks, 3dgs_amd/dist.py ThreadGroup): the entry points that
+ * touch the library-owned scratch (gsplat_fused_loss, gsplat_compute_psnr, gsplat_compact/scatter_masked_array,
+ * gsplat_get_sorted_gaussian_list, gsplat_initialize_gaussians, gsplat_knn_mean_distance) serialise on a lock.
  */
 #ifndef GSPLAT_HIP_H
 #define GSPLAT_HIP_H
