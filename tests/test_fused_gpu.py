@@ -421,6 +421,15 @@ def test_full_size_properties_and_parity(gpu, scene, orc):
     _full_size_bookkeeping(fwd, ref, W, H, "config3")
     bref = orc.backward_pass(ref, r["cam"], r["gi"], c["bg"], r["L"], threads=16)
     _check_backward(r["grads"], bref)
+    # the lean forward the benchmark times (no Sigma / J / conic / colour stores, positions recomputed): the same bits
+    keep = {k: _np(fwd[k]).copy() for k in ("radius", "sorted", "ranges", "image", "T", "n")}
+    r["ctx"].set_lean_forward(True)
+    lean = r["ctx"].rasterize_image(r["dp"], r["dc"], c, c["bg"], r["L"])
+    for k, v in keep.items():
+        assert (_np(lean[k]) == v).all(), f"{k}: the lean forward differs at full size"
+    g2 = r["ctx"].alloc_gradients(lean["num_culled"], r["L"])
+    r["ctx"].backward_pass(r["dp"], r["dc"], torch.as_tensor(r["gi"]).cuda(), c["bg"], r["L"], g2)
+    _check_backward(g2, bref)
 
 
 def test_pack_gradients_global_layout(gpu, scene):
@@ -652,6 +661,16 @@ def test_interleaved_culling_at_scale(gpu, scene, orc):
     _check_backward(grads, bref)
     for k in ("conic", "uv", "J", "sigma", "xyz_c"):
         assert_grad_close(_np(grads[k]), bref[k], "intermediate grad_" + k)
+    # the same view again: this forward walks the compacted slots (the previous one culled more than a fifth), lean too
+    keep = {k: _np(fwd[k]).copy() for k in ("compact_to_global", "radius", "sorted", "ranges", "image", "T", "n")}
+    ctx.set_lean_forward(True)
+    again = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    for k, v in keep.items():
+        assert (_np(again[k]) == v).all(), f"{k}: compacted, lean walk differs from the walk over all indices"
+    assert again["sigma"] is None and again["num_splats"] == fwd["num_splats"]
+    g2 = ctx.alloc_gradients(again["num_culled"], L)
+    ctx.backward_pass(dp, dc, torch.as_tensor(gi).cuda(), c["bg"], L, g2)
+    _check_backward(g2, bref)
 
 
 @pytest.mark.parametrize("splat_scale", [6.0, 25.0])
