@@ -305,17 +305,21 @@ def test_lean_forward_and_compacted_walk_change_nothing(gpu, scene, orc):
     bref = orc.backward_pass(ref, cam, scene.make_grad_image(W, H), c["bg"], L, threads=8)
     keys = ("mask", "compact_to_global", "xyz_c", "uv", "radius", "sorted", "ranges", "image", "T", "n")
     mids = ("sigma", "J", "conic", "rgb")
-    for lean in (False, True):
+    for lean, route in ((False, 1), (True, 1), (False, 2), (True, 2)):  # route 2: the radix sorts (scan of counts[0..N])
         ctx = raster.RasterContext(N, W, H)
         ctx.set_lean_forward(lean)
+        ctx.set_binning_route(route)
         first = ctx.rasterize_image(dp, dc, c, c["bg"], L)          # walks all indices (no previous forward)
         assert first["num_culled"] < 0.8 * N
         if not lean:
             _check_forward(first, ref)
         a = {k: _np(first[k]).copy() for k in keys + (() if lean else mids)}
-        if not lean:
+        if not lean and route == 1:
             full = a
+        if not lean:
             assert first["uv_all"] is not None and first["xyz_c_all"] is not None
+            for k in keys:
+                assert (a[k] == full[k]).all(), f"{k}: binning route {route} differs from route 1"
         else:  # the lean forward recomputes positions instead of reading them back: the same bits
             for k in keys:
                 assert (a[k] == full[k]).all(), f"{k}: lean forward differs from the full one"
