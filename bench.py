@@ -448,26 +448,27 @@ def run_rank(args, comm, device_index):
     if valu_insts and dom_ms > 0:
         ginst = valu_insts / (dom_ms * 1e-3) / 1e9
         # r03 slope experiment (profiles/r03_valu_slope.txt, tools/experiments/r03_valu_slope.sh): k extra independent
-        # v_fma_f32 per trip of render_bwd's loop cost +3.5 us per instruction (k = 4, 8, 16: +16.4, +29.8, +56.2 us on
-        # 339.8 us), i.e. 3.77 M trips / 1024 SIMDs x 2.09 cycles at the kernel's 2.2 GHz: the FULL nominal issue cost
-        # of the guide's table (2 cycles per wave64 VALU instruction per SIMD) -- nothing of an added instruction hides,
-        # so the loop is issue bound; removing the 22-instruction row reduction and its LDS atomic took -134 us = 3.6
-        # cycles per instruction (DPP operands, selects).  frac_at_measured_issue_cost prices every VALU instruction of
-        # the launch at the measured plain cost (a lower bound: DPP / transcendental / 64-bit instructions cost more).
-        cyc_plain, clock_ghz, simds = 2.09, 2.2, 1024
+        # v_fma_f32 per trip of render_bwd's loop cost +3.51 us per instruction (k = 4, 8, 16: +16.4, +29.8, +56.2 us on
+        # 339.8 us), i.e. 3.61 M wave trips / 1024 SIMDs x 2.2 cycles at the kernel's 2.23 GHz: the FULL nominal issue
+        # cost of the guide's table (2 cycles per wave64 VALU instruction per SIMD) plus a tenth -- nothing of an added
+        # instruction hides, so the loop is issue bound; removing the 22-instruction row reduction and its LDS atomic took
+        # -134 us = 3.9 cycles per instruction (DPP operands, selects).  frac_at_measured_issue_cost prices every VALU
+        # instruction of the launch at the measured plain cost (a lower bound: DPP / transcendental / 64-bit cost more).
+        cyc_plain, clock_ghz, simds = 2.2, 2.23, 1024
         busy_ms = valu_insts * cyc_plain / simds / (clock_ghz * 1e6)
         roofline_valu = {"kernel": dom, "bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST,
                          "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST,
                          "valu_instructions_per_launch": valu_insts,
                          "measured_issue_cost": {"plain_valu_cycles_per_instruction_per_simd": cyc_plain,
-                                                 "row_reduction_block_cycles_per_instruction": 3.6,
+                                                 "row_reduction_block_cycles_per_instruction": 3.9,
+                                                 "wave_trips_per_launch": 3606560,
                                                  "kernel_clock_ghz": clock_ghz,
                                                  "source": "profiles/r03_valu_slope.txt (same-box A/B, 300 steps, two rounds)"},
                          "frac_at_measured_issue_cost": busy_ms / dom_ms,
                          "note": "achieved = SQ_INSTS_VALU per launch (profiles/traffic.json, same sources) / live launch "
                                  "duration; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 v_fma_f32 "
-                                 "(MI355X_MICROARCH.md); frac_at_measured_issue_cost = instructions x 2.09 cycles / "
-                                 "(1024 SIMDs x 2.2 GHz x launch duration), every instruction at the plain-FMA cost "
+                                 "(MI355X_MICROARCH.md); frac_at_measured_issue_cost = instructions x 2.2 cycles / "
+                                 "(1024 SIMDs x 2.23 GHz x launch duration), every instruction at the plain-FMA cost "
                                  "the slope experiment measured"}
 
     # ---- forward-only rate (render fps), outside the timed region
