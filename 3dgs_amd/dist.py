@@ -54,19 +54,19 @@ class TorchComm:
     tests and the one-GPU rehearsals); a single process is a group of one."""
 
     def __init__(self):
-        on = dist.is_initialized()
-        self.world = dist.get_world_size() if on else 1
-        self.rank = dist.get_rank() if on else 0
+        self.on = dist.is_initialized()  # a group of ONE still goes through the backend (tools/nccl_one_rank.py)
+        self.world = dist.get_world_size() if self.on else 1
+        self.rank = dist.get_rank() if self.on else 0
 
     def all_reduce(self, t, async_op=False):
-        if self.world == 1:
+        if not self.on:
             return _Done()
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op) or _Done()
 
     def all_gather_blocks(self, out, block, async_op=False):
         """out[world, ...] <- every rank's `block`.  One collective; RCCL/NCCL gathers straight into the contiguous
         buffer, gloo (CPU tests, single-GPU rehearsal) takes the list form."""
-        if self.world == 1:
+        if not self.on:
             out[0].copy_(block)
             return _Done()
         if dist.get_backend() == "nccl":
@@ -74,11 +74,11 @@ class TorchComm:
         return dist.all_gather(list(out.unbind(0)), block, async_op=async_op) or _Done()
 
     def barrier(self):
-        if self.world > 1:
+        if self.on:
             dist.barrier()
 
     def all_reduce_max(self, t):
-        if self.world > 1:
+        if self.on:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t
 

@@ -37,6 +37,20 @@ torch.cuda.synchronize()
 err = (packed - full).abs().max().item(); scale = full.abs().max().item()
 print(f"split exchange over nccl, one rank: max abs diff {err:.3e} (scale {scale:.3e})")
 assert err <= 1e-6 * max(scale, 1e-30) + 1e-12, "split exchange differs from the full rows"
+# the chunked backward: one all-reduce per range of global indices, started behind that range (async handles on RCCL)
+step.chunks = 4
+step.ctx.backward_render(gi, cfg["bg"], step.rgb)
+step._rgb_gather = gdist.all_gather_blocks(step.rgb_all, step.rgb, async_op=True)
+step.backward_gaussians_chunked(cam)
+assert len(step._chunk_reduces) == 4
+chunked = step.exchange_gradients(cam).clone()
+torch.cuda.synchronize()
+step.ctx.pack_gradients_global(step.grads, L, N, full)  # the full rows of THIS backward (float atomics: not the first one's bits)
+dist.all_reduce(full)
+torch.cuda.synchronize()
+err = (chunked - full).abs().max().item()
+print(f"chunked split exchange over nccl, one rank: max abs diff {err:.3e}")
+assert err <= 1e-6 * max(scale, 1e-30) + 1e-12, "chunked exchange differs from the full rows"
 dist.barrier()
 dist.destroy_process_group()
 print("nccl one-rank rehearsal: ok")
