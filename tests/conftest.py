@@ -41,6 +41,20 @@ def gpu():
     return torch
 
 
+@pytest.fixture(scope="session")
+def config3_case(scene, orc):
+    """BASELINE configs[2] (1e6 gaussians, 1920x1080, SH 3, view 0) with the oracle's forward and backward, computed once
+    per session (about 25 s on the box's 16 host threads) and shared by every full-size parity test."""
+    N, W, H, L, _ = scene.WORKLOADS["config3"]
+    c = scene.CONFIG
+    params = scene.make_gaussians(N, W, H, L)
+    cam = scene.make_camera(W, H, 0)
+    gi = scene.make_grad_image(W, H)
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=16)
+    bref = orc.backward_pass(ref, cam, gi, c["bg"], L, threads=16)
+    return dict(N=N, W=W, H=H, L=L, params=params, cam=cam, gi=gi, ref=ref, bref=bref)
+
+
 # ---------------------------------------------------------------- comparison helpers (tolerances live here)
 PIXEL_L1_TOL = 1e-4      # north_star: rendered pixels within 1e-4 per-pixel L1
 GRAD_REL_TOL = 1e-3      # north_star: gradients within 1e-3 relative

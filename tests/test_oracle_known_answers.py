@@ -135,6 +135,76 @@ def test_sh_basis_l3_is_orthonormal(orc):
     np.testing.assert_allclose(gram, np.eye(16), atol=1e-7)
 
 
+def _scipy_real_sh(pts, l_max=3):
+    """Real orthonormal spherical harmonics without the Condon-Shortley phase, index l*l + l + m -- sphericart's
+    published convention (the reference calls sphericart::cuda::SphericalHarmonics, cuda/spherical_harmonics.cu:72,89;
+    the submodule is not vendored) -- built from scipy's complex Y_l^m, which carry the phase:
+    m > 0: sqrt(2) (-1)^m Re Y_l^m,  m < 0: sqrt(2) (-1)^m Im Y_l^|m|,  m = 0: Y_l^0."""
+    from scipy.special import sph_harm_y
+    pts = np.asarray(pts, np.float64)
+    r = np.linalg.norm(pts, axis=-1)
+    theta, phi = np.arccos(pts[..., 2] / r), np.arctan2(pts[..., 1], pts[..., 0])
+    Y = np.zeros(pts.shape[:-1] + ((l_max + 1) ** 2,))
+    for l in range(l_max + 1):
+        for m in range(-l, l + 1):
+            c = sph_harm_y(l, abs(m), theta, phi)
+            v = c.real if m == 0 else np.sqrt(2.0) * (-1) ** m * (c.real if m > 0 else c.imag)
+            Y[..., l * l + l + m] = v
+    return Y
+
+
+def test_sh_basis_all_16_functions_match_scipy(orc):
+    """The pin for the l = 3 block (and once more for l <= 2): every basis function of the oracle against
+    scipy.special.sph_harm_y with the Condon-Shortley phase removed, index l^2 + l + m.  The residual is the 1e-9 the
+    reference adds to the direction's norm (cuda/spherical_harmonics.cu:8-26)."""
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(200, 3)) * rng.uniform(0.2, 30.0, size=(200, 1))
+    want = _scipy_real_sh(pts)
+    got = np.zeros_like(want)
+    for k in range(16):  # isolate basis k with one-hot coefficients
+        band0 = np.zeros((len(pts), 3))
+        sh = np.zeros((len(pts), 15, 3))
+        if k == 0:
+            band0[:, 0] = 1
+        else:
+            sh[:, k - 1, 0] = 1
+        got[:, k] = orc.precompute_spherical_harmonics(pts, sh, band0, [0, 0, 0], 3, dtype=F64)[:, 0] - 0.5
+    assert np.abs(got - want).max() < 2e-8, np.abs(got - want).max(axis=0)
+    # and through a camera position, in float32 (what the parity checker runs)
+    campos = np.array([0.3, -0.2, 0.1])
+    coef = rng.normal(size=(len(pts), 16, 3))
+    rgb32 = orc.precompute_spherical_harmonics(pts, coef[:, 1:], coef[:, 0], campos, 3)
+    want32 = 0.5 + np.einsum("nk,nkc->nc", _scipy_real_sh(pts - campos), coef)
+    np.testing.assert_allclose(rgb32, want32, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("l_max", [1, 2, 3])
+def test_sh_backward_matches_scipy(orc, l_max):
+    """Per-coefficient sh_grad (= rgb_grad x Y_k: unpinned by the reference's tests for every l) against the scipy basis,
+    and the position gradient against central differences of the scipy colour (cuda/spherical_harmonics_backward.cu:
+    168-209 reads sphericart's derivative buffer; the reference's own test checks it by finite differences too)."""
+    rng = np.random.default_rng(5 + l_max)
+    M, n = 40, (l_max + 1) ** 2
+    pts = rng.normal(size=(M, 3)) * rng.uniform(0.5, 10.0, size=(M, 1))
+    campos = np.array([0.25, 0.1, -0.4])
+    coef = rng.normal(size=(M, n, 3))
+    g = rng.normal(size=(M, 3))
+    sh_g, b0_g, x_g = orc.precompute_spherical_harmonics_backward(pts, coef[:, 0], coef[:, 1:], campos, g, l_max, dtype=F64)
+    Y = _scipy_real_sh(pts - campos, l_max)
+    np.testing.assert_allclose(b0_g, g * Y[:, :1], atol=1e-8)
+    np.testing.assert_allclose(sh_g.reshape(M, n - 1, 3), Y[:, 1:, None] * g[:, None, :], atol=2e-8)
+
+    def loss(p):
+        return (g * (0.5 + np.einsum("nk,nkc->nc", _scipy_real_sh(p - campos, l_max), coef))).sum(-1)
+
+    fd = np.zeros((M, 3))
+    for a in range(3):
+        e = np.zeros(3)
+        e[a] = 1e-5
+        fd[:, a] = (loss(pts + e) - loss(pts - e)) / 2e-5
+    np.testing.assert_allclose(x_g, fd, rtol=1e-5, atol=1e-7)
+
+
 def _expected_color(px, py, uv, opacity, conic, rgb, bg):  # cuda_forward_test.cpp:705-744
     r = g = b = bg
     acc = 0.0
