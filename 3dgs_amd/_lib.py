@@ -43,6 +43,23 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_cpp_host(name):
+    """Compile tests/cpp/<name>.cpp -- a host program written against the drop-in headers (include/gsplat_cuda/*.cuh) --
+    and link it with the library; returns the executable's path.  Rebuilt when the source, a header or the library is
+    newer.  Used by the tests, by bench.py's reference_host_path leg and by __graft_entry__.build()."""
+    root = os.path.normpath(os.path.join(_HERE, ".."))
+    lib = build()
+    src = os.path.join(root, "tests", "cpp", name + ".cpp")
+    exe = os.path.join(root, "tests", "cpp", name)
+    inc = os.path.join(root, "include", "gsplat_cuda")
+    deps = [src, lib, os.path.join(root, "include", "gsplat_hip.h")] + [os.path.join(inc, h) for h in os.listdir(inc)]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in deps):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", "-I",
+                               os.path.join(root, "include"), src, "-x", "none", lib, "-Wl,-rpath," + os.path.dirname(lib),
+                               "-o", exe])
+    return exe
+
+
 def source_hash():
     """sha256 (first 16 hex digits) over the device sources the library is built from: ties a stored profile
     (profiles/traffic.json) to the code it was measured on."""
@@ -99,14 +116,20 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
-ABI_VERSION = 3  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
+ABI_VERSION = 4  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 SIGNATURES = {
     "gsplat_last_error": (ctypes.c_char_p, []),
     "gsplat_abi_version": (_I, []),
+    "gsplat_source_hash": (ctypes.c_char_p, []),
+    "gsplat_build_flags": (ctypes.c_char_p, []),
     "gsplat_release_scratch": (_I, []),
+    "gsplat_pool_alloc": (_I, [ctypes.POINTER(ctypes.c_void_p), _S]),
+    "gsplat_pool_free": (_I, [_P]),
+    "gsplat_pool_release": (_I, []),
+    "gsplat_pool_bytes": (_S, [_I]),
     "gsplat_compute_camera_space_points": (_I, [_P, _P, _I, _P, _P]),
     "gsplat_project_to_screen": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "gsplat_cull_gaussians": (_I, [_P, _P, _I, _F, _I, _I, _I, _P, _P]),
@@ -154,6 +177,7 @@ SIGNATURES = {
                                   ctypes.POINTER(Gradients), _P]),
     "gsplat_context_set_render_only": (_I, [_P, _I]),
     "gsplat_context_set_lean_forward": (_I, [_P, _I]),
+    "gsplat_context_get_counters": (_I, [_P, ctypes.POINTER(ctypes.c_longlong), _I]),
     "gsplat_context_set_timing": (_I, [_P, _I]),
     "gsplat_context_set_timing_stages": (_I, [_P, ctypes.c_uint]),
     "gsplat_context_get_timing": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), _I]),
@@ -199,8 +223,30 @@ def load():
     got = lib.gsplat_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"libgsplat_hip.so reports ABI {got}, this binding expects {ABI_VERSION}: stale library")
+    # The binary says what it was built from (gsplat_source_hash).  A loader that did not build it -- GSPLAT_NO_BUILD
+    # (rank processes, runs under rocprofv3) or a GSPLAT_LIB variant -- may be looking at a library older than, or
+    # deliberately different from, the sources next to it: say so once, and let library_matches_sources() keep stored
+    # profiles (profiles/traffic.json) from being attached to it.
+    built_from, flags = lib.gsplat_source_hash().decode(), lib.gsplat_build_flags().decode()
+    if built_from != source_hash() or flags:
+        import sys
+        print(f"[3dgs_amd] NOTE: {path} was built from sources {built_from}"
+              + (f" with extra flags '{flags}'" if flags else "") + f"; the sources here hash to {source_hash()}",
+              file=sys.stderr, flush=True)
     _lib = lib
     return lib
+
+
+def library_source_hash():
+    """The source hash the LOADED binary carries (gsplat_source_hash), with its extra build flags appended when it is a
+    diagnostic build: equals source_hash() exactly when the library was built from the sources next to it."""
+    lib = load()
+    flags = lib.gsplat_build_flags().decode()
+    return lib.gsplat_source_hash().decode() + (("+" + flags) if flags else "")
+
+
+def library_matches_sources():
+    return library_source_hash() == source_hash()
 
 
 def check(status):

@@ -559,6 +559,21 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
   struct Class { int cls; size_t per; };
   const Class classes[3] = {{0, 2}, {1, 4}, {2, 8}};
   bool forked[3] = {false, false, false};
+  // Whatever path leaves this function after a fork -- a failed launch of a later kernel included -- `st` first waits for
+  // the side streams: the caller may re-reserve or re-run the forward as soon as it sees the error, and the forked
+  // kernels are still writing `payload` / `sorted_out`.
+  struct JoinForks {
+    const SortFork *fork; hipStream_t st; bool *forked;
+    ~JoinForks() {
+      for (int k = 0; k < 3; ++k)
+        if (forked[k]) { (void)hipStreamWaitEvent(st, fork->ev_join[k], 0); forked[k] = false; }
+    }
+    int join() {  // the normal exit: the same waits, with their status
+      for (int k = 0; k < 3; ++k)
+        if (forked[k]) { forked[k] = false; GS_HIP(hipStreamWaitEvent(st, fork->ev_join[k], 0)); }
+      return GSPLAT_OK;
+    }
+  } joiner{fork, st, forked};
   auto launch_class = [&](int k, hipStream_t s) {
     const int cap = (int)std::min<size_t>((size_t)num_tiles, S / (classes[k].per * (size_t)kWaveSortMax));
     if (k == 0) tile_depth_sort_kernel<4><<<std::min(cap, 5 * 256), 256, 0, s>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
@@ -578,9 +593,12 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
         if (wanted(k)) {
           GS_HIP(hipStreamWaitEvent(fork->side[k], fork->ev_fork, 0));
           launch_class(k, fork->side[k]);
-          GS_LAUNCH_CHECK();
-          GS_HIP(hipEventRecord(fork->ev_join[k], fork->side[k]));
-          forked[k] = true;
+          const hipError_t launched = hipGetLastError();
+          // the join event is recorded even behind a failed launch: whatever did reach the side stream is waited for
+          const hipError_t recorded = hipEventRecord(fork->ev_join[k], fork->side[k]);
+          forked[k] = recorded == hipSuccess;
+          if (launched != hipSuccess) { set_error("tile_depth_sort (side stream): %s", hipGetErrorString(launched)); return GSPLAT_ERR_HIP; }
+          GS_HIP(recorded);
         }
     }
   }
@@ -597,9 +615,7 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
         GS_LAUNCH_CHECK();
       }
   }
-  for (int k = 0; k < 3; ++k)
-    if (forked[k]) GS_HIP(hipStreamWaitEvent(st, fork->ev_join[k], 0));
-  return GSPLAT_OK;
+  return joiner.join();
 }
 
 static int tile_bits(int num_tiles) {

@@ -1,7 +1,10 @@
 // gs_common.hip -- status/error text, device-pointer validation, scratch arena.
 #include "gs_common.h"
 
+#include <map>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace gs {
 
@@ -103,7 +106,103 @@ HostWords &host_words() { return g_words; }
 
 }  // namespace gs
 
+// ---- device block pool (gsplat_pool_alloc / gsplat_pool_free): see include/gsplat_hip.h
+namespace gs {
+namespace {
+struct PoolBlock { size_t cls; int device; };
+std::mutex g_pool_mutex;
+std::unordered_map<void *, PoolBlock> g_pool_live, g_pool_idle_info;
+std::map<std::pair<int, size_t>, std::vector<void *>> g_pool_idle;  // (device, class size) -> cached blocks
+size_t g_pool_idle_bytes = 0, g_pool_live_bytes = 0;
+
+// size classes with three mantissa bits: at most 12.5 % of a block is slack, and the per-view sizes of a training run
+// (they follow the visible count and the instance count, which change a little from view to view) fall into the same
+// few classes iteration after iteration
+size_t pool_class(size_t bytes) {
+  if (bytes <= 4096) return 4096;
+  int e = 63 - __builtin_clzll((unsigned long long)(bytes - 1));
+  const size_t step = (size_t)1 << (e > 3 ? e - 3 : 0);
+  return (bytes + step - 1) / step * step;
+}
+
+int pool_drop_idle_locked() {  // hipFree of every cached block (synchronises the device)
+  if (g_pool_idle_bytes == 0) return GSPLAT_OK;
+  (void)hipDeviceSynchronize();
+  for (auto &kv : g_pool_idle)
+    for (void *p : kv.second) (void)hipFree(p);
+  g_pool_idle.clear();
+  g_pool_idle_info.clear();
+  g_pool_idle_bytes = 0;
+  return GSPLAT_OK;
+}
+}  // namespace
+}  // namespace gs
+
 extern "C" {
+int gsplat_pool_alloc(void **ptr, size_t bytes) {
+  GS_REQUIRE(ptr != nullptr, "ptr is null");
+  *ptr = nullptr;
+  if (bytes == 0) return GSPLAT_OK;
+  int dev = 0;
+  GS_HIP(hipGetDevice(&dev));
+  const size_t cls = gs::pool_class(bytes);
+  std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
+  auto it = gs::g_pool_idle.find({dev, cls});
+  if (it != gs::g_pool_idle.end() && !it->second.empty()) {
+    void *p = it->second.back();
+    it->second.pop_back();
+    gs::g_pool_idle_info.erase(p);
+    gs::g_pool_idle_bytes -= cls;
+    gs::g_pool_live[p] = {cls, dev};
+    gs::g_pool_live_bytes += cls;
+    *ptr = p;
+    return GSPLAT_OK;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e != hipSuccess) {  // out of memory with blocks cached: give them back and try once more
+    (void)hipGetLastError();
+    gs::pool_drop_idle_locked();
+    e = hipMalloc(&p, cls);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    gs::set_error("gsplat_pool_alloc: hipMalloc(%zu) failed: %s", cls, hipGetErrorString(e));
+    return GSPLAT_ERR_HIP;
+  }
+  gs::g_pool_live[p] = {cls, dev};
+  gs::g_pool_live_bytes += cls;
+  *ptr = p;
+  return GSPLAT_OK;
+}
+
+int gsplat_pool_free(void *ptr) {
+  if (!ptr) return GSPLAT_OK;
+  std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
+  auto it = gs::g_pool_live.find(ptr);
+  if (it == gs::g_pool_live.end()) {
+    gs::set_error("gsplat_pool_free: %p was not allocated by gsplat_pool_alloc (or was freed twice)", ptr);
+    return GSPLAT_ERR_INVALID_ARG;
+  }
+  const gs::PoolBlock b = it->second;
+  gs::g_pool_live.erase(it);
+  gs::g_pool_live_bytes -= b.cls;
+  gs::g_pool_idle[{b.device, b.cls}].push_back(ptr);
+  gs::g_pool_idle_info[ptr] = b;
+  gs::g_pool_idle_bytes += b.cls;
+  return GSPLAT_OK;
+}
+
+int gsplat_pool_release(void) {
+  std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
+  return gs::pool_drop_idle_locked();
+}
+
+size_t gsplat_pool_bytes(int idle_only) {
+  std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
+  return idle_only ? gs::g_pool_idle_bytes : gs::g_pool_idle_bytes + gs::g_pool_live_bytes;
+}
+
 const char *gsplat_last_error(void) { return gs::g_err; }
 int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
 int gsplat_release_scratch(void) {

@@ -89,6 +89,10 @@ struct gsplat_context {
   double stage_ms[kStages] = {};
   long long stage_n[kStages] = {};
   long long fwd_calls = 0;
+  // what the speculative forward did (gsplat_context_get_counters): forwards, forwards whose queued tail had to be redone
+  // (instances outgrew the room, or the longest list needed a sort kernel that was not queued), forwards that walked the
+  // compacted slots, growths of the instance buffers
+  long long n_forwards = 0, n_tail_redone = 0, n_compact_walks = 0, n_instance_growths = 0;
   int slot = 0;
   void mark(int stage, bool stop, hipStream_t st) {
     if (!((timing >> stage) & 1u)) return;
@@ -473,6 +477,29 @@ struct BwdOut {
   float *conic, *uv, *J, *sigma, *xyz_c, *pre_rgb;
 };
 
+// Number of entries of the increasing array c2g[0..M) that are below `key` = the first compacted slot whose global index
+// is >= key.  A 64-ary search by the whole wave: every step the lanes probe 64 evenly spaced entries and a ballot keeps
+// the one sub-interval that contains the answer (four steps of one load each at 1e6 gaussians; every wave of the
+// grid does it for itself, no barrier).
+__device__ __forceinline__ int first_slot_not_below(const int *__restrict__ c2g, int M, int key) {
+  const int lane = threadIdx.x & 63;
+  int lo = 0, hi = M;  // c2g[j] < key for j < lo, c2g[j] >= key for j >= hi
+  while (hi > lo) {
+    const int step = (hi - lo + 63) >> 6;
+    const long long p = (long long)lo + (long long)lane * step;
+    const bool below = p < hi && c2g[p] < key;
+    const int t = __popcll(__ballot(below));  // the array is increasing: the first t probes are below the key
+    if (t == 0) {
+      hi = lo;
+    } else {
+      const long long next = (long long)lo + (long long)t * step;  // the probe after the last one below (if it exists)
+      hi = next < hi ? (int)next : hi;
+      lo = lo + (t - 1) * step + 1;
+    }
+  }
+  return lo;
+}
+
 // ---- backward of everything per gaussian, one thread per compacted slot
 template <int L>
 __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
@@ -483,14 +510,17 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
                                                                 float tan_fovx, float tan_fovy, float fwd_tan_fovx,
                                                                 float fwd_tan_fovy, float mh_dist, float cx, float cy,
                                                                 float cz, int width, int height, BwdOut o,
-                                                                const int *__restrict__ rank, int i_lo, int i_hi) {
-  // rank != null: only the gaussians with global index in [i_lo, i_hi), i.e. the compacted slots [rank[i_lo], rank[i_hi])
-  // (chunked backward of a view-sharded step: the exchange of one chunk runs while the next is computed); the grid covers
-  // the largest possible chunk, blocks past its end leave at once
+                                                                int ranged, int i_lo, int i_hi) {
+  // ranged: only the gaussians with global index in [i_lo, i_hi), i.e. the compacted slots [first slot whose global index
+  // is >= i_lo, first slot whose global index is >= i_hi) (chunked backward of a view-sharded step: the exchange of one
+  // chunk runs while the next is computed); the grid covers the largest possible chunk, blocks past its end leave at once.
+  // The two slots come from compact_to_global, which is increasing, NOT from rank[]: after a forward that walked the
+  // compacted slots (preprocess_kernel<.., kCompact>) rank[i] of a CULLED index still holds the cull's slice-local
+  // count, and a range bound may well be a culled index.
   int j_first = 0;
-  if (rank) {
-    j_first = rank[i_lo];
-    M = rank[i_hi];
+  if (ranged) {
+    j_first = first_slot_not_below(c2g, M, i_lo);
+    M = first_slot_not_below(c2g, M, i_hi);
   }
   const int j = j_first + blockIdx.x * kBlock + threadIdx.x;
   constexpr int n = (L + 1) * (L + 1), kRest = (n - 1) * 3;
@@ -1211,9 +1241,13 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->dense_route = gs::binning_next_route_is_radix(sparse, S, num_tiles, longest);
   c->last_longest = longest;
   const bool emitted = S <= inst_cap;  // dense route: else grow the instance buffers (synchronises) and emit again
+  c->n_forwards++;
+  if (compact) c->n_compact_walks++;
   if (sparse) {
     const bool fits = S <= spec_cap;
     if (!fits || !(spec_hint < 0 || list_class(longest) <= list_class(spec_hint))) {
+      c->n_tail_redone++;
+      if (!fits) c->n_instance_growths++;
       // grow (synchronises); the placement queued below writes the true ranges
       if (!fits && (rc = reserve_instances(c, S + S / 4, num_tiles, st))) return rc;
       // the long-tile counter lives at the head of keys_a: zeroed by bin_offsets, then used by the queued sorts
@@ -1318,12 +1352,12 @@ int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g
   const float fwd_tan_fovx = c->tan_fovx, fwd_tan_fovy = c->tan_fovy;  // the recorded forward's (cuda/raster.cu:92-93)
   BwdOut bo = {out->grad_xyz, out->grad_rgb, out->grad_sh, out->grad_opacity, out->grad_scale, out->grad_quaternion,
                out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb};
-  // a range of global indices holds at most that many visible gaussians (and never more than M); the kernel reads the
-  // range's compacted slots from rank[] on the device
+  // a range of global indices holds at most that many visible gaussians (and never more than M); the kernel finds the
+  // range's compacted slots in compact_to_global on the device (first_slot_not_below)
   const bool whole = first_gaussian == 0 && end_gaussian == g->num_gaussians;
   const int span = whole ? M : std::min(M, end_gaussian - first_gaussian);
   if (span == 0) return GSPLAT_OK;
-  const int *rank_arg = whole ? nullptr : c->rank.as<int>();
+  const int ranged = whole ? 0 : 1;
   const dim3 grid(gs::div_up(span, kBlock)), block(kBlock);
   c->mark(7, false, st);
 #define GS_BWD(LL)                                                                                                     \
@@ -1331,7 +1365,7 @@ int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g
                                                     c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
                                                     tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
                                                     cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
-                                                    rank_arg, first_gaussian, end_gaussian)
+                                                    ranged, first_gaussian, end_gaussian)
   switch (l_max) {
     case 0: GS_BWD(0); break;
     case 1: GS_BWD(1); break;
@@ -1377,6 +1411,13 @@ int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask)
   for (int k = 0; k < gsplat_context::kStages; ++k) { c->stage_ms[k] = 0; c->stage_n[k] = 0; }
   c->timing = stage_mask & ((1u << gsplat_context::kStages) - 1u);
   return GSPLAT_OK;
+}
+
+int gsplat_context_get_counters(gsplat_context *c, long long *out, int n) {
+  GS_REQUIRE(c && out && n >= 0, "null argument");
+  const long long v[4] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths};
+  for (int k = 0; k < n && k < 4; ++k) out[k] = v[k];
+  return 4;
 }
 
 int gsplat_context_set_render_only(gsplat_context *c, int enabled) {

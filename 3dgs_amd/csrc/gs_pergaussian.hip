@@ -402,11 +402,12 @@ int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int
   const long long total = (long long)N * stride;
   compact_rows_kernel<<<gs::div_up(total, kBlock), kBlock, 0, st>>>(src, mask, ranks.as<int>(), total, stride, dst);
   GS_LAUNCH_CHECK();
+  if (!num_selected) return GSPLAT_OK;  // the caller knows the count (the reference's call sites pass num_culled)
   rc = gs::host_words().ensure();
   if (rc) return rc;
   GS_HIP(hipMemcpyAsync(gs::host_words().p, ranks.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  if (num_selected) *num_selected = gs::host_words().p[0];
+  *num_selected = gs::host_words().p[0];
   return GSPLAT_OK;
 }
 

@@ -263,8 +263,13 @@ class ViewShardedStep:
         self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
         self.N = N = int(params["xyz"].shape[0])
-        self.ctx = ctx if ctx is not None else raster.RasterContext(N, width, height)
-        self.ctx.set_lean_forward(True)  # only the fused backward follows: Sigma / J / conic / colour are not materialised
+        # A context this step creates is lean (only the fused backward follows: Sigma / J / conic / colour are not
+        # materialised).  A context the CALLER owns is left as it is: its later forwards may feed the stand-alone
+        # backward operators, which read those arrays -- the caller switches it itself (Trainer and bench.py do).
+        if ctx is None:
+            ctx = raster.RasterContext(N, width, height)
+            ctx.set_lean_forward(True)
+        self.ctx = ctx
         self.width_cols = wc = raster.packed_gradient_width(l_max)
         dev = params["xyz"].device
         self.comm = comm if comm is not None else TorchComm()  # ThreadComm: in-process ranks (ThreadGroup)

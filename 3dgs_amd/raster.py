@@ -140,6 +140,12 @@ class RasterContext:
         recomputes what it needs); those four views are then absent from the forward's result."""
         check(self._lib.gsplat_context_set_lean_forward(self._h, int(bool(enabled))))
 
+    def counters(self):
+        """What the context's forwards did so far (gsplat_context_get_counters)."""
+        v = (ctypes.c_longlong * 4)()
+        self._lib.gsplat_context_get_counters(self._h, v, 4)
+        return dict(forwards=int(v[0]), tail_redone=int(v[1]), compact_walks=int(v[2]), instance_growths=int(v[3]))
+
     def set_timing(self, enabled, stages=None):
         """Per-stage HIP-event timing on / off; `stages`: names from STAGES to time only those (each timed stage costs
         two event records per call)."""

@@ -155,10 +155,28 @@ def stage_pass(ctx, dp, dc, dgi, cfg, L, grads, reps, do_bwd=True):
     return st
 
 
-def hbm_entry(kernel, nbytes, ms):
+def hbm_entry(kernel, nbytes, ms, moved=None):
     ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    return {"kernel": kernel, "bound": "hbm", "algorithmic_bytes": int(nbytes), "avg_launch_ms": round(ms, 4),
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    out = {"kernel": kernel, "bound": "hbm", "algorithmic_bytes": int(nbytes), "avg_launch_ms": round(ms, 4),
+           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    if moved is not None:  # what this instantiation of the kernel actually reads and writes (see preprocess_bytes)
+        out["bytes_moved"] = int(moved)
+        out["frac_on_bytes_moved"] = (moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0
+    return out
+
+
+def preprocess_bytes(M, N, L, lean):
+    """(SURVEY 8d algorithmic bytes, bytes this instantiation moves) of the fused per-gaussian forward.  The survey's
+    figure is the reference's operator chain: 288 B per visible gaussian at SH 3 (+ 13 B per gaussian for the cull).  The
+    kernel here reads per visible gaussian xyz 12 + band0 12 + sh 12((L+1)^2-1) + opacity 4 + scale 12 + quaternion 16 +
+    mask 1 + rank 4 and writes rank 4 + compact_to_global 4 + xyz_c 12 + uv 8 + radius 16 + the 48-byte splat record +
+    tile count 4 + hit mask 8 = 104 B; with every ForwardPassData array stored also Sigma 24 + J 24 + conic 12 + colour
+    12.  Culled gaussians cost the cull's 12 B read + 5 B written (lean) or 25 B (full: uncompacted xyz_c and uv)."""
+    rest = 12 * ((L + 1) ** 2 - 1)
+    alg = (12 + 16 + 12 + 4 + 12 + rest + 8 + 12 + 12 + 16 + 4) * M + 13 * N  # SURVEY.md 8d: 288 B at SH 3
+    read = 12 + 12 + rest + 4 + 12 + 16 + 1 + 4
+    write = 104 + (0 if lean else 72)
+    return alg, (read + write) * M + (12 + (5 if lean else 25)) * N
 
 
 def extra_workload(torch, scene, raster, name, dev, reps=20):
@@ -214,7 +232,8 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
         del dpt, opt, tg, lg, target
     out = {"N": N, "M": M, "S": S, "num_pairs": fwd["num_pairs"], "tile_list_mean": round(float(lens.float().mean().item()), 1),
            "tile_list_max": int(lens.max().item()), "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
-           "preprocess": hbm_entry("preprocess", 288 * M + 13 * N, st["preprocess"][0]),
+           "preprocess": hbm_entry("preprocess (lean)", preprocess_bytes(M, N, L, True)[0], st["preprocess"][0],
+                                   preprocess_bytes(M, N, L, True)[1]),
            "preprocess_backward": hbm_entry("preprocess_backward", 560 * M, st["preprocess_backward"][0])}
     if train_it_s is not None:
         out["train_it_s"] = round(train_it_s, 1)
@@ -222,6 +241,39 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
     del dp, dgi, grads
     torch.cuda.empty_cache()
     return out
+
+
+def reference_host_path(params, cam, gi, cfg, L, iterations=20):
+    """The path the REFERENCE host drives, timed outside the timed region: tests/cpp/reference_host.cpp is a C++ host
+    written against the drop-in headers only (include/gsplat_cuda/raster.cuh, cuda_data.cuh, cuda_backward.cuh) that runs,
+    per iteration, what TrainerImpl::train does around the rasterizer (cuda/trainer.cu:1294-1360): a fresh
+    ForwardPassData, zero_grads, rasterize_image (the shim: full forward + 13 device-to-device copies into pass_data),
+    then backward_pass' eight compact_masked_array calls and the seven stand-alone backward operators
+    (cuda/trainer.cu:941-1012).  A child process (its own HIP context); parity of the same binary at this size:
+    tests/test_reference_host_gpu.py."""
+    import tempfile
+    scene_io = importlib.import_module("3dgs_amd.scene_io")
+    exe = importlib.import_module("3dgs_amd._lib").build_cpp_host("reference_host")
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, "scene.bin")
+        scene_io.write_host_scene(inp, params, cam, gi, cfg, L)
+        out = {}
+        for mode in ("fresh", "keep"):
+            r = subprocess.run([exe, inp, "-", str(iterations)] + (["keep"] if mode == "keep" else []),
+                               capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError(f"reference_host failed ({r.returncode}): {r.stderr[-300:]}")
+            out[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    f = out["fresh"]
+    return {"what": "tests/cpp/reference_host.cpp: C++ host against include/gsplat_cuda/*.cuh, per iteration a fresh "
+                    "ForwardPassData + zero_grads + rasterize_image shim (all ForwardPassData arrays, 13 copies) + "
+                    "8 compact_masked_array + the 7 stand-alone backward operators (cuda/trainer.cu:941-1012, 1294-1360)",
+            "ms_per_iteration": f["ms_per_iteration"], "it_s": 1e3 / f["ms_per_iteration"],
+            "ms_zero_grads_and_rasterize_image": f["ms_zero_grads_and_rasterize_image"],
+            "ms_backward_pass": f["ms_backward_pass"],
+            "ms_per_call_synchronised": f["ms_per_call_synchronised"],
+            "ms_per_iteration_one_forward_pass_data_kept": out["keep"]["ms_per_iteration"],
+            "iterations": iterations, "pool_bytes": f["pool_bytes"]}
 
 
 def cpu_baseline(scene, args, params, cam, gi, cfg, N, W, H, L, do_bwd):
@@ -307,7 +359,7 @@ def main():
 
 
 def run_rank(args, comm, device_index):
-    import numpy as np  # noqa: F401
+    import numpy as np
     import torch
     scene = importlib.import_module("3dgs_amd.scene")
     raster = importlib.import_module("3dgs_amd.raster")
@@ -334,6 +386,7 @@ def run_rank(args, comm, device_index):
     want = os.environ.get("GSPLAT_EXCHANGE", "auto" if world > 1 else "split")
     exchange_ms = {}
     ctx = raster.RasterContext(N, W, H)
+    ctx.set_lean_forward(True)  # the timed step runs the fused backward only (config.forward_outputs says so)
     if world > 1 and do_bwd and want == "auto":
         errors = {}
         for mode in ("full", "factored", "split", "split_chunks4"):
@@ -388,6 +441,22 @@ def run_rank(args, comm, device_index):
     stages_full = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, 10, do_bwd)
     step.ctx.set_lean_forward(True)
 
+    # the whole step with every ForwardPassData array stored (the timed region below runs the lean forward)
+    ms_full_outputs = None
+    if do_bwd and world == 1:
+        step.ctx.set_lean_forward(False)
+        for _ in range(5):
+            one_step()
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        reps_f = max(5, min(args.steps, 50))
+        for _ in range(reps_f):
+            one_step()
+        torch.cuda.synchronize()
+        ms_full_outputs = (time.perf_counter() - tf) / reps_f * 1e3
+        step.ctx.set_lean_forward(True)
+        one_step()
+
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
@@ -398,9 +467,14 @@ def run_rank(args, comm, device_index):
     if world > 1:
         comm.barrier()
     torch.cuda.synchronize()
+    # Per-step marks cost the GPU nothing: every forward ends its host part by waiting for its own count record (the
+    # forward's one read-back), which arrives behind the previous step's backward -- so the host's clock after each step
+    # advances by one step of GPU time, and the intervals give a median next to the wall-clock mean below.
+    marks = [0.0] * args.steps
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         one_step()
+        marks[k] = time.perf_counter()
     torch.cuda.synchronize()
     if world > 1:
         comm.barrier()
@@ -431,7 +505,8 @@ def run_rank(args, comm, device_index):
         try:
             tj = json.load(open(tfile))
             # counters are per-launch properties of ONE build: only reported when the profile was taken on these sources
-            have = importlib.import_module("3dgs_amd._lib").source_hash()
+            # ... and that build is the LOADED binary (its embedded hash), not merely the sources next to it
+            have = importlib.import_module("3dgs_amd._lib").library_source_hash()
             if tj.get("source_sha16") == have:
                 traffic, valu_insts, valu_busy = tj.get(dom), tj.get(dom + "_valu_insts"), tj.get(dom + "_valu_busy")
             else:
@@ -521,6 +596,63 @@ def run_rank(args, comm, device_index):
         train_ms = (time.perf_counter() - t1) / reps_tr * 1e3
         del dp_train, opt, tgrads, loss_grad, target
 
+    # ---- two views in turn on one context (extra key): the forward queues its tail -- placement, per-tile sorts,
+    # compositing -- BEFORE the host has seen this view's counts, from the previous forward's route, cull ratio and longest
+    # list; the timed region repeats one view, so it only ever measures that speculation on a hit.  View B stands 6 units
+    # further into the scene: ~40 % of the gaussians fall behind it and the rest are closer (longer lists), so every
+    # forward follows one with a different cull ratio and a different longest list.
+    alternating = None
+    if world == 1 and do_bwd and args.workload == "config3":
+        try:
+            cam_b = dict(cam)
+            vb = np.array(cam["view"], np.float32).copy()
+            vb[11] = -6.0  # t_z: the camera moves forward along its axis (R = I for view 0)
+            cam_b["view"], cam_b["campos"] = vb, np.array([0.0, 0.0, 6.0], np.float32)
+            dcb = raster.device_camera(cam_b, dev)
+            actx = raster.RasterContext(N, W, H)
+            actx.set_lean_forward(True)
+            ag = actx.alloc_gradients(N, L)
+            stats = []
+            for k in range(6):
+                f = actx.rasterize_image(dp, dcb if k % 2 else dc, cfg, cfg["bg"], L)
+                actx.backward_pass(dp, dcb if k % 2 else dc, dgi, cfg["bg"], L, ag)
+                lens = f["ranges"][1:] - f["ranges"][:-1]
+                stats.append((f["num_culled"], f["num_splats"], int(lens.max().item())))
+            c0 = actx.counters()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            reps_a = 40
+            for k in range(reps_a):
+                actx.rasterize_image(dp, dcb if k % 2 else dc, cfg, cfg["bg"], L)
+                actx.backward_pass(dp, dcb if k % 2 else dc, dgi, cfg["bg"], L, ag)
+            torch.cuda.synchronize()
+            alt_ms = (time.perf_counter() - ta) / reps_a * 1e3
+            c1 = actx.counters()
+            single = {}
+            for name, d in (("view_a", dc), ("view_b", dcb)):
+                for _ in range(3):
+                    actx.rasterize_image(dp, d, cfg, cfg["bg"], L)
+                    actx.backward_pass(dp, d, dgi, cfg["bg"], L, ag)
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(20):
+                    actx.rasterize_image(dp, d, cfg, cfg["bg"], L)
+                    actx.backward_pass(dp, d, dgi, cfg["bg"], L, ag)
+                torch.cuda.synchronize()
+                single[name] = (time.perf_counter() - ta) / 20 * 1e3
+            alternating = {"ms_per_step_alternating": alt_ms, "ms_per_step_view_a_alone": single["view_a"],
+                           "ms_per_step_view_b_alone": single["view_b"],
+                           "view_a": dict(zip(("M", "S", "longest_list"), stats[-2])),
+                           "view_b": dict(zip(("M", "S", "longest_list"), stats[-1])),
+                           "steps": reps_a, "tails_redone": c1["tail_redone"] - c0["tail_redone"],
+                           "compact_walks": c1["compact_walks"] - c0["compact_walks"],
+                           "instance_buffer_growths": c1["instance_growths"] - c0["instance_growths"]}
+            actx.close()
+            del ag, dcb
+            torch.cuda.empty_cache()
+        except Exception as e:  # never lose the headline line to a side measurement
+            alternating = {"error": repr(e)[:300]}
+
     # ---- non-headline workloads (extra keys): what real training views do to the per-gaussian kernels and the binning
     extra = None
     if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
@@ -540,6 +672,16 @@ def run_rank(args, comm, device_index):
             cpu = {"error": repr(e)[:300]}
 
     ms = elapsed / args.steps * 1e3
+    iv = sorted((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
+    step_stats = ({"median": iv[len(iv) // 2], "min": iv[0], "max": iv[-1], "p90": iv[int(0.9 * (len(iv) - 1))],
+                   "what": "host-clock intervals between consecutive steps of the timed region (each forward waits for "
+                           "its count record, so an interval is one step of GPU time)"} if iv else None)
+    ref_host = None
+    if world == 1 and do_bwd and os.environ.get("GSPLAT_BENCH_REFERENCE_HOST", "1") != "0":
+        try:
+            ref_host = reference_host_path(params, cam, gi, cfg, L)
+        except Exception as e:  # never lose the headline line to a side measurement
+            ref_host = {"error": repr(e)[:300]}
     origin = {"config2": "BASELINE configs[1]", "config3": "BASELINE configs[2]"}.get(args.workload,
                                                                                      f"'{args.workload}' (not a BASELINE config)")
     line = {
@@ -564,15 +706,22 @@ def run_rank(args, comm, device_index):
         | {f"{p}_at_8_ranks": gdist.exchange_model(8, N, L, p) for p in ("full", "factored", "split")},
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
+        "ms_per_step_stats": step_stats,
+        "ms_per_step_full_forward_outputs": ms_full_outputs,
+        "reference_host_path": ref_host,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
         "preprocess_ms_all_forward_outputs": round(stages_full["preprocess"][0], 4),
         "roofline": roofline,
         "roofline_valu_issue": roofline_valu,
         # the HBM-bound kernels either side of the compositing, from the per-stage pass (algorithmic bytes per
         # gaussian: SURVEY.md 8d / DESIGN.md section 4); not the dominant kernel, reported for completeness
-        "roofline_per_gaussian_kernels": [hbm_entry(k, b, stages[k][0]) for k, b in
-                                          (("preprocess", 288 * M + 13 * N), ("preprocess_backward", 560 * M))
-                                          if (do_bwd or k == "preprocess")],
+        "roofline_per_gaussian_kernels": (
+            [hbm_entry("preprocess (lean: what the timed step runs)", preprocess_bytes(M, N, L, True)[0], stages["preprocess"][0],
+                       preprocess_bytes(M, N, L, True)[1]),
+             hbm_entry("preprocess (all ForwardPassData arrays stored)", preprocess_bytes(M, N, L, False)[0],
+                       stages_full["preprocess"][0], preprocess_bytes(M, N, L, False)[1])]
+            + ([hbm_entry("preprocess_backward", 560 * M, stages["preprocess_backward"][0])] if do_bwd else [])),
+        "alternating_views": alternating,
         "extra_workloads": extra,
         "cpu_baseline": cpu,
         "setup_s": round(gen_s, 1),

@@ -10,10 +10,96 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <new>
+#include <utility>
 
 #include "hip_compat.h"
 
+#include <thrust/device_ptr.h>
+#include <thrust/host_vector.h>
+
 namespace gsplat_shim {
+// A device vector for the objects the reference host creates and destroys EVERY iteration: the members of
+// ForwardPassData (cuda/trainer.cu:1295 constructs a fresh one per iteration, :1027 copies it by value) and the results
+// of compact_masked_array (8 per backward_pass, 16+ per optimizer_step).  As thrust::device_vectors each of them is a
+// hipMalloc + a hipFree that synchronises the device: 4 of the 6.5 ms such an iteration took at 1e6 gaussians.  This
+// class has the part of device_vector's interface those call sites use -- size / empty / resize / clear / data /
+// begin / end / operator[], copy and move, conversion to thrust::device_vector and thrust::host_vector -- on storage
+// from the library's block pool (gsplat_pool_alloc: a freed block is handed to the next request of its size class, in
+// stream order), so the steady state of a training loop allocates nothing.  Unlike device_vector it does NOT
+// value-initialise new elements (every user overwrites them).
+template <typename T> class device_array {
+ public:
+  using value_type = T;
+  using size_type = size_t;
+  using pointer = thrust::device_ptr<T>;
+  using const_pointer = thrust::device_ptr<const T>;
+  using iterator = pointer;
+  using const_iterator = const_pointer;
+
+  device_array() = default;
+  explicit device_array(size_t n) { resize(n); }
+  device_array(const device_array &o) { assign_raw(o.ptr_, o.size_); }
+  device_array(device_array &&o) noexcept : ptr_(o.ptr_), size_(o.size_), cap_(o.cap_) { o.ptr_ = nullptr; o.size_ = o.cap_ = 0; }
+  template <typename A> device_array(const thrust::device_vector<T, A> &v) { assign_raw(thrust::raw_pointer_cast(v.data()), v.size()); }
+  device_array &operator=(device_array o) noexcept { swap(o); return *this; }
+  ~device_array() { release(); }
+
+  void swap(device_array &o) noexcept { std::swap(ptr_, o.ptr_); std::swap(size_, o.size_); std::swap(cap_, o.cap_); }
+  size_t size() const { return size_; }
+  bool empty() const { return size_ == 0; }
+  void clear() { size_ = 0; }
+  // new elements are uninitialised; the first min(old, new) elements are kept
+  void resize(size_t n) {
+    if (n > cap_) {
+      void *fresh = nullptr;
+      const int st = gsplat_pool_alloc(&fresh, n * sizeof(T));
+      if (st != GSPLAT_OK) throw std::bad_alloc();
+      if (size_) (void)hipMemcpyAsync(fresh, ptr_, size_ * sizeof(T), hipMemcpyDeviceToDevice, 0);
+      release();
+      ptr_ = static_cast<T *>(fresh);
+      cap_ = n;
+    }
+    size_ = n;
+  }
+  pointer data() { return pointer(ptr_); }
+  const_pointer data() const { return const_pointer(ptr_); }
+  iterator begin() { return pointer(ptr_); }
+  iterator end() { return pointer(ptr_ + size_); }
+  const_iterator begin() const { return const_pointer(ptr_); }
+  const_iterator end() const { return const_pointer(ptr_ + size_); }
+  const_iterator cbegin() const { return begin(); }
+  const_iterator cend() const { return end(); }
+  thrust::device_reference<T> operator[](size_t i) { return *(begin() + i); }
+  thrust::device_reference<const T> operator[](size_t i) const { return *(begin() + i); }
+
+  // copies, for the call sites that name thrust's types (`thrust::device_vector<float> d_sh_selected; d_sh_selected =
+  // compact_masked_array<45>(...)`, cuda/trainer.cu:950-960; `thrust::host_vector<bool> mask = pass.d_mask`)
+  operator thrust::device_vector<T>() const {
+    thrust::device_vector<T> v(size_);
+    if (size_) (void)hipMemcpyAsync(thrust::raw_pointer_cast(v.data()), ptr_, size_ * sizeof(T), hipMemcpyDeviceToDevice, 0);
+    return v;
+  }
+  operator thrust::host_vector<T>() const {
+    thrust::host_vector<T> v(size_);
+    if (size_) (void)hipMemcpy(thrust::raw_pointer_cast(v.data()), ptr_, size_ * sizeof(T), hipMemcpyDeviceToHost);
+    return v;
+  }
+
+ private:
+  void assign_raw(const T *src, size_t n) {
+    resize(n);
+    if (n) (void)hipMemcpyAsync(ptr_, src, n * sizeof(T), hipMemcpyDeviceToDevice, 0);
+  }
+  void release() {
+    if (ptr_) (void)gsplat_pool_free(ptr_);
+    ptr_ = nullptr;
+    size_ = cap_ = 0;
+  }
+  T *ptr_ = nullptr;
+  size_t size_ = 0, cap_ = 0;
+};
+
 template <typename F> inline void alloc_or_exit(const char *what, F &&f) {
   try {
     f();
@@ -85,43 +171,46 @@ struct CudaDataManager {  // owns every persistent device buffer of a training r
   explicit CudaDataManager(size_t n) : max_gaussians(n), gaussians(n), optimizer(n), gradients(n), accumulators(n), camera() {}
 };
 
-struct ForwardPassData {  // per-view outputs of rasterize_image, saved for the backward pass
+// Per-view outputs of rasterize_image, saved for the backward pass.  Member names, element types and sizes are the
+// reference's (cuda_data.cuh:70-86); the containers are gsplat_shim::device_array (above) instead of
+// thrust::device_vector, because the reference host constructs this struct afresh every iteration.
+struct ForwardPassData {
   size_t num_culled = 0;
-  thrust::device_vector<float> d_sigma, d_conic, d_J, d_precomputed_rgb;  // [num_culled, 6 | 3 | 6 | 3]
-  thrust::device_vector<float> d_uv, d_xyz_c;                             // [N, 2 | 3], uncompacted
-  thrust::device_vector<bool> d_mask;                                     // [N]
-  thrust::device_vector<float4> d_radius;                                 // [num_culled]
-  thrust::device_vector<int> d_sorted_gaussians, d_splat_start_end_idx_by_tile_idx;
-  thrust::device_vector<float> d_image_buffer, d_weight_per_pixel;
-  thrust::device_vector<int> d_splats_per_pixel;
+  gsplat_shim::device_array<float> d_sigma, d_conic, d_J, d_precomputed_rgb;  // [num_culled, 6 | 3 | 6 | 3]
+  gsplat_shim::device_array<float> d_uv, d_xyz_c;                             // [N, 2 | 3], uncompacted
+  gsplat_shim::device_array<bool> d_mask;                                     // [N]
+  gsplat_shim::device_array<float4> d_radius;                                 // [num_culled]
+  gsplat_shim::device_array<int> d_sorted_gaussians, d_splat_start_end_idx_by_tile_idx;
+  gsplat_shim::device_array<float> d_image_buffer, d_weight_per_pixel;
+  gsplat_shim::device_array<int> d_splats_per_pixel;
 };
 
 // compact_masked_array<STRIDE>(source, mask, num_culled): the rows of `source` whose mask entry is set, in order.
-template <int STRIDE, typename T, typename MaskType>
-thrust::device_vector<T> compact_masked_array(const thrust::device_vector<T> &d_source,
-                                              const thrust::device_vector<MaskType> &d_mask, int num_culled) {
+// `source` / `mask`: thrust::device_vector or gsplat_shim::device_array.  Like the reference's (cuda_data.cuh:106-127) it
+// trusts num_culled (the count rasterize_image reported for this mask) and does not read the count back.
+template <int STRIDE, typename Source, typename Mask>
+gsplat_shim::device_array<typename Source::value_type> compact_masked_array(const Source &d_source, const Mask &d_mask,
+                                                                            int num_culled) {
+  using T = typename Source::value_type;
   static_assert(sizeof(T) == 4, "rows are made of 4-byte elements (float / int)");
-  static_assert(sizeof(MaskType) == 1, "the mask is one byte per row (bool)");
-  thrust::device_vector<T> d_selected((size_t)num_culled * STRIDE);
-  int selected = 0;
+  static_assert(sizeof(typename Mask::value_type) == 1, "the mask is one byte per row (bool)");
+  gsplat_shim::device_array<T> d_selected;
+  gsplat_shim::alloc_or_exit("compact_masked_array", [&] { d_selected.resize((size_t)num_culled * STRIDE); });
   gsplat_shim::require_ok(
       gsplat_compact_masked_array(reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_source.data())),
                                   reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data())),
                                   (int)d_mask.size(), STRIDE,
-                                  reinterpret_cast<float *>(thrust::raw_pointer_cast(d_selected.data())), &selected, 0),
+                                  reinterpret_cast<float *>(thrust::raw_pointer_cast(d_selected.data())), nullptr, 0),
       "compact_masked_array");
-  if (selected != num_culled) {
-    std::fprintf(stderr, "compact_masked_array: num_culled = %d but the mask selects %d rows\n", num_culled, selected);
-    std::exit(EXIT_FAILURE);
-  }
   return d_selected;
 }
 
 // scatter_masked_array<STRIDE>(compacted, mask, destination): the inverse; rows whose mask entry is clear are untouched.
-template <int STRIDE, typename T, typename MaskType>
-void scatter_masked_array(const thrust::device_vector<T> &d_compacted, const thrust::device_vector<MaskType> &d_mask,
-                          thrust::device_vector<T> &d_destination) {
-  static_assert(sizeof(T) == 4 && sizeof(MaskType) == 1, "4-byte elements, one-byte mask");
+template <int STRIDE, typename Compacted, typename Mask, typename Destination>
+void scatter_masked_array(const Compacted &d_compacted, const Mask &d_mask, Destination &d_destination) {
+  using T = typename Destination::value_type;
+  static_assert(sizeof(T) == 4 && sizeof(typename Mask::value_type) == 1, "4-byte elements, one-byte mask");
+  static_assert(sizeof(typename Compacted::value_type) == 4, "4-byte elements");
   if (d_compacted.size() / STRIDE == 0) return;
   gsplat_shim::require_ok(
       gsplat_scatter_masked_array(reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_compacted.data())),

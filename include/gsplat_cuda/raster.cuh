@@ -10,8 +10,9 @@
 // camera_parameters.d_view / d_proj must already hold this view's matrices, as in the reference
 // (cuda/trainer.cu:1310-1331).  Like the reference it prints to stderr and exits when nothing is in view.
 //
-// The fused forward keeps its outputs in a gsplat_context; the reference's callers read thrust vectors owned by
-// pass_data, so the outputs are copied there device-to-device (about 0.2 GB at 1e6 gaussians / 1080p).  A host that
+// The fused forward keeps its outputs in a gsplat_context; the reference's callers read vectors owned by pass_data,
+// so the outputs are copied there device-to-device (about 0.2 GB at 1e6 gaussians / 1080p: ~0.1 ms; the vectors come
+// from the library's block pool, cuda_data.cuh: a fresh ForwardPassData per iteration allocates nothing).  A host that
 // wants to skip the copies uses gsplat_rasterize_image / gsplat_forward_view directly.
 #pragma once
 
@@ -31,8 +32,9 @@ inline gsplat_context *context_for(int capacity, int width, int height) {
 }
 inline gsplat_context *&last_context() { static gsplat_context *c = nullptr; return c; }
 
-template <typename T> inline void copy_into(thrust::device_vector<T> &dst, const void *src, size_t count) {
-  dst.resize(count);
+template <typename T> inline void copy_into(device_array<T> &dst, const void *src, size_t count) {
+  dst.clear();  // nothing of the previous view is worth carrying over a growth
+  alloc_or_exit("rasterize_image (ForwardPassData)", [&] { dst.resize(count); });
   if (count) (void)hipMemcpyAsync(thrust::raw_pointer_cast(dst.data()), src, count * sizeof(T), hipMemcpyDeviceToDevice, 0);
 }
 }  // namespace gsplat_shim

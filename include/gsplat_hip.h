@@ -52,10 +52,30 @@ extern "C" {
 const char *gsplat_last_error(void);
 /* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
  * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
-#define GSPLAT_ABI_VERSION 3
+#define GSPLAT_ABI_VERSION 4
 int gsplat_abi_version(void);
+/* What the loaded binary was built from: sha256 (first 16 hex digits) over the kernel sources (3dgs_amd/csrc: Makefile,
+ * *.h, *.hip) at link time, and the extra compiler flags of a diagnostic build ("" for the product build).  A loader
+ * that did not build the library itself compares the hash with the sources it sees (3dgs_amd/_lib.py), and stored
+ * profiles (profiles/traffic.json) are tied to it. */
+const char *gsplat_source_hash(void);
+const char *gsplat_build_flags(void);
 /* Frees library-owned scratch memory of the current device. */
 int gsplat_release_scratch(void);
+
+/* Device block pool.  The reference host creates and destroys ~20 thrust::device_vectors per training iteration (a
+ * fresh ForwardPassData, cuda/trainer.cu:1295; one vector per compact_masked_array, cuda/trainer.cu:941-964,1028-1044):
+ * with the runtime's allocator every one of them is a hipMalloc + a hipFree (which synchronises the device) -- 4 of the
+ * 6.5 ms the unmodified reference-host iteration took at 1e6 gaussians.  The vectors the drop-in headers create
+ * (include/gsplat_cuda/cuda_data.cuh: gsplat_shim::device_array) draw from this pool instead: a freed block is kept and
+ * handed to the next request of its size class (three mantissa bits: <= 12.5 % slack), so the steady state allocates
+ * nothing.  Blocks are reused in STREAM ORDER: a block freed while work of stream s still reads it may only be
+ * re-used by work queued on s afterwards (the reference host issues everything on the NULL stream).
+ * gsplat_pool_release hipFree()s the idle blocks; gsplat_pool_bytes reports idle (idle_only != 0) or idle + live bytes. */
+int gsplat_pool_alloc(void **ptr, size_t bytes);
+int gsplat_pool_free(void *ptr);
+int gsplat_pool_release(void);
+size_t gsplat_pool_bytes(int idle_only);
 
 /* ---------------------------------------------------------------- forward operators --- */
 
@@ -248,7 +268,9 @@ int gsplat_gather_rows(int N, int stride, const int *order, const float *in, flo
 /* ------------------------------------------------------------- compaction templates --- */
 
 /* replaces compact_masked_array<STRIDE>  (cuda_data.cuh:106-127): stable compaction of src[N,stride] by mask[N]
- * into dst (room for N*stride floats); *num_selected <- rows kept (host value; blocks the host). */
+ * into dst (room for N*stride floats, or for the selected rows when the caller knows their number, as the reference's
+ * callers do: they pass num_culled).  num_selected != NULL: *num_selected <- rows kept (a host value: blocks the host);
+ * NULL: no read-back, the call stays asynchronous. */
 int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int N, int stride, float *dst,
                                 int *num_selected, void *stream);
 
@@ -366,6 +388,12 @@ int gsplat_context_set_render_only(gsplat_context *ctx, int enabled);
  * gradients are unchanged.  Off by default: the reference's own backward_pass (cuda/trainer.cu:941-1012) hands these
  * arrays to the stand-alone backward operators. */
 int gsplat_context_set_lean_forward(gsplat_context *ctx, int enabled);
+/* What the forwards of this context did so far: out[0] forwards completed, out[1] forwards whose speculatively queued
+ * tail (placement, per-tile sorts, compositing: queued before the host has seen the counts, from the previous forward's
+ * figures) had to be redone because the instances outgrew the buffers or the longest list needed a sort kernel that
+ * was not queued, out[2] forwards that walked the compacted slots, out[3] growths of the instance buffers.  Writes
+ * min(n, 4) values and returns 4. */
+int gsplat_context_get_counters(gsplat_context *ctx, long long *out, int n);
 int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
 /* The same for a subset of the stages (bit k of stage_mask = stage k; 0 switches timing off).  Every timed stage
  * costs two event records per call, about 0.7 % of a 1 ms step each: bench.py times only stage 6 inside its timed

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <thrust/copy.h>
@@ -79,8 +80,30 @@ Scene load_scene(const char *path) {
 template <class V> auto raw(V &v) { return thrust::raw_pointer_cast(v.data()); }
 template <class V> auto raw(const V &v) { return thrust::raw_pointer_cast(v.data()); }
 
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// `profile` runs: every call is followed by a device synchronisation and its wall time goes to a named slot
+struct Laps {
+  bool on = false;
+  double last = 0.0;
+  std::vector<std::pair<std::string, double>> slots;
+  void start() { if (on) { (void)hipDeviceSynchronize(); last = now_ms(); } }
+  void lap(const char *name) {
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    const double t = now_ms();
+    for (auto &s : slots)
+      if (s.first == name) { s.second += t - last; last = t; return; }
+    slots.emplace_back(name, t - last);
+    last = t;
+  }
+};
+
 // the training state of the reference's TrainerImpl that the two calls touch
 struct Host {
+  Laps laps;
   CudaDataManager cuda;
   int num_gaussians, l_max;
   Camera camera;
@@ -135,29 +158,33 @@ struct Host {
     else if (l_max == 2) sh_sel = compact_masked_array<24>(prm.d_sh, pass.d_mask, M);
     else if (l_max == 3) sh_sel = compact_masked_array<45>(prm.d_sh, pass.d_mask, M);
     const float3 campos = make_float3((float)image.campos[0], (float)image.campos[1], (float)image.campos[2]);
+    laps.lap("compact_masked_array x8");
 
     render_image_backward(raw(uv_sel), raw(opacity_sel), raw(pass.d_conic), raw(pass.d_precomputed_rgb), bg,
                           raw(pass.d_sorted_gaussians), raw(pass.d_splat_start_end_idx_by_tile_idx),
                           raw(pass.d_splats_per_pixel), raw(pass.d_weight_per_pixel), raw(d_grad_image), W, H,
                           raw(g.d_grad_precompute_rgb), raw(g.d_grad_opacity), raw(g.d_grad_uv), raw(g.d_grad_conic));
+    laps.lap("render_image_backward");
     precompute_spherical_harmonics_backward(raw(xyz_sel), raw(rgb_sel), raw(sh_sel), campos, raw(g.d_grad_precompute_rgb),
                                             l_max, M, raw(g.d_grad_sh), raw(g.d_grad_rgb), raw(g.d_grad_xyz));
+    laps.lap("precompute_spherical_harmonics_backward");
     compute_conic_backward(raw(pass.d_J), raw(pass.d_sigma), raw(cuda.camera.d_view), raw(pass.d_conic),
                            raw(g.d_grad_conic), M, raw(g.d_grad_J), raw(g.d_grad_sigma));
+    laps.lap("compute_conic_backward");
     const float fx = (float)camera.params[0], fy = (float)camera.params[1];
     const float fov_x = 2.0f * std::atan(camera.width / (2.0f * fx)), fov_y = 2.0f * std::atan(camera.height / (2.0f * fy));
     const float tan_fovx = std::tan(fov_x * 0.5f), tan_fovy = std::tan(fov_y * 0.5f);
     compute_projection_jacobian_backward(raw(xyz_c_sel), fx, fy, tan_fovx, tan_fovy, raw(g.d_grad_J), M, raw(g.d_grad_xyz_c));
+    laps.lap("compute_projection_jacobian_backward");
     compute_sigma_backward(raw(quaternion_sel), raw(scale_sel), raw(g.d_grad_sigma), M, raw(g.d_grad_quaternion),
                            raw(g.d_grad_scale));
+    laps.lap("compute_sigma_backward");
     project_to_screen_backward(raw(xyz_c_sel), raw(cuda.camera.d_proj), raw(g.d_grad_uv), M, W, H, raw(g.d_grad_xyz_c));
+    laps.lap("project_to_screen_backward");
     compute_camera_space_points_backward(raw(xyz_sel), raw(cuda.camera.d_view), raw(g.d_grad_xyz_c), M, raw(g.d_grad_xyz));
+    laps.lap("compute_camera_space_points_backward");
   }
 };
-
-double now_ms() {
-  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 template <class V> void write_floats(FILE *f, const V &dev, size_t count) {
   thrust::host_vector<float> h(dev.begin(), dev.begin() + count);
@@ -197,6 +224,27 @@ int main(int argc, char **argv) {
   const double per_iter = (now_ms() - t0) / (iters > 0 ? iters : 1);
   double fwd_ms = 0.0, bwd_ms = 0.0;
   for (int k = 0; k < iters; ++k) iteration(true, &fwd_ms, &bwd_ms);
+  // per-call breakdown: every call followed by a device synchronisation
+  host.laps.on = true;
+  for (int k = 0; k < iters; ++k) {
+    ForwardPassData fresh;
+    ForwardPassData &pass = keep ? kept : fresh;
+    host.laps.start();
+    host.zero_grads();
+    host.laps.lap("zero_grads");
+    host.forward(pass, s.bg);
+    host.laps.lap("rasterize_image");
+    host.backward_pass(pass, s.bg);
+    host.laps.start();
+  }
+  host.laps.on = false;
+  std::string per_call = "{";
+  for (auto &sl : host.laps.slots) {
+    char buf[160];
+    std::snprintf(buf, sizeof(buf), "%s\"%s\": %.4f", per_call.size() > 1 ? ", " : "", sl.first.c_str(), sl.second / (iters > 0 ? iters : 1));
+    per_call += buf;
+  }
+  per_call += "}";
 
   if (std::strcmp(argv[2], "-") != 0) {  // one more iteration whose results are kept for the parity check
     ForwardPassData pass;
@@ -218,9 +266,10 @@ int main(int argc, char **argv) {
     std::fclose(f);
   }
   std::printf("{\"iterations\": %d, \"forward_pass_data\": \"%s\", \"ms_per_iteration\": %.4f, "
-              "\"ms_zero_grads_and_rasterize_image\": %.4f, \"ms_backward_pass\": %.4f, \"num_gaussians\": %d, "
-              "\"num_culled\": %zu, \"sorted_list_capacity\": %zu}\n",
+              "\"ms_zero_grads_and_rasterize_image\": %.4f, \"ms_backward_pass\": %.4f, \"ms_per_call_synchronised\": %s, "
+              "\"pool_bytes\": %zu, \"num_gaussians\": %d, \"num_culled\": %zu, \"sorted_list_capacity\": %zu}\n",
               iters, keep ? "kept across iterations" : "fresh per iteration (cuda/trainer.cu:1295)", per_iter,
-              fwd_ms / (iters > 0 ? iters : 1), bwd_ms / (iters > 0 ? iters : 1), s.N, M, S);
+              fwd_ms / (iters > 0 ? iters : 1), bwd_ms / (iters > 0 ? iters : 1), per_call.c_str(), gsplat_pool_bytes(0),
+              s.N, M, S);
   return 0;
 }

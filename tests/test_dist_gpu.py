@@ -27,6 +27,14 @@ def _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=None):
     step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange="split", with_uv_norm=True, comm=comm, chunks=5)
     assert len(step.chunk_bounds()) == 5 and step.chunk_bounds()[-1][1] == step.N
     step.step(cam, gi)
+    # The SECOND step of a context is the one that matters: the scene culls a third of its gaussians, so this forward
+    # walks the compacted slots (preprocess_kernel<.., kCompact>), which leaves rank[] of the culled indices slice-local --
+    # and two of the four interior range bounds (1600, 2400) are culled indices.  The ranges must not depend on them.
+    first = step.ctx._last[1]
+    fwd = step.step(cam, gi)
+    assert fwd["num_culled"] == first and first * 5 < step.N * 4, "the scene must cull enough for the compacted walk"
+    mask = fwd["mask"].cpu().numpy()
+    assert sum(1 for lo, _ in step.chunk_bounds()[1:] if not mask[lo]) >= 2, "range bounds on culled indices wanted"
     torch.cuda.synchronize()
     chunked, uv_chunked = step.packed.clone(), step.uv_norm_sum.clone()
     grads_chunked = {k: v.clone() for k, v in step.grads.items()}
@@ -66,7 +74,8 @@ def _worker(rank, world, port, out_dir):
     gdist.init_from_env()
     N, W, H, L = 4000, 160, 96, 3
     params = scene.make_gaussians(N, W, H, L)
-    params["xyz"][::9, 2] *= -1
+    params["xyz"][::3, 2] *= -1  # a third culled, interleaved: the second forward of a context walks compacted slots
+    params["xyz"][1500:1700, 2] = -abs(params["xyz"][1500:1700, 2])  # and a run of them across a range bound (1600)
     cam = raster.device_camera(scene.make_camera(W, H, view_index=rank + 1))
     dp = raster.device_params(params)
     gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
@@ -185,7 +194,8 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
     world = 8
     N, W, H, L = 4000, 160, 96, 3
     params = scene.make_gaussians(N, W, H, L)
-    params["xyz"][::9, 2] *= -1
+    params["xyz"][::3, 2] *= -1  # (as in _worker: enough culled for the compacted walk, range bounds on culled indices)
+    params["xyz"][1500:1700, 2] = -np.abs(params["xyz"][1500:1700, 2])
     dp = raster.device_params(params)
     gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
     c = scene.CONFIG

@@ -360,28 +360,41 @@ def test_backward_in_ranges_of_global_indices(gpu, scene):
     c = scene.CONFIG
     ctx = raster.RasterContext(N, W, H)
     dp, dc = raster.device_params(params), raster.device_camera(cam)
-    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
-    M = fwd["num_culled"]
-    ctx.backward_render(torch.as_tensor(scene.make_grad_image(W, H)).cuda(), c["bg"])
-    whole = ctx.alloc_gradients(N, L, intermediates=True)
-    parts = ctx.alloc_gradients(N, L, intermediates=True)
-    for g in list(whole.values()) + list(parts.values()):
-        g.fill_(float("nan"))
-    ctx.backward_gaussians(dp, dc, L, whole)
-    bounds = [0, 1, 1, 700, 2000, 3100, 3163, 5999, N]
-    for lo, hi in zip(bounds[:-1], bounds[1:]):
-        ctx.backward_gaussians_range(dp, dc, L, parts, lo, hi)
-    torch.cuda.synchronize()
-    for k in whole:
-        assert torch.isfinite(whole[k][:M]).all(), k
-        assert torch.equal(whole[k][:M], parts[k][:M]), f"grad_{k}: the ranges do not add up to the whole backward"
-    common_a = torch.full((N, 12), float("nan"), device="cuda")
-    common_b = torch.full((N, 12), float("nan"), device="cuda")
-    raster.pack_gradients_split(ctx, whole, N, common_a, None)
-    for lo, hi in zip(bounds[:-1], bounds[1:]):
-        raster.pack_gradients_split_range(ctx, parts, N, lo, hi, common_b, None)
-    assert torch.equal(common_a, common_b)
-    assert (common_a[2000:3100] == 0).all() and (common_a[:, 11].sum().item() == M)
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    # bounds on visible AND on culled indices (0, 3, 2000, 2500, 4002 are culled), an empty range, an all-culled range
+    bounds = [0, 1, 1, 3, 700, 2000, 2500, 3100, 3163, 4002, 5999, N]
+    # Twice on the same context: the first forward walks all indices (rank[] global everywhere), the second -- the view
+    # culled more than a fifth -- walks the compacted slots, after which rank[] of a CULLED index still holds the cull's
+    # slice-local count (r03 advisor finding: the ranges used to be read from rank[]; they now come from
+    # compact_to_global).  A lean context too: what the training loop and ViewShardedStep run.
+    for lean in (False, True):
+        ctx.set_lean_forward(lean)
+        for walk in ("all indices", "compacted slots"):
+            fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+            M = fwd["num_culled"]
+            assert M * 5 < N * 4  # enough culled for the compacted walk from the second forward on
+            mask = fwd["mask"].cpu().numpy()
+            assert sum(1 for b in bounds[:-1] if not mask[b]) >= 5
+            ctx.backward_render(gi, c["bg"])
+            whole = ctx.alloc_gradients(N, L, intermediates=True)
+            parts = ctx.alloc_gradients(N, L, intermediates=True)
+            for g in list(whole.values()) + list(parts.values()):
+                g.fill_(float("nan"))
+            ctx.backward_gaussians(dp, dc, L, whole)
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                ctx.backward_gaussians_range(dp, dc, L, parts, lo, hi)
+            torch.cuda.synchronize()
+            for k in whole:
+                assert torch.isfinite(whole[k][:M]).all(), (k, walk)
+                assert torch.equal(whole[k][:M], parts[k][:M]), \
+                    f"grad_{k} (lean={lean}, forward walked {walk}): the ranges do not add up to the whole backward"
+            common_a = torch.full((N, 12), float("nan"), device="cuda")
+            common_b = torch.full((N, 12), float("nan"), device="cuda")
+            raster.pack_gradients_split(ctx, whole, N, common_a, None)
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                raster.pack_gradients_split_range(ctx, parts, N, lo, hi, common_b, None)
+            assert torch.equal(common_a, common_b)
+            assert (common_a[2000:3100] == 0).all() and (common_a[:, 11].sum().item() == M)
     with pytest.raises(pkg("_lib").GsplatError):
         ctx.backward_gaussians_range(dp, dc, L, parts, 10, N + 1)
 

@@ -103,16 +103,7 @@ def test_get_sorted_gaussian_list_two_calls_at_config3(gpu, config3_case):
 
 
 def _build_reference_host():
-    lib = pkg("_lib").build()
-    src = os.path.join(ROOT, "tests", "cpp", "reference_host.cpp")
-    exe = os.path.join(ROOT, "tests", "cpp", "reference_host")
-    inc = os.path.join(ROOT, "include", "gsplat_cuda")
-    deps = [src, lib] + [os.path.join(inc, h) for h in os.listdir(inc)]
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in deps):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", "-I",
-                               os.path.join(ROOT, "include"), src, "-x", "none", lib, "-Wl,-rpath," + os.path.dirname(lib),
-                               "-o", exe])
-    return exe
+    return pkg("_lib").build_cpp_host("reference_host")
 
 
 def test_cpp_reference_host_at_config3(gpu, scene, config3_case, tmp_path):

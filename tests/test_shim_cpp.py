@@ -12,15 +12,7 @@ RASTER_EXE = os.path.join(ROOT, "tests", "cpp", "raster_shim_test")
 
 
 def _build(name="shim_test"):
-    lib = pkg("_lib").build()
-    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    exe = os.path.join(ROOT, "tests", "cpp", name)
-    hdrs = [os.path.join(ROOT, "include", "gsplat_cuda", h) for h in os.listdir(os.path.join(ROOT, "include", "gsplat_cuda"))]
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in [src, lib] + hdrs):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", "-I",
-                               os.path.join(ROOT, "include"), src, "-x", "none", lib, "-Wl,-rpath," + os.path.dirname(lib),
-                               "-o", exe])
-    return exe
+    return pkg("_lib").build_cpp_host(name)
 
 
 def test_host_written_against_reference_headers_compiles():
@@ -33,6 +25,12 @@ def test_shim_known_answers_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+def test_reference_host_program_compiles():
+    """tests/cpp/reference_host.cpp: the reference trainer's per-iteration sequence (fresh ForwardPassData, zero_grads,
+    rasterize_image, backward_pass with its compact_masked_array calls) against the drop-in headers."""
+    assert os.path.exists(_build("reference_host"))
 
 
 def test_raster_header_host_compiles():
