@@ -98,7 +98,7 @@ void SortFork::destroy() {
 static HostWords g_words;
 int HostWords::ensure() {
   if (p) return GSPLAT_OK;
-  hipError_t e = hipHostMalloc((void **)&p, 64 * sizeof(int), hipHostMallocDefault);
+  hipError_t e = hipHostMalloc((void **)&p, 512 * sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { p = nullptr; set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return GSPLAT_ERR_HIP; }
   return GSPLAT_OK;
 }

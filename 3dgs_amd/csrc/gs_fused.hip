@@ -20,6 +20,7 @@
 #include "gs_common.h"
 #include "gs_math.h"
 #include "gs_render.h"
+#include "gs_rows.h"
 
 namespace gs {
 // from gs_binning.hip / gs_render.hip
@@ -139,40 +140,6 @@ struct gsplat_context {
 namespace {
 
 constexpr int kBlock = 256;
-
-// ---- staging of array-of-rows data through LDS.  A lane reading ITS row of kRest floats (180 B at SH degree 3)
-// touches 64 different cache lines per wave instruction and runs at the cache's tag rate, not at HBM rate; the
-// wave's 64 rows as one linear span touch 8 lines per instruction.
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at 4-byte alignment
-
-// A wave's `rows` (<= 64) consecutive rows of kRest floats between global memory and its LDS staging area, as one
-// linear span of 16-byte accesses.  A full wave issues all its loads before the first LDS store (11.25 per lane at
-// degree 3), so the whole 11.5 KB is in flight at once.
-template <int kRest>
-__device__ __forceinline__ void rows_to_lds(const float *__restrict__ src, float *wsh, int rows, int lane) {
-  constexpr int kVec = 16 * kRest, kFull = kVec / 64, kTail = kVec % 64;  // float4s of a full wave's span
-  if (rows == 64) {
-    float4 v[kFull + 1];
-#pragma unroll
-    for (int t = 0; t < kFull; ++t) v[t] = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src + 4 * (lane + 64 * t)));
-    if (kTail > 0 && lane < kTail) v[kFull] = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src + 4 * (lane + 64 * kFull)));
-#pragma unroll
-    for (int t = 0; t < kFull; ++t) *reinterpret_cast<float4 *>(wsh + 4 * (lane + 64 * t)) = v[t];
-    if (kTail > 0 && lane < kTail) *reinterpret_cast<float4 *>(wsh + 4 * (lane + 64 * kFull)) = v[kFull];
-  } else {
-    const int total = rows * kRest;
-    for (int e = lane * 4; e + 3 < total; e += 256)
-      *reinterpret_cast<float4 *>(wsh + e) = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src + e));
-    for (int e = (total & ~3) + lane; e < total; e += 64) wsh[e] = src[e];
-  }
-}
-template <int kRest>
-__device__ __forceinline__ void rows_from_lds(float *__restrict__ dst, const float *wsh, int rows, int lane) {
-  const int total = rows * kRest;
-  for (int e = lane * 4; e + 3 < total; e += 256)
-    *reinterpret_cast<f4u *>(dst + e) = __builtin_bit_cast(f4u, *reinterpret_cast<const float4 *>(wsh + e));
-  for (int e = (total & ~3) + lane; e < total; e += 64) dst[e] = wsh[e];
-}
 
 // ---- A: world -> camera -> pixel -> keep-mask, for all N, and the compaction ranks
 // kBinBlocks workgroups of kBinThreads; workgroup b owns the global indices of the chunks [C*b/kBinBlocks,
@@ -538,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   if constexpr (kRest > 0) {
     const int i0 = __builtin_amdgcn_readfirstlane(i);
     if (__all(!live || i == i0 + lane)) {  // consecutive gaussians (no culling in between): one linear span
-      rows_to_lds<kRest>(g.sh + (size_t)i0 * kRest, wsh, rows, lane);
+      gs::rows_to_lds<kRest>(g.sh + (size_t)i0 * kRest, wsh, rows, lane);
     } else {
       // Culled gaussians in between (every real training view): the wave's rows are scattered.  Twelve lanes fetch one
       // row -- eleven 16-byte pieces and the last float(s) -- so a wave instruction brings in five whole rows (880 B)
@@ -558,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
         if (in_grp && r < rows) {
           const float *src = g.sh + (size_t)ir * kRest + 4 * piece;
           if (4 * piece + 3 < kRest) {
-            v[it] = __builtin_bit_cast(float4, *reinterpret_cast<const f4u *>(src));
+            v[it] = __builtin_bit_cast(float4, *reinterpret_cast<const gs::f4u *>(src));
           } else {  // the row's last, partial piece
             v[it].x = src[0];
             if (4 * piece + 1 < kRest) v[it].y = src[1];
@@ -598,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   if constexpr (kRest > 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
+    gs::rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
   }
   if (!live) return;
   gx = 0.0f + gx; gy = 0.0f + gy; gz = 0.0f + gz;
@@ -773,19 +740,19 @@ __global__ __launch_bounds__(kBlock) void pack_split_kernel(const unsigned char 
                                                             float *__restrict__ rgb) {
   const int i = i_first + blockIdx.x * kBlock + threadIdx.x;  // one gaussian per thread: three 16-byte stores per row
   if (i >= N) return;
-  f4u r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = r0, r2 = r0;
+  gs::f4u r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = r0, r2 = r0;
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   if (mask[i]) {
     const size_t j = (size_t)rank_of[i];
     const float *gq = gr.grad_quaternion + 4 * j;
-    r0 = f4u{gr.grad_xyz[3 * j], gr.grad_xyz[3 * j + 1], gr.grad_xyz[3 * j + 2], gr.grad_opacity[j]};
-    r1 = f4u{gr.grad_scale[3 * j], gr.grad_scale[3 * j + 1], gr.grad_scale[3 * j + 2], gq[0]};
-    r2 = f4u{gq[1], gq[2], gq[3], 1.0f};
+    r0 = gs::f4u{gr.grad_xyz[3 * j], gr.grad_xyz[3 * j + 1], gr.grad_xyz[3 * j + 2], gr.grad_opacity[j]};
+    r1 = gs::f4u{gr.grad_scale[3 * j], gr.grad_scale[3 * j + 1], gr.grad_scale[3 * j + 2], gq[0]};
+    r2 = gs::f4u{gq[1], gq[2], gq[3], 1.0f};
     if (rgb) {
       c0 = gr.grad_precompute_rgb[3 * j]; c1 = gr.grad_precompute_rgb[3 * j + 1]; c2 = gr.grad_precompute_rgb[3 * j + 2];
     }
   }
-  f4u *row = reinterpret_cast<f4u *>(common + (size_t)i * 12);
+  gs::f4u *row = reinterpret_cast<gs::f4u *>(common + (size_t)i * 12);
   row[0] = r0; row[1] = r1; row[2] = r2;
   if (rgb) { rgb[(size_t)i * 3] = c0; rgb[(size_t)i * 3 + 1] = c1; rgb[(size_t)i * 3 + 2] = c2; }
 }

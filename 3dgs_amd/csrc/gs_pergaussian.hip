@@ -6,6 +6,7 @@
 
 #include "gs_common.h"
 #include "gs_math.h"
+#include "gs_rows.h"
 
 namespace {
 
@@ -158,69 +159,137 @@ __global__ __launch_bounds__(kBlock) void sigma_bwd_kernel(const float *__restri
   gs_[3 * i] = dS[0]; gs_[3 * i + 1] = dS[1]; gs_[3 * i + 2] = dS[2];
 }
 
+// The coefficient rows (180 B per gaussian at degree 3) and their gradient rows go through LDS as in the fused backward
+// (gs_rows.h): a lane reading ITS row touches 64 cache lines per wave instruction and the kernel ran at the cache's tag
+// rate (r04: 0.21 ms for 372 MB at 1e6 gaussians); each wave moves its 64 consecutive rows as one linear span instead.
 template <int L>
 __global__ __launch_bounds__(kBlock) void sh_bwd_kernel(const float *__restrict__ xyz, const float *__restrict__ band0,
                                                         const float *__restrict__ sh, float cx, float cy, float cz,
                                                         const float *__restrict__ grgb, int N,
                                                         float *__restrict__ gsh, float *__restrict__ gband0,
                                                         float *__restrict__ gxyz) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  constexpr int n = (L + 1) * (L + 1);
-  const float gr[3] = {grgb[3 * i], grgb[3 * i + 1], grgb[3 * i + 2]};
+  constexpr int n = (L + 1) * (L + 1), kRest = (n - 1) * 3;
+  __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 ? kBlock * kRest : 4];
+  const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
+  const int iw = blockIdx.x * kBlock + wave_first;  // first gaussian of this wave
+  if (iw >= N) return;
+  const int rows = min(64, N - iw);
+  const int i = iw + lane;
+  const bool live = lane < rows;
+  float *wsh = s_sh + wave_first * kRest;
+  if constexpr (kRest > 0) {
+    gs::rows_to_lds<kRest>(sh + (size_t)iw * kRest, wsh, rows, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int ir = live ? i : iw;  // dead lanes of the last wave recompute row iw and store nothing
+  const float gr[3] = {grgb[3 * ir], grgb[3 * ir + 1], grgb[3 * ir + 2]};
   float ox, oy, oz, b0g[3];
-  gs::sh_bwd<L>(sh + (size_t)i * (n - 1) * 3, band0 + 3 * i, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz,
-                gr, gsh + (size_t)i * (n - 1) * 3, b0g, ox, oy, oz);
+  float *row = wsh + (live ? lane : 0) * kRest;  // read as coefficients, overwritten with their gradients
+  if (live || kRest == 0)
+    gs::sh_bwd<L>(row, band0 + 3 * ir, xyz[3 * ir], xyz[3 * ir + 1], xyz[3 * ir + 2], cx, cy, cz, gr, row, b0g, ox, oy, oz);
+  if constexpr (kRest > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    gs::rows_from_lds<kRest>(gsh + (size_t)iw * kRest, wsh, rows, lane);
+  }
+  if (!live) return;
   gband0[3 * i] = b0g[0]; gband0[3 * i + 1] = b0g[1]; gband0[3 * i + 2] = b0g[2];
   gxyz[3 * i] += ox; gxyz[3 * i + 1] += oy; gxyz[3 * i + 2] += oz;
 }
 
 // ------------------------------------------------------------------ compaction
-__global__ __launch_bounds__(kBlock) void mask_to_int_kernel(const unsigned char *__restrict__ mask, int N,
-                                                             int *__restrict__ flags) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < N) flags[i] = mask[i] ? 1 : 0;
+// compact_masked_array / scatter_masked_array in TWO launches each (the reference host calls them ~8 times per backward and
+// ~35 times per optimizer step, cuda/trainer.cu:941-964, 1028-1110; r03 spent five launches per call: memset, mask -> int,
+// two kernels of a rocPRIM scan, the row kernel).  Kernel 1: kMaskSlices workgroups, each over one contiguous slice of
+// the mask, leave every row's rank INSIDE its slice and the slice's count; kernel 2 (the row kernel) scans the kMaskSlices
+// counts in LDS itself and adds a row's slice base.
+constexpr int kMaskSlices = 256;
+__device__ __host__ inline long long mask_slice_first(long long N, int s) { return N * s / kMaskSlices; }
+// the slice that holds row i: the largest s with mask_slice_first(N, s) <= i
+__device__ inline int mask_slice_of(long long N, long long i) { return (int)(((i + 1) * kMaskSlices - 1) / N); }
+
+__global__ __launch_bounds__(1024) void mask_slice_ranks_kernel(const unsigned char *__restrict__ mask, int N,
+                                                                int *__restrict__ ranks, int *__restrict__ slice_counts) {
+  __shared__ int s_wave[16];
+  __shared__ int s_run;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long lo = mask_slice_first(N, blockIdx.x), hi = mask_slice_first(N, blockIdx.x + 1);
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (long long base = lo; base < hi; base += 1024) {
+    const long long i = base + threadIdx.x;
+    const bool k = i < hi && mask[i] != 0;
+    const unsigned long long bal = __ballot(k);
+    if (lane == 0) s_wave[w] = __popcll(bal);
+    __syncthreads();
+    int before = s_run, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = s_wave[q];
+      before += q < w ? c : 0;
+      total += c;
+    }
+    if (i < hi) ranks[i] = before + __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) slice_counts[blockIdx.x] = s_run;
 }
 
-// one thread per destination element; rank[i] = exclusive scan of the mask
-__global__ __launch_bounds__(kBlock) void compact_rows_kernel(const float *__restrict__ src,
-                                                              const unsigned char *__restrict__ mask,
-                                                              const int *__restrict__ rank, long long total,
-                                                              int stride, float *__restrict__ dst) {
+// exclusive scan of the kMaskSlices slice counts into LDS (s_base[kMaskSlices] = the total); kBlock == kMaskSlices threads
+__device__ __forceinline__ void mask_slice_bases(const int *__restrict__ slice_counts, int *s_base) {
+  static_assert(kBlock == kMaskSlices, "one thread per slice");
+  __shared__ int s_wsum[kBlock / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cnt = slice_counts[threadIdx.x];
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += u;
+  }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int q = 0; q < w; ++q) before += s_wsum[q];
+  s_base[threadIdx.x] = before + incl - cnt;
+  if (threadIdx.x == kBlock - 1) s_base[kMaskSlices] = before + incl;
+  __syncthreads();
+}
+
+// one thread per source element; a row's compacted slot = its slice's base + its rank inside the slice
+template <bool kScatter>
+__global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__restrict__ src,
+                                                             const unsigned char *__restrict__ mask,
+                                                             const int *__restrict__ ranks,
+                                                             const int *__restrict__ slice_counts, int N, long long total,
+                                                             int stride, float *__restrict__ dst) {
+  __shared__ int s_base[kMaskSlices + 1];
+  mask_slice_bases(slice_counts, s_base);
   const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= total) return;
   const int i = (int)(e / stride), k = (int)(e % stride);
-  if (mask[i]) dst[(size_t)rank[i] * stride + k] = src[e];
-}
-
-__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(const float *__restrict__ src,
-                                                              const unsigned char *__restrict__ mask,
-                                                              const int *__restrict__ rank, long long total,
-                                                              int stride, float *__restrict__ dst) {
-  const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= total) return;
-  const int i = (int)(e / stride), k = (int)(e % stride);
-  if (mask[i]) dst[e] = src[(size_t)rank[i] * stride + k];
+  if (!mask[i]) return;
+  const size_t slot = (size_t)(s_base[mask_slice_of(N, i)] + ranks[i]);
+  if (kScatter) dst[e] = src[slot * stride + k];
+  else dst[slot * stride + k] = src[e];
 }
 
 }  // namespace
 
 namespace gs {
-// exclusive scan of a byte mask into int ranks (+ total at ranks[N]); shared with gs_fused.hip
-int mask_ranks(const unsigned char *mask, int N, int *ranks /*N+1*/, hipStream_t st) {
-  if (N <= 0) return GSPLAT_OK;
-  DeviceBuffer &flags = scratch(SCR_COUNTS);
-  int rc = flags.reserve((size_t)(N + 1) * sizeof(int));
+// slice-local ranks of a byte mask + the kMaskSlices slice counts (library scratch); see masked_rows_kernel
+static int mask_slice_ranks(const unsigned char *mask, int N, int **ranks, int **slice_counts, hipStream_t st) {
+  DeviceBuffer &rk = scratch(SCR_OFFSETS), &cnt = scratch(SCR_COUNTS);
+  int rc = rk.reserve((size_t)(N + 1) * sizeof(int));
   if (rc) return rc;
-  GS_HIP(hipMemsetAsync(flags.as<int>() + N, 0, sizeof(int), st));
-  mask_to_int_kernel<<<div_up(N, kBlock), kBlock, 0, st>>>(mask, N, flags.as<int>());
+  if ((rc = cnt.reserve((size_t)kMaskSlices * sizeof(int)))) return rc;
+  mask_slice_ranks_kernel<<<kMaskSlices, 1024, 0, st>>>(mask, N, rk.as<int>(), cnt.as<int>());
   GS_LAUNCH_CHECK();
-  size_t tmp_bytes = 0;
-  GS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags.as<int>(), ranks, 0, (size_t)N + 1, rocprim::plus<int>(), st));
-  DeviceBuffer &tmp = scratch(SCR_TEMP);
-  rc = tmp.reserve(tmp_bytes);
-  if (rc) return rc;
-  GS_HIP(rocprim::exclusive_scan(tmp.ptr, tmp_bytes, flags.as<int>(), ranks, 0, (size_t)N + 1, rocprim::plus<int>(), st));
+  *ranks = rk.as<int>();
+  *slice_counts = cnt.as<int>();
   return GSPLAT_OK;
 }
 }  // namespace gs
@@ -394,20 +463,21 @@ int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int
   GS_REQUIRE_DEV(src); GS_REQUIRE_DEV(mask); GS_REQUIRE_DEV(dst);
   hipStream_t st = (hipStream_t)stream;
   gs::ScratchLock lock;  // library scratch and the pinned count words are process-wide
-  gs::DeviceBuffer &ranks = gs::scratch(gs::SCR_OFFSETS);
-  int rc = ranks.reserve((size_t)(N + 1) * sizeof(int));
-  if (rc) return rc;
-  rc = gs::mask_ranks(mask, N, ranks.as<int>(), st);
+  int *ranks = nullptr, *slice_counts = nullptr;
+  int rc = gs::mask_slice_ranks(mask, N, &ranks, &slice_counts, st);
   if (rc) return rc;
   const long long total = (long long)N * stride;
-  compact_rows_kernel<<<gs::div_up(total, kBlock), kBlock, 0, st>>>(src, mask, ranks.as<int>(), total, stride, dst);
+  masked_rows_kernel<false><<<gs::div_up(total, kBlock), kBlock, 0, st>>>(src, mask, ranks, slice_counts, N, total, stride, dst);
   GS_LAUNCH_CHECK();
   if (!num_selected) return GSPLAT_OK;  // the caller knows the count (the reference's call sites pass num_culled)
   rc = gs::host_words().ensure();
   if (rc) return rc;
-  GS_HIP(hipMemcpyAsync(gs::host_words().p, ranks.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  static_assert(kMaskSlices <= 256, "the pinned words hold the slice counts");
+  GS_HIP(hipMemcpyAsync(gs::host_words().p, slice_counts, kMaskSlices * sizeof(int), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  *num_selected = gs::host_words().p[0];
+  int selected = 0;
+  for (int k = 0; k < kMaskSlices; ++k) selected += gs::host_words().p[k];
+  *num_selected = selected;
   return GSPLAT_OK;
 }
 
@@ -420,13 +490,11 @@ int gsplat_scatter_masked_array(const float *src, const unsigned char *mask, int
   GS_REQUIRE_DEV(src);
   hipStream_t st = (hipStream_t)stream;
   gs::ScratchLock lock;  // library scratch and the pinned count words are process-wide
-  gs::DeviceBuffer &ranks = gs::scratch(gs::SCR_OFFSETS);
-  int rc = ranks.reserve((size_t)(N + 1) * sizeof(int));
-  if (rc) return rc;
-  rc = gs::mask_ranks(mask, N, ranks.as<int>(), st);
+  int *ranks = nullptr, *slice_counts = nullptr;
+  int rc = gs::mask_slice_ranks(mask, N, &ranks, &slice_counts, st);
   if (rc) return rc;
   const long long total = (long long)N * stride;
-  scatter_rows_kernel<<<gs::div_up(total, kBlock), kBlock, 0, st>>>(src, mask, ranks.as<int>(), total, stride, dst);
+  masked_rows_kernel<true><<<gs::div_up(total, kBlock), kBlock, 0, st>>>(src, mask, ranks, slice_counts, N, total, stride, dst);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

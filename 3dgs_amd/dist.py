@@ -73,6 +73,25 @@ class TorchComm:
             return dist.all_gather_into_tensor(out, block, async_op=async_op) or _Done()
         return dist.all_gather(list(out.unbind(0)), block, async_op=async_op) or _Done()
 
+    def all_to_all_blocks(self, out, inp, async_op=False):
+        """out[r] <- rank r's inp[my rank]: every rank sends block j of `inp` to rank j -- W-1 point-to-point transfers
+        per rank, one per xGMI link (the direct half of a reduce-scatter).  RCCL: all_to_all_single; gloo (CPU tests,
+        one-GPU rehearsals) has no CUDA all-to-all: pairs of isend / irecv."""
+        if not self.on:
+            out[0].copy_(inp[0])
+            return _Done()
+        if dist.get_backend() == "nccl":
+            return dist.all_to_all_single(out, inp, async_op=async_op) or _Done()
+        out[self.rank].copy_(inp[self.rank])
+        ops = []
+        for r in range(self.world):
+            if r != self.rank:
+                ops.append(dist.P2POp(dist.isend, inp[r], r))
+                ops.append(dist.P2POp(dist.irecv, out[r], r))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return _Done()
+
     def barrier(self):
         if self.on:
             dist.barrier()
@@ -156,6 +175,15 @@ class ThreadComm:
         g._barrier.wait()
         return _Done()
 
+    def all_to_all_blocks(self, out, inp, async_op=False):
+        g = self.group
+        g._slots[self.rank] = inp
+        g._barrier.wait()
+        for r in range(self.world):
+            out[r].copy_(g._slots[r][self.rank])
+        g._barrier.wait()
+        return _Done()
+
     def barrier(self):
         self.group._barrier.wait()
 
@@ -203,6 +231,11 @@ def exchange_model(world, num_gaussians, l_max, payload, with_uv_norm=False, chu
         coll = [("all_reduce", 4 * (N + 1) * (12 + 3 * W) + tail)]
     elif payload == "split":
         coll = [("all_gather", 4 * (N + 1) * 3), ("all_reduce", 4 * N * 12 + tail)]
+    elif payload == "split_direct":
+        # the all-reduce spelled out as its two direct halves: all-to-all of the W shards (reduce-scatter), local sum,
+        # all-gather of the reduced shards; the same bytes as a ring all-reduce, one peer per link
+        shard = (4 * N * 12 + tail + W - 1) // W
+        coll = [("all_gather", 4 * (N + 1) * 3), ("all_to_all", shard * W), ("all_gather", shard)]
     else:
         raise ValueError(payload)
     out = dict(world=W, payload=payload, chunks=int(chunks), collectives=[], sent_bytes_per_rank=0, ring_ms=0.0, direct_ms=0.0)
@@ -210,13 +243,20 @@ def exchange_model(world, num_gaussians, l_max, payload, with_uv_norm=False, chu
     for kind, b in coll:
         if kind == "all_reduce":
             sent, ring, direct = 2 * (W - 1) / W * b, 2 * (W - 1) / W * b / per_ms, 2 * b / W / per_ms
+        elif kind == "all_to_all":  # b = the whole buffer: a rank keeps 1/W of it and sends one shard to each peer
+            sent, ring, direct = (W - 1) / W * b, (W - 1) / W * b / per_ms, (b / W / per_ms if W > 1 else 0.0)
         else:
             sent, ring, direct = (W - 1) * b, (W - 1) * b / per_ms, (b / per_ms if W > 1 else 0.0)
         out["collectives"].append(dict(kind=kind, buffer_bytes=int(b), sent_bytes_per_rank=int(sent), ring_ms=round(ring, 4),
                                        direct_ms=round(direct, 4)))
         out["sent_bytes_per_rank"] += int(sent)
     # the split payload's two collectives run concurrently (different buffers, the gather starts first)
-    if payload == "split":
+    if payload == "split_direct":
+        out["ring_ms"] = round(sum(c["ring_ms"] for c in out["collectives"]), 4)
+        out["direct_ms"] = round(sum(c["direct_ms"] for c in out["collectives"]), 4)
+        out["exposed_direct_ms_after_backward"] = round(sum(c["direct_ms"] for c in out["collectives"][1:]), 4)
+        out["exposed_ring_ms_after_backward"] = round(sum(c["ring_ms"] for c in out["collectives"][1:]), 4)
+    elif payload == "split":
         out["ring_ms"] = round(sum(c["ring_ms"] for c in out["collectives"]), 4)       # same links: they add up
         out["direct_ms"] = round(sum(c["direct_ms"] for c in out["collectives"]), 4)
         # with `chunks` ranges only the last range's share of the all-reduce is behind the backward
@@ -258,7 +298,7 @@ class ViewShardedStep:
     """
 
     def __init__(self, params, l_max, width, height, config, bg, exchange="split", with_uv_norm=False, ctx=None,
-                 comm=None, chunks=None):
+                 comm=None, chunks=None, exchange_at_world_one=False):
         from . import raster
         self.raster = raster
         self.params, self.l_max, self.config, self.bg = params, l_max, config, bg
@@ -274,13 +314,23 @@ class ViewShardedStep:
         dev = params["xyz"].device
         self.comm = comm if comm is not None else TorchComm()  # ThreadComm: in-process ranks (ThreadGroup)
         self.world, self.rank = self.comm.world, self.comm.rank
-        if exchange not in ("split", "factored", "full"):
+        if exchange not in ("split", "split_direct", "factored", "full"):
             raise ValueError(f"unknown exchange {exchange!r}")
-        self.exchange = exchange
+        # "split_direct": the split payload with the all-reduce of the twelve common columns spelled out as its two
+        # direct halves -- an all-to-all of the W shards (every peer over its own xGMI link), a local sum, an all-gather of
+        # the reduced shards -- instead of leaving the algorithm to RCCL (a single-link ring is per-link bound).
+        self.direct = exchange == "split_direct"
+        self.exchange = exchange = "split" if self.direct else exchange
+        # a group of ONE normally skips the exchange; exchange_at_world_one runs it anyway (the collectives degenerate to
+        # copies through the real backend): what tools/nccl_one_rank.py uses to rehearse and to time the host's share
+        self.always_exchange = bool(exchange_at_world_one)
+        self.host_s = 0.0  # host seconds spent in the exchange's own Python + collective calls (exchange_gradients etc.)
         # chunks > 1 (split exchange, more than one rank): the per-gaussian backward runs in that many ranges of global
         # indices and the all-reduce of one range's twelve common columns is in flight while the next range is computed
         # (GSPLAT_EXCHANGE_CHUNKS; default 1: one all-reduce behind the whole backward).  Same packed rows either way.
         self.chunks = max(1, int(chunks if chunks is not None else os.environ.get("GSPLAT_EXCHANGE_CHUNKS", "1")))
+        if self.direct:
+            self.chunks = 1  # the shards of the direct exchange cut across the ranges: one exchange behind the whole backward
         self.with_uv_norm = bool(with_uv_norm)
         tail = N if with_uv_norm else 0
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
@@ -298,12 +348,18 @@ class ViewShardedStep:
             self.factored = self._reduce_buf[:(N + 1) * self.fw].view(N + 1, self.fw)
         self._rgb_gather = None
         if exchange == "split":
-            self._reduce_buf = z(N * 12 + tail)
+            W = self.world
+            shard = (N * 12 + tail + W - 1) // W  # split_direct: the buffer is cut into W equal shards
+            self._reduce_buf = z(shard * W if self.direct else N * 12 + tail)
+            if self.direct:
+                self._shards_in = z(shard * W).view(W, shard)   # what the peers sent: their copies of this rank's shard
+                self._shard_sum = z(shard)
             self.common = self._reduce_buf[:N * 12].view(N, 12)
             self.rgb = z((N + 1) * 3).view(N + 1, 3)          # row N: campos
             self.rgb_all = z(self.world * (N + 1) * 3).view(self.world, N + 1, 3)
         if with_uv_norm:
-            self.uv_norm_sum = self._reduce_buf[self._reduce_buf.numel() - N:]
+            body = N * 12 if exchange == "split" else self._reduce_buf.numel() - N  # (split_direct pads behind the tail)
+            self.uv_norm_sum = self._reduce_buf[body:body + N]
         # capacity N: never reallocated
         self.grads = self.ctx.alloc_gradients(N, l_max)
         self.grads["precompute_rgb"] = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -315,6 +371,9 @@ class ViewShardedStep:
 
     def describe_exchange(self):
         mb = lambda t: f"{t.numel() * 4 / 1e6:.0f} MB"
+        if self.exchange == "split" and self.direct:
+            return (f"split_direct: all-to-all of {mb(self._reduce_buf)} in {self.world} shards + local sum + all-gather of "
+                    f"{mb(self._shard_sum)} per rank (the all-reduce's two direct halves) + all-gather of {mb(self.rgb)} per rank")
         if self.exchange == "split":
             how = f" in {self.chunks} ranges behind the ranges of the per-gaussian backward" if self.chunks > 1 else ""
             return f"split: all-reduce of {mb(self._reduce_buf)}{how} + all-gather of {mb(self.rgb)} per rank"
@@ -352,6 +411,8 @@ class ViewShardedStep:
                 self._chunk_reduces = None
                 if self.with_uv_norm:
                     reduces.append(self.comm.all_reduce(self.uv_norm_sum, async_op=True))
+            elif self.direct:
+                reduces = [self.comm.all_to_all_blocks(self._shards_in, self._reduce_buf.view(self.world, -1), async_op=True)]
             else:
                 reduces = [self.comm.all_reduce(self._reduce_buf, async_op=True)]
             # the SH columns only need the gathered g_rgb: rebuild them while the all-reduce is in flight
@@ -360,6 +421,11 @@ class ViewShardedStep:
                                                N, self.world, self.packed)
             for r in reduces:
                 r.wait()
+            if self.direct:
+                # second half: this rank owns the sum of its shard (formed in rank order: one rank computes each element,
+                # so every replica receives the same bits), and gathers everybody's
+                torch.sum(self._shards_in, dim=0, out=self._shard_sum)
+                self.comm.all_gather_blocks(self._reduce_buf.view(self.world, -1), self._shard_sum)
             self.raster.unpack_gradients_split(None, self.common, None, 0, self.l_max, N, self.world, self.packed)
         elif self.exchange == "factored":
             f = self.factored
@@ -409,8 +475,10 @@ class ViewShardedStep:
     def step(self, cam, grad_image=None, grad_fn=None, bg=None):
         """One view-sharded step.  grad_image: dL/dimage [H,W,3]; or grad_fn(fwd) -> dL/dimage computed from this
         rank's rendering (the training loop's loss).  Returns the forward dict (None when nothing was in view)."""
+        import time
         bg = self.bg if bg is None else bg
-        overlap = self.world > 1 and self.exchange == "split"
+        exchanging = self.world > 1 or self.always_exchange
+        overlap = exchanging and self.exchange == "split"
         if overlap:
             self._set_campos(cam)  # device-to-device (or cached): issued before the GPU has work queued
         self._blind = False
@@ -426,13 +494,17 @@ class ViewShardedStep:
             if overlap:
                 # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
                 self.ctx.backward_render(grad_image, bg, self.rgb)
+                t0 = time.perf_counter()
                 self._rgb_gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+                self.host_s += time.perf_counter() - t0
                 if self.chunks > 1:
                     self.backward_gaussians_chunked(cam)
                 else:
                     self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
             else:
                 self.ctx.backward_pass(self.params, cam, grad_image, bg, self.l_max, self.grads)
-        if self.world > 1:
+        if exchanging:
+            t0 = time.perf_counter()
             self.exchange_gradients(cam)
+            self.host_s += time.perf_counter() - t0
         return fwd

@@ -389,11 +389,11 @@ def run_rank(args, comm, device_index):
     ctx.set_lean_forward(True)  # the timed step runs the fused backward only (config.forward_outputs says so)
     if world > 1 and do_bwd and want == "auto":
         errors = {}
-        for mode in ("full", "factored", "split", "split_chunks4"):
+        for mode in ("full", "factored", "split", "split_chunks4", "split_direct"):
             ms_local, err = None, None
             try:  # a payload whose collectives this node's backend rejects is reported and left out, not fatal
-                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode.split("_")[0], ctx=ctx, comm=comm,
-                                           chunks=4 if mode.endswith("chunks4") else 1)
+                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode.replace("_chunks4", ""), ctx=ctx,
+                                           comm=comm, chunks=4 if mode.endswith("chunks4") else 1)
                 for _ in range(3):
                     st.step(dc, dgi)
                 torch.cuda.synchronize()
@@ -421,7 +421,7 @@ def run_rank(args, comm, device_index):
         want = min(exchange_ms, key=exchange_ms.get)  # the same on every rank: the times were MAX-reduced
         exchange_ms.update({m: "failed: " + msg for m, msg in errors.items()})
     want = want if want != "auto" else "split"
-    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want.split("_")[0], ctx=ctx, comm=comm,
+    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want.replace("_chunks4", ""), ctx=ctx, comm=comm,
                                  chunks=4 if want.endswith("chunks4") else None)
 
     def one_step():
@@ -596,40 +596,44 @@ def run_rank(args, comm, device_index):
         train_ms = (time.perf_counter() - t1) / reps_tr * 1e3
         del dp_train, opt, tgrads, loss_grad, target
 
-    # ---- two views in turn on one context (extra key): the forward queues its tail -- placement, per-tile sorts,
+    # ---- three views in turn on one context (extra key): the forward queues its tail -- placement, per-tile sorts,
     # compositing -- BEFORE the host has seen this view's counts, from the previous forward's route, cull ratio and longest
-    # list; the timed region repeats one view, so it only ever measures that speculation on a hit.  View B stands 6 units
-    # further into the scene: ~40 % of the gaussians fall behind it and the rest are closer (longer lists), so every
-    # forward follows one with a different cull ratio and a different longest list.
+    # list; the timed region repeats one view, so it only ever measures that speculation on a hit.  View B stands 8 units
+    # further back (everything in view and closer together on screen: the longest list several times view A's, beyond the
+    # sort kernels queued on A's figures: a redo), view C 3 units further in (part of the scene behind it: a different
+    # cull ratio, so the walk over compacted slots switches on and off).
     alternating = None
     if world == 1 and do_bwd and args.workload == "config3":
         try:
-            cam_b = dict(cam)
-            vb = np.array(cam["view"], np.float32).copy()
-            vb[11] = -6.0  # t_z: the camera moves forward along its axis (R = I for view 0)
-            cam_b["view"], cam_b["campos"] = vb, np.array([0.0, 0.0, 6.0], np.float32)
-            dcb = raster.device_camera(cam_b, dev)
+            def moved(tz):
+                cm = dict(cam)
+                vm = np.array(cam["view"], np.float32).copy()
+                vm[11] = tz  # t_z (R = I for view 0): camera position (0, 0, -tz)
+                cm["view"], cm["campos"] = vm, np.array([0.0, 0.0, -tz], np.float32)
+                return raster.device_camera(cm, dev)
+            cams = [("view_a", dc), ("view_b_8_back", moved(8.0)), ("view_c_3_forward", moved(-3.0))]
             actx = raster.RasterContext(N, W, H)
             actx.set_lean_forward(True)
             ag = actx.alloc_gradients(N, L)
-            stats = []
-            for k in range(6):
-                f = actx.rasterize_image(dp, dcb if k % 2 else dc, cfg, cfg["bg"], L)
-                actx.backward_pass(dp, dcb if k % 2 else dc, dgi, cfg["bg"], L, ag)
+            stats = {}
+            for k in range(9):
+                name, d = cams[k % 3]
+                f = actx.rasterize_image(dp, d, cfg, cfg["bg"], L)
+                actx.backward_pass(dp, d, dgi, cfg["bg"], L, ag)
                 lens = f["ranges"][1:] - f["ranges"][:-1]
-                stats.append((f["num_culled"], f["num_splats"], int(lens.max().item())))
+                stats[name] = {"M": f["num_culled"], "S": f["num_splats"], "longest_list": int(lens.max().item())}
             c0 = actx.counters()
             torch.cuda.synchronize()
             ta = time.perf_counter()
-            reps_a = 40
+            reps_a = 60
             for k in range(reps_a):
-                actx.rasterize_image(dp, dcb if k % 2 else dc, cfg, cfg["bg"], L)
-                actx.backward_pass(dp, dcb if k % 2 else dc, dgi, cfg["bg"], L, ag)
+                d = cams[k % 3][1]
+                actx.rasterize_image(dp, d, cfg, cfg["bg"], L)
+                actx.backward_pass(dp, d, dgi, cfg["bg"], L, ag)
             torch.cuda.synchronize()
             alt_ms = (time.perf_counter() - ta) / reps_a * 1e3
             c1 = actx.counters()
-            single = {}
-            for name, d in (("view_a", dc), ("view_b", dcb)):
+            for name, d in cams:
                 for _ in range(3):
                     actx.rasterize_image(dp, d, cfg, cfg["bg"], L)
                     actx.backward_pass(dp, d, dgi, cfg["bg"], L, ag)
@@ -639,16 +643,14 @@ def run_rank(args, comm, device_index):
                     actx.rasterize_image(dp, d, cfg, cfg["bg"], L)
                     actx.backward_pass(dp, d, dgi, cfg["bg"], L, ag)
                 torch.cuda.synchronize()
-                single[name] = (time.perf_counter() - ta) / 20 * 1e3
-            alternating = {"ms_per_step_alternating": alt_ms, "ms_per_step_view_a_alone": single["view_a"],
-                           "ms_per_step_view_b_alone": single["view_b"],
-                           "view_a": dict(zip(("M", "S", "longest_list"), stats[-2])),
-                           "view_b": dict(zip(("M", "S", "longest_list"), stats[-1])),
-                           "steps": reps_a, "tails_redone": c1["tail_redone"] - c0["tail_redone"],
+                stats[name]["ms_per_step_alone"] = (time.perf_counter() - ta) / 20 * 1e3
+            alternating = {"ms_per_step_alternating": alt_ms,
+                           "ms_per_step_mean_of_the_views_alone": sum(v["ms_per_step_alone"] for v in stats.values()) / 3,
+                           "views": stats, "steps": reps_a, "tails_redone": c1["tail_redone"] - c0["tail_redone"],
                            "compact_walks": c1["compact_walks"] - c0["compact_walks"],
                            "instance_buffer_growths": c1["instance_growths"] - c0["instance_growths"]}
             actx.close()
-            del ag, dcb
+            del ag, cams
             torch.cuda.empty_cache()
         except Exception as e:  # never lose the headline line to a side measurement
             alternating = {"error": repr(e)[:300]}
@@ -682,6 +684,22 @@ def run_rank(args, comm, device_index):
             ref_host = reference_host_path(params, cam, gi, cfg, L)
         except Exception as e:  # never lose the headline line to a side measurement
             ref_host = {"error": repr(e)[:300]}
+    # the exchange's HOST cost through the real backend, one rank (a child: it needs a process group of its own)
+    host_cost = None
+    if world == 1 and do_bwd and args.workload == "config3" and os.environ.get("GSPLAT_BENCH_EXCHANGE_HOST_COST", "1") != "0":
+        try:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+                       HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_NO_BUILD="1")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_one_rank.py"), args.workload], env=env,
+                               capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-300:])
+            host_cost = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:  # never lose the headline line to a side measurement
+            host_cost = {"error": repr(e)[:300]}
     origin = {"config2": "BASELINE configs[1]", "config3": "BASELINE configs[2]"}.get(args.workload,
                                                                                      f"'{args.workload}' (not a BASELINE config)")
     line = {
@@ -699,11 +717,15 @@ def run_rank(args, comm, device_index):
                                       "preprocess with all of them stored: preprocess_ms_all_forward_outputs",
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": num_pairs, "scene_seed": scene.SEED},
         "exchange_ms_per_step": exchange_ms or None,
+        # tools/nccl_one_rank.py: every payload through RCCL with ONE rank (collectives = copies): ms per step with the
+        # exchange, and the microseconds of it the host spends in the exchange's Python + torch.distributed calls
+        "exchange_host_cost_one_rank": host_cost,
         # what the exchange of this workload moves and costs on xGMI by the link arithmetic of 3dgs_amd/dist.py
         # exchange_model (ring / direct bounds per collective), for the payload in use at this world size and for the
         # 8-rank shape; the driver's measured multi-GPU step times can be checked against it
-        "exchange_model": ({"this_run": gdist.exchange_model(world, N, L, step.exchange, chunks=step.chunks)} if world > 1 else {})
-        | {f"{p}_at_8_ranks": gdist.exchange_model(8, N, L, p) for p in ("full", "factored", "split")},
+        "exchange_model": ({"this_run": gdist.exchange_model(world, N, L, "split_direct" if step.direct else step.exchange,
+                                                             chunks=step.chunks)} if world > 1 else {})
+        | {f"{p}_at_8_ranks": gdist.exchange_model(8, N, L, p) for p in ("full", "factored", "split", "split_direct")},
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
         "ms_per_step_stats": step_stats,

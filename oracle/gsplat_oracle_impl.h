@@ -307,7 +307,8 @@ long FN(orc_sorted_gaussian_list)(const R *uv, const R *xyz, const R *radius, in
 /* S1  precompute_spherical_harmonics   cuda/spherical_harmonics.cu:8-94                 */
 /* The basis comes from sphericart (un-vendored): real, orthonormal, no Condon-Shortley  */
 /* phase, index l*l+l+m.  l<=2 pinned by tests/cuda_forward_test.cpp:541-627 and         */
-/* tests/cuda_backward_test.cpp:610-624; l=3 follows the same convention (unpinned).     */
+/* tests/cuda_backward_test.cpp:610-624; all 16 functions and their gradients pinned      */
+/* against scipy.special.sph_harm_y (tests/test_oracle_known_answers.py, r04).           */
 /* ------------------------------------------------------------------------------------ */
 #define SH_C0 ((R)0.28209479177387814)
 #define SH_C1 ((R)0.4886025119029199)

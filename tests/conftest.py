@@ -58,9 +58,16 @@ def config3_case(scene, orc):
 # ---------------------------------------------------------------- comparison helpers (tolerances live here)
 PIXEL_L1_TOL = 1e-4      # north_star: rendered pixels within 1e-4 per-pixel L1
 GRAD_REL_TOL = 1e-3      # north_star: gradients within 1e-3 relative
-# The alpha > 1/255 test is a step function of a float expression: two correct implementations that round the
-# exponent differently may flip it on a few (pixel, gaussian) pairs, each worth at most alpha*colour ~ 4e-3.
-FLIP_FRACTION = 2e-4
+# The alpha > 1/255 and T < 1e-4 tests are step functions of float expressions: two correct implementations that round
+# an exponent differently may flip one on a (pixel, gaussian) pair whose value sits on the threshold.  Measured against
+# the oracle: 1 pixel of 2 073 600 at 1920x1080 (max 1.7e-3), 0-1 pixel on the small scenes (max 1.4e-4).  The bar below
+# is the one bar for every rendered image (r04: the looser '2e-4 of the pixels' / 'mean 1e-4' of earlier rounds are gone);
+# where the oracle's lists are at hand, tests/test_fused_gpu.py::_tight_bookkeeping additionally demands a float64
+# explanation (borderline alpha / T) for every pixel this bar lets through.
+MEAN_L1_TOL = 1e-6       # mean per-pixel L1 (measured: 1.0e-7)
+ABOVE_TOL_FRACTION = 1e-5  # of the pixels may exceed PIXEL_L1_TOL (+ 2 pixels: one pixel of 64x48 is already 3e-4)
+FLIP_MAX = 2e-2          # what one flipped decision can be worth: alpha * |colour - behind| summed over three channels
+STOP_INDEX_FRACTION = 1e-4  # of the pixels may stop one splat earlier / later (+ 2)
 
 
 def assert_image_close(got, ref, what="image"):
@@ -68,10 +75,18 @@ def assert_image_close(got, ref, what="image"):
     assert got.shape == ref.shape
     err = np.abs(got - ref)
     per_pixel_l1 = err.reshape(-1, got.shape[-1]).sum(1) if got.ndim == 3 else err.reshape(-1)
-    assert per_pixel_l1.mean() < PIXEL_L1_TOL, f"{what}: mean per-pixel L1 {per_pixel_l1.mean():.3e}"
-    bad = (per_pixel_l1 > PIXEL_L1_TOL).mean()
-    assert bad <= FLIP_FRACTION, f"{what}: {bad:.2e} of pixels differ by more than {PIXEL_L1_TOL}"
-    assert err.max() < 2e-2, f"{what}: max abs error {err.max():.3e}"
+    P = per_pixel_l1.size
+    assert per_pixel_l1.mean() < MEAN_L1_TOL, f"{what}: mean per-pixel L1 {per_pixel_l1.mean():.3e}"
+    above = int((per_pixel_l1 > PIXEL_L1_TOL).sum())
+    assert above <= ABOVE_TOL_FRACTION * P + 2, f"{what}: {above} of {P} pixels differ by more than {PIXEL_L1_TOL}"
+    assert per_pixel_l1.max() < FLIP_MAX, f"{what}: max per-pixel L1 {per_pixel_l1.max():.3e}"
+
+
+def assert_stop_indices_close(got, ref, what="splats_per_pixel"):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape
+    bad = int((got != ref).sum())
+    assert bad <= STOP_INDEX_FRACTION * got.size + 2, f"{what}: {bad} of {got.size} stop indices differ"
 
 
 def assert_grad_close(got, ref, what="grad", rel=GRAD_REL_TOL):

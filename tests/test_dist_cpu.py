@@ -68,6 +68,21 @@ def _worker(rank, world, port, out_dir):
         wk.wait()
     for rr in range(world):
         assert (blocks[rr] == float(rr + 1)).all()
+    # the direct exchange (split_direct): all-to-all of the W shards, local sum, all-gather of the reduced shards must
+    # give the all-reduce's sums (bit for bit at two ranks: a two-term sum has one order), identical on every rank
+    comm = gdist.TorchComm()
+    flat = local[:, :12].contiguous().reshape(-1)
+    shard = (flat.numel() + world - 1) // world
+    buf = torch.zeros(shard * world)
+    buf[:flat.numel()] = flat
+    want = buf.clone()
+    torch.distributed.all_reduce(want)
+    got_in, got_sum = torch.zeros(world, shard), torch.zeros(shard)
+    comm.all_to_all_blocks(got_in, buf.view(world, shard), async_op=True).wait()
+    torch.sum(got_in, dim=0, out=got_sum)
+    comm.all_gather_blocks(buf.view(world, shard), got_sum).wait()
+    assert torch.equal(buf, want), "direct exchange differs from the all-reduce"
+    np.save(os.path.join(out_dir, f"direct{rank}.npy"), buf.numpy())
     un = gdist.unpack(packed, L)
     assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3) and un["visible"].shape == (N,)
     assert params_all["xyz"].shape == (N, 3)
@@ -83,6 +98,8 @@ def test_view_sharded_all_reduce_gloo(tmp_path):
     reduced = [np.load(tmp_path / f"reduced{r}.npy") for r in range(world)]
     np.testing.assert_allclose(reduced[0], local[0] + local[1], rtol=1e-6, atol=1e-12)
     assert (reduced[0] == reduced[1]).all(), "all ranks must end with identical gradients"
+    direct = [np.load(tmp_path / f"direct{r}.npy") for r in range(world)]
+    assert (direct[0] == direct[1]).all() and np.abs(direct[0]).max() > 0
     gdist = pkg("dist")
     cols, width = gdist.packed_layout(2)
     vis = reduced[0][:, cols["visible"][0]]

@@ -81,7 +81,7 @@ def _worker(rank, world, port, out_dir):
     gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
     c = scene.CONFIG
     out = {}
-    for ex in ("split", "factored", "full"):
+    for ex in ("split", "split_direct", "factored", "full"):
         step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange=ex)
         step.step(cam, gi)
         step.step(cam, gi)  # twice: buffers are reused
@@ -100,12 +100,12 @@ def test_view_sharded_step_two_ranks_one_gpu(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
-    for ex in ("split", "factored", "full", "chunked"):
+    for ex in ("split", "split_direct", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
     full = r[0]["full"]
     scale = np.abs(full).mean()
-    for ex in ("split", "factored", "chunked"):
+    for ex in ("split", "split_direct", "factored", "chunked"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()  # views that saw each gaussian
@@ -203,10 +203,10 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
     def body(comm):
         cam = raster.device_camera(scene.make_camera(W, H, view_index=comm.rank + 1))
         out = {}
-        for ex in ("split", "factored", "full"):
+        for ex in ("split", "split_direct", "factored", "full"):
             step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange=ex, comm=comm)
             assert step.world == world and step.fw == 12 + 3 * world
-            if ex == "split":
+            if ex.startswith("split"):
                 assert tuple(step.rgb_all.shape) == (world, N + 1, 3)
             step.step(cam, gi)
             step.step(cam, gi)
@@ -218,12 +218,12 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
         return out
 
     r = gdist.ThreadGroup(world).run(body)
-    for ex in ("split", "factored", "full", "chunked"):
+    for ex in ("split", "split_direct", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
     full = r[0]["full"]
     scale = np.abs(full).mean()  # (each payload ran its own backward: float atomics, so payloads agree to rounding only)
-    for ex in ("split", "factored", "chunked"):
+    for ex in ("split", "split_direct", "factored", "chunked"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()
@@ -292,7 +292,11 @@ def test_split_exchange_on_rccl_one_rank():
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_one_rank.py")], env=env, capture_output=True,
                          text=True, timeout=300)
-    assert out.returncode == 0 and "nccl one-rank rehearsal: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and "nccl one-rank rehearsal: ok" in out.stderr, out.stdout[-2000:] + out.stderr[-2000:]
+    import json
+    rep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    for payload in ("split", "split_chunks4", "split_direct", "factored", "full"):  # every payload went through RCCL
+        assert rep[payload]["host_us_per_step_in_exchange_calls"] > 0, payload
 
 
 @pytest.mark.parametrize("world,threads", [(2, False), (4, False), (8, True)])
@@ -313,7 +317,7 @@ def test_bench_launches_its_own_ranks(world, threads):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == world and line["config"]["views_per_step"] == world and line["scaling"] == "weak"
     assert line["config"]["backend"] == ("threads" if threads else "gloo")
-    assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split", "split_chunks4"}
+    assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split", "split_chunks4", "split_direct"}
     assert line["exchange_model"]["this_run"]["world"] == world and "split_at_8_ranks" in line["exchange_model"]
     assert line["config"]["exchange"].split(":")[0] in ("full", "factored", "split")
     assert line["value"] > 0 and line["steps"] == 4

@@ -8,7 +8,7 @@ agree to a few ulps; the compositing operators are compared with the north-star 
 import numpy as np
 import pytest
 
-from conftest import assert_grad_close, assert_image_close, pkg
+from conftest import assert_grad_close, assert_image_close, assert_stop_indices_close, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -220,7 +220,7 @@ def test_render_image(gpu, case):
     ops.render_image(uv, op, conic, rgb, 0.5, srt, rng, W, H, n, T, img)
     assert_image_close(img.cpu().numpy(), f["image"], "image")
     assert_image_close(T.cpu().numpy(), f["T"], "final transmittance")
-    assert (n.cpu().numpy() != f["n"]).mean() < 2e-4
+    assert_stop_indices_close(n.cpu().numpy(), f["n"])
 
 
 def test_known_answer_render(gpu):  # reference tests/cuda_forward_test.cpp:631-767

@@ -9,7 +9,10 @@ cp "$src" ./_variant_$name.hip
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -mllvm -amdgpu-atomic-optimizer-strategy=None \
   -Wno-unused-function "$@" -c -o /tmp/_variant_${name}_$tag.o ./_variant_$name.hip || { rm -f ./_variant_$name.hip; exit 1; }
 rm -f ./_variant_$name.hip
-objs=""
+# the variant says so itself (gsplat_build_flags): stored profiles are never attached to it (3dgs_amd/_lib.py)
+make -s gs_source_hash.inc || exit 1
+g++ -O2 -std=c++17 -fPIC -DGS_BUILD_FLAGS="\"variant:$tag $*\"" -c -o /tmp/_variant_version_$tag.o gs_version.cpp || exit 1
+objs="/tmp/_variant_version_$tag.o"
 for o in gs_common gs_pergaussian gs_binning gs_render gs_fused gs_loss gs_init gs_density; do
   if [ "$o" == "$name" ]; then objs="$objs /tmp/_variant_${name}_$tag.o"; else objs="$objs $o.o"; fi
 done
