@@ -15,7 +15,9 @@
  * other operators are pinned by the reference's own known-answer tests
  * (tests/cuda_forward_test.cpp, tests/cuda_backward_test.cpp); the l=3 SH basis and the
  * per-coefficient SH gradients come from sphericart, which is NOT vendored in the
- * reference ("parity unpinned" for those two items).
+ * reference: they are pinned against scipy.special.sph_harm_y in sphericart's published
+ * convention (tests/test_oracle_known_answers.py); only the sphericart VERSION the
+ * reference would link stays unpinned.
  */
 
 #ifndef R
