@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace gs {
 
 constexpr float kAlphaMin = 0.00392156862f;  // 1/255, cuda/render.cu:74
@@ -272,6 +274,80 @@ __device__ __host__ __forceinline__ int row_moments9_index(int lane) {
   if (b1) return (b0 == 0 && b3 == 0) ? 7 + b2 : -1;  // the (cx cy | cy^2) register: lanes 2 and 6 of the row
   const int a = 4 * b0 + 2 * b3 + b2;                  // A0..A7 = rgb0 rgb1 rgb2 (dup) S_1 S_cx S_cy S_cx2
   return a < 3 ? a : (a == 3 ? -1 : a - 1);
+}
+
+// ---- r04: the same nine row sums with the first TWO butterfly stages folded into the products.  A quad = the four
+// lanes of one pixel row of the 4x4 block.  Three registers, each the quad-partial of up to four sums (one per lane of
+// the quad), built as  F * W_0 + qp1(F) * W_1 + qp2(F) * W_2 + qp3(F) * W_3  (qp_k = the quad permutation lane -> lane ^ k,
+// W_k = the weight of the sum THIS lane is responsible for, at the pixel of lane ^ k: loop-invariant lane constants):
+//   A from aT: lanes 0..2 of the quad -> rgb0, rgb1, rgb2        (lane 3: weight 0)
+//   B from gp: lanes 0..3             -> S_1, S_cx, S_cy, S_cx2
+//   C from gp: lanes 0..1             -> S_cxcy, S_cy2           (lanes 2, 3: weight 0)
+// = 3 v_mul + 9 v_fmac_dpp; then the four quads (= DPP banks) of the row are summed with the masked-bank pairs of
+// row_sum9: lanes 4 apart fold A and B into one register (banks 0,2: A, banks 1,3: B; 2 instructions) and C onto itself (1),
+// lanes 8 apart fold that pair (banks 0,1: the A / B totals; banks 2,3: C's; 2 instructions).  17 VALU + one wait state
+// instead of 22 + three; bank 0 ends with the rgb totals, bank 1 with S_1 S_cx S_cy S_cx2, lanes 8, 9 with S_cxcy S_cy2.
+struct QuadWeights { float a[4], b[4], c[4]; };
+
+// lane = lane in the wave, (cx, cy) and grad[3] this lane's pixel (cx relative to the tile centre: the lanes of a quad are
+// four pixels in a row, lane ^ k sits (lane ^ k) - lane pixels to the right)
+__device__ __forceinline__ QuadWeights make_quad_weights(int lane, float cx, float cy, float g0, float g1, float g2) {
+  const int p = lane & 3;
+  QuadWeights w;
+  auto qp = [](float v, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  // rgb: the lane that will RECEIVE through qp_k is lane ^ k, responsible for channel p ^ k: this lane offers that channel
+  auto offer = [&](int k) { const int ch = p ^ k; return ch == 0 ? g0 : ch == 1 ? g1 : ch == 2 ? g2 : 0.0f; };
+  w.a[0] = offer(0);
+  w.a[1] = qp(offer(1), std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
+  w.a[2] = qp(offer(2), std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
+  w.a[3] = qp(offer(3), std::integral_constant<int, 0x1B>{});  // quad_perm [3,2,1,0]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float cxk = cx + (float)((p ^ k) - p);  // pixel of lane ^ k (same row: cy is shared)
+    w.b[k] = p == 0 ? 1.0f : p == 1 ? cxk : p == 2 ? cy : cxk * cxk;
+    w.c[k] = p == 0 ? cxk * cy : p == 1 ? cy * cy : 0.0f;
+  }
+  return w;
+}
+
+__device__ __forceinline__ float row_moments9q(float aT, float gp, const QuadWeights &w) {
+  float A, B, C;
+  asm volatile(
+      // the three plain products first: they are also the wait states between the instruction that wrote gp and its
+      // first DPP read
+      "v_mul_f32 %[A], %[aT], %[a0]\n\t"
+      "v_mul_f32 %[B], %[gp], %[b0]\n\t"
+      "v_mul_f32 %[C], %[gp], %[c0]\n\t"
+      "v_fmac_f32_dpp %[C], %[gp], %[c1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[C], %[gp], %[c2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[C], %[gp], %[c3] quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[A], %[aT], %[a1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[A], %[aT], %[a2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[A], %[aT], %[a3] quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[B], %[gp], %[b1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[B], %[gp], %[b2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[B], %[gp], %[b3] quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      // quads 4 lanes apart: C onto itself (banks 0 and 2 end with the pair sums), then A | B into A (banks 0,2 | 1,3)
+      "v_add_f32_dpp %[A], %[A], %[A] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[A], %[B], %[B] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[C], %[C], %[C] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      // quads 8 lanes apart: banks 0,1 keep the A | B totals, banks 2,3 take C's (bank 2: the total, bank 3: unused).
+      // (a VGPR written by VALU may be read through DPP two wait states later: C's fold and the s_nop cover A)
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %[A], %[A], %[A] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[A], %[C], %[C] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      : [A] "=&v"(A), [B] "=&v"(B), [C] "=&v"(C)
+      : [aT] "v"(aT), [gp] "v"(gp), [a0] "v"(w.a[0]), [a1] "v"(w.a[1]), [a2] "v"(w.a[2]), [a3] "v"(w.a[3]),
+        [b0] "v"(w.b[0]), [b1] "v"(w.b[1]), [b2] "v"(w.b[2]), [b3] "v"(w.b[3]), [c0] "v"(w.c[0]), [c1] "v"(w.c[1]),
+        [c2] "v"(w.c[2]), [c3] "v"(w.c[3]));
+  return A;
+}
+// which of the nine sums a lane holds after row_moments9q (0..2 rgb, 3 S_1, 4 S_cx, 5 S_cy, 6 S_cx2, 7 S_cxcy, 8 S_cy2; -1: none)
+__device__ __host__ __forceinline__ int row_moments9q_index(int lane) {
+  const int j = lane & 15;
+  return j < 3 ? j : (j >= 4 && j < 8) ? j - 1 : j == 8 ? 7 : j == 9 ? 8 : -1;
 }
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so

@@ -44,6 +44,11 @@
 #ifndef GS_EXTRA_FMA
 #define GS_EXTRA_FMA 0
 #endif
+// r04: the nine-value row reduction with two butterfly stages folded into the products (gs_render.h: row_moments9q,
+// 17 VALU + 1 wait state) instead of one (row_moments9, 22 + 3).  0 keeps the r01-r03 form (A/B: tools/ab).
+#ifndef GS_ROWSUM_QUAD
+#define GS_ROWSUM_QUAD 1
+#endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
@@ -387,7 +392,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (top <= 0) return;
   // where this lane's share of the nine row totals goes (see row_moments9), and the lane constants of the sums:
   // pixel position relative to the tile centre, pixel gradient
+#if GS_ROWSUM_QUAD
+  const int red_idx = row_moments9q_index(lane);
+#else
   const int red_idx = row_moments9_index(lane);
+#endif
   const bool red_lane = red_idx >= 0;
   const unsigned int acc_lane = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)accb + (unsigned int)(red_idx * 8);
 
@@ -441,8 +450,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       // kernel they push it past the 80-register step and the compiler spills them to scratch (+0.2 GB of traffic).
       float g0b = g0, g1b = g1, g2b = g2;
       asm volatile("" : "+v"(g0b), "+v"(g1b), "+v"(g2b));
+#if GS_ROWSUM_QUAD
+      // (from the opaque index, like the addresses above: derived from the plain thread index the twelve weights are
+      // loop-invariant for the whole kernel, get hoisted above the batch loop and spilled)
+      const QuadWeights rw = make_quad_weights(t & 63, (float)(((t >> 6) & 1) * 8 + ((t >> 4) & 1) * 4 + (t & 3)) - 7.5f,
+                                               (float)((t >> 7) * 8 + ((t >> 5) & 1) * 4 + ((t >> 2) & 3)) - 7.5f, g0b, g1b, g2b);
+#else
       const RowWeights rw = make_row_weights(lane, (float)((wave & 1) * 8 + (row & 1) * 4 + (j & 3)) - 7.5f,
                                              (float)((wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2)) - 7.5f, g0b, g1b, g2b);
+#endif
       // The loop is bound by VALU issue at the measured per-instruction costs (tools/valu_cost_model.py: compares,
       // selects and min/max cost 4.4 cycles per wave instruction against 2.9 for a multiply), so it exists twice: when
       // every pixel of the wave needs the whole batch (no pixel stopped inside it: the common case), the per-trip
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
           const float4 c = make_float4(0.5f, 0.25f, 0.125f, 0.0f);
 #else
           const float4 c = *reinterpret_cast<const float4 *>(r2b + off);
+          asm volatile("" ::"v"(c.w));  // keep the 16-byte read: as ds_read_b96 it costs twice the LDS cycles (8 vs 4)
 #endif
           const float dx = a.x - fpx, dy = a.y - fpy;
           // opa * exp(power): d alpha / d gg . gg (the reference differentiates through the 0.99 cap as if absent)
@@ -502,7 +519,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #if GS_ABLATE == 2
           asm volatile("" ::"v"(aT), "v"(gp));
 #else
+#if GS_ROWSUM_QUAD
+          const float red = row_moments9q(aT, gp, rw);
+#else
           const float red = row_moments9(aT, gp, rw);
+#endif
 #if GS_ABLATE == 1
           asm volatile("" ::"v"(red));
 #else

@@ -598,7 +598,7 @@ def run_rank(args, comm, device_index):
 
     # ---- three views in turn on one context (extra key): the forward queues its tail -- placement, per-tile sorts,
     # compositing -- BEFORE the host has seen this view's counts, from the previous forward's route, cull ratio and longest
-    # list; the timed region repeats one view, so it only ever measures that speculation on a hit.  View B stands 8 units
+    # list; the timed region repeats one view, so it only ever measures that speculation on a hit.  View B stands 16 units
     # further back (everything in view and closer together on screen: the longest list several times view A's, beyond the
     # sort kernels queued on A's figures: a redo), view C 3 units further in (part of the scene behind it: a different
     # cull ratio, so the walk over compacted slots switches on and off).
@@ -611,7 +611,7 @@ def run_rank(args, comm, device_index):
                 vm[11] = tz  # t_z (R = I for view 0): camera position (0, 0, -tz)
                 cm["view"], cm["campos"] = vm, np.array([0.0, 0.0, -tz], np.float32)
                 return raster.device_camera(cm, dev)
-            cams = [("view_a", dc), ("view_b_8_back", moved(8.0)), ("view_c_3_forward", moved(-3.0))]
+            cams = [("view_a", dc), ("view_b_16_back", moved(16.0)), ("view_c_3_forward", moved(-3.0))]
             actx = raster.RasterContext(N, W, H)
             actx.set_lean_forward(True)
             ag = actx.alloc_gradients(N, L)

@@ -20,13 +20,24 @@ __global__ void km(const float *in, float *out) {
   out[lane] = gs::row_moments9(aT, gp, w);
 }
 
-static int test_moments(const float *h, float *d_in, float *d_out) {
+// row_moments9q (r04: two butterfly stages folded into the products): cx / cy are the REAL pixel offsets of the lane
+// (the quad's four lanes are four pixels in a row -- make_quad_weights derives the neighbours' cx from that)
+__global__ void kq(const float *in, float *out) {
+  const int lane = threadIdx.x;
+  const float aT = in[lane], gp = in[64 + lane], cx = in[128 + lane], cy = in[192 + lane];
+  const float g0 = in[256 + lane], g1 = in[320 + lane], g2 = in[384 + lane];
+  const gs::QuadWeights w = gs::make_quad_weights(lane, cx, cy, g0, g1, g2);
+  out[lane] = gs::row_moments9q(aT, gp, w);
+}
+
+static int test_moments(const float *h, float *d_in, float *d_out, bool quad = false) {
   float o[64];
-  km<<<1, 64>>>(d_in, d_out);
+  if (quad) kq<<<1, 64>>>(d_in, d_out);
+  else km<<<1, 64>>>(d_in, d_out);
   hipMemcpy(o, d_out, sizeof(o), hipMemcpyDeviceToHost);
   int bad = 0, active = 0;
   for (int lane = 0; lane < 64; ++lane) {
-    const int row = lane >> 4, idx = gs::row_moments9_index(lane);
+    const int row = lane >> 4, idx = quad ? gs::row_moments9q_index(lane) : gs::row_moments9_index(lane);
     if (idx < 0) continue;
     ++active;
     double ref = 0.0;
@@ -43,7 +54,8 @@ static int test_moments(const float *h, float *d_in, float *d_out) {
     }
   }
   if (active != 36) { std::printf("row_moments9: %d active lanes, want 36\n", active); ++bad; }
-  std::printf(bad ? "row_moments9: %d mismatches\n" : "row_moments9: ok\n", bad);
+  if (quad) std::printf(bad ? "row_moments9q: %d mismatches\n" : "row_moments9q: ok\n", bad);
+  else std::printf(bad ? "row_moments9: %d mismatches\n" : "row_moments9: ok\n", bad);
   return bad;
 }
 
@@ -66,5 +78,13 @@ int main() {
   }
   std::printf(bad ? "row_sum9: %d mismatches\n" : "row_sum9: ok\n", bad);
   bad += test_moments(h, d_in, d_out);
+  // the quad form needs a real pixel grid in (cx, cy): lane j of a row = pixel (j & 3, j >> 2) of a 4x4 block
+  for (int lane = 0; lane < 64; ++lane) {
+    const int row = lane >> 4, j = lane & 15;
+    h[128 + lane] = (float)((row & 1) * 4 + (j & 3)) - 7.5f;
+    h[192 + lane] = (float)((row >> 1) * 4 + (j >> 2)) - 7.5f;
+  }
+  hipMemcpy(d_in, h, sizeof(h), hipMemcpyHostToDevice);
+  bad += test_moments(h, d_in, d_out, true);
   return bad != 0;
 }
