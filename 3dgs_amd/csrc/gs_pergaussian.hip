@@ -206,8 +206,15 @@ __global__ __launch_bounds__(kBlock) void sh_bwd_kernel(const float *__restrict_
 // counts in LDS itself and adds a row's slice base.
 constexpr int kMaskSlices = 256;
 __device__ __host__ inline long long mask_slice_first(long long N, int s) { return N * s / kMaskSlices; }
-// the slice that holds row i: the largest s with mask_slice_first(N, s) <= i
-__device__ inline int mask_slice_of(long long N, long long i) { return (int)(((i + 1) * kMaskSlices - 1) / N); }
+// the slice that holds row i: the largest s with mask_slice_first(N, s) <= i, i.e. floor(((i + 1) * kMaskSlices - 1) / N)
+// -- without the 64-bit division (~100 instructions per element, more than the rest of the row kernel): a float
+// estimate, corrected by at most one step either way against the exact slice bounds (a multiply and a shift each)
+__device__ inline int mask_slice_of(int N, unsigned int i, float slices_per_row) {
+  int s = min(kMaskSlices - 1, (int)(((float)i + 0.5f) * slices_per_row));
+  while (mask_slice_first(N, s) > (long long)i) --s;
+  while (mask_slice_first(N, s + 1) <= (long long)i) ++s;
+  return s;
+}
 
 __global__ __launch_bounds__(1024) void mask_slice_ranks_kernel(const unsigned char *__restrict__ mask, int N,
                                                                 int *__restrict__ ranks, int *__restrict__ slice_counts) {
@@ -274,13 +281,14 @@ __global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__rest
   __shared__ int s_base[kMaskSlices + 1];
   mask_slice_bases(slice_counts, s_base);
   const unsigned int stride = kStride > 0 ? (unsigned int)kStride : (unsigned int)stride_rt;
+  const float slices_per_row = (float)kMaskSlices / (float)N;
 #pragma unroll
   for (int r = 0; r < kRowsPer; ++r) {
     const unsigned int e = (blockIdx.x * kRowsPer + r) * kBlock + threadIdx.x;
     if (e >= total) return;
     const unsigned int i = e / stride, k = e - i * stride;
     if (!mask[i]) continue;
-    const size_t slot = (size_t)(s_base[mask_slice_of(N, i)] + ranks[i]);
+    const size_t slot = (size_t)(s_base[mask_slice_of(N, i, slices_per_row)] + ranks[i]);
     if (kScatter) dst[e] = src[slot * stride + k];
     else dst[slot * stride + k] = src[e];
   }
