@@ -846,7 +846,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
   const int walk_chunks = bin_chunks(compact_walk ? M : N);
   auto place = [&](int tile, unsigned long long pay) {
     const int pos = atomicAdd(&s_cur[tile], 1);
+#if defined(GS_SCATTER_WINDOW)
+    // diagnostic build (tools/experiments/r04_scatter_window.sh): every store lands in a 128 KB window that stays in L2,
+    // i.e. the kernel without the HBM cost of its isolated 8-byte stores (the lists are garbage: timing only)
+    if (pos < capacity) payload[pos & 0x3FFF] = pay;
+#else
     if (pos < capacity) payload[pos] = pay;
+#endif
   };
   // wave-uniform trip count: rectangles of more than 64 tiles carry no hit mask and repeat the separating-axis tests;
   // one lane walking thousands of tiles alone decided this kernel's duration on scenes with large splats, so the wave

@@ -644,6 +644,8 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
     render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   } else if (recs) {
     render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+  } else if (rows) {  // the reference operator's input arrays, gradient rows out (gsplat_render_image_backward stages them)
+    render_bwd_kernel<false, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   } else {
     render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
   }
@@ -681,6 +683,44 @@ int gsplat_render_image(const float *uv, const float *opacity, const float *coni
                                0, nullptr);
 }
 
+}  // extern "C"
+
+namespace {
+// rows[g] = {rgb3, opacity1, conic3, uv2, pad7} (what render_bwd_kernel<.., kRows = true> accumulates) added into the
+// reference operator's four gradient arrays ("+=", cuda_backward.cuh:116-122)
+__global__ __launch_bounds__(256) void rows_to_arrays_kernel(const float4 *__restrict__ rows, long long count,
+                                                             float *__restrict__ g_rgb, float *__restrict__ g_opacity,
+                                                             float *__restrict__ g_uv, float *__restrict__ g_conic) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= count) return;
+  const float4 a = rows[4 * g], b = rows[4 * g + 1];
+  const float c = rows[4 * g + 2].x;
+  // a row nobody added to stays +0: skip its nine read-modify-writes (most rows of an over-sized bound, below)
+  if (a.x == 0.0f && a.y == 0.0f && a.z == 0.0f && a.w == 0.0f && b.x == 0.0f && b.y == 0.0f && b.z == 0.0f &&
+      b.w == 0.0f && c == 0.0f)
+    return;
+  g_rgb[3 * g] += a.x; g_rgb[3 * g + 1] += a.y; g_rgb[3 * g + 2] += a.z;
+  g_opacity[g] += a.w;
+  g_conic[3 * g] += b.x; g_conic[3 * g + 1] += b.y; g_conic[3 * g + 2] += b.z;
+  g_uv[2 * g] += b.w; g_uv[2 * g + 1] += c;
+}
+
+// How many rows of `floats_per_row` floats fit between p and the end of the device allocation p points into: an upper
+// bound on the gaussian ids the caller's lists may hold (a larger id would index past the caller's own array).
+long long rows_to_allocation_end(const void *p, int floats_per_row) {
+  void *base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  const long long bytes = (long long)((const char *)base + size - (const char *)p);
+  return bytes / (4ll * floats_per_row);
+}
+}  // namespace
+
+extern "C" {
+
 int gsplat_render_image_backward(const float *uvs, const float *opacity, const float *conic, const float *rgb,
                                  float background_opacity, const int *sorted_splats,
                                  const int *splat_range_by_tile, const int *num_splats_per_pixel,
@@ -693,10 +733,43 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
   GS_REQUIRE_DEV(grad_opacity); GS_REQUIRE_DEV(grad_uv); GS_REQUIRE_DEV(grad_conic);
   GS_REQUIRE(image_width > 0 && image_height > 0, "image size must be positive");
   gs::RawSplats raw = {uvs, opacity, conic, rgb};
+  hipStream_t st = (hipStream_t)stream;
+  // Nine float atomics per (gaussian, tile) into FOUR arrays are four 64-byte atomic requests at the memory side where
+  // the fused path's 64-byte gradient row is one (MI355X_MICROARCH.md, global float atomics: ~1.3 TB/s of 64-byte
+  // requests chip-wide): at 1e6 gaussians / 1080p that is 8.9 M requests, ~0.4 ms, against 0.33 ms for the whole fused
+  // kernel (r04: 0.55 ms for this operator).  So the operator accumulates rows in library scratch and adds them to the
+  // caller's arrays in one pass.  The operator is not told the number of gaussians; the rows needed are bounded by the
+  // smallest of its per-gaussian arrays (an id beyond it would index past the caller's own allocation).  A bound that
+  // is unknown or wasteful (arrays carved out of a much larger allocation) keeps the direct atomics.
+  long long bound = -1;
+  {
+    const struct { const void *p; int w; } arrays[] = {{uvs, 2}, {opacity, 1}, {conic, 3}, {rgb, 3}, {grad_rgb, 3},
+                                                       {grad_opacity, 1}, {grad_uv, 2}, {grad_conic, 3}};
+    for (const auto &a : arrays) {
+      const long long r = rows_to_allocation_end(a.p, a.w);
+      if (r < 0) { bound = -1; break; }
+      bound = bound < 0 ? r : (r < bound ? r : bound);
+    }
+  }
+  const long long kMaxScratchRows = 4ll << 20;  // 256 MiB of rows: clearing more than that costs what the rows save
+  if (bound > 0 && bound <= kMaxScratchRows) {
+    gs::ScratchLock lock;
+    gs::DeviceBuffer &rows = gs::scratch(gs::SCR_GRADROWS);
+    int rc = rows.reserve((size_t)bound * 64);
+    if (rc) return rc;
+    GS_HIP(hipMemsetAsync(rows.ptr, 0, (size_t)bound * 64, st));
+    rc = gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
+                               final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
+                               rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    rows_to_arrays_kernel<<<gs::div_up(bound, 256), 256, 0, st>>>(rows.as<float4>(), bound, grad_rgb, grad_opacity, grad_uv,
+                                                                  grad_conic);
+    GS_LAUNCH_CHECK();
+    return GSPLAT_OK;
+  }
   return gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, (hipStream_t)stream, nullptr, nullptr,
-                               nullptr);
+                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, st, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

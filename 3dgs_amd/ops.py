@@ -219,14 +219,18 @@ def gather_rows(src, order):
 
 
 def compact_masked_array(stride, d_source, d_mask, num_culled=None):
-    """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride]."""
+    """compact_masked_array<STRIDE>(d_source, d_mask, num_culled) -> new tensor [num_culled*stride].  With num_culled
+    given the count is trusted, as the reference's template does (cuda_data.cuh:106-127): no read-back, the call stays
+    asynchronous; without it the library reads the count back (blocks the host)."""
     N = int(d_mask.numel())
+    if num_culled is not None:
+        out = torch.empty(max(int(num_culled) * stride, 1), dtype=torch.float32, device=d_mask.device if N else "cuda")
+        check(_lib.load().gsplat_compact_masked_array(_p(d_source), _p(d_mask), N, stride, _p(out), None, _stream()))
+        return out[: int(num_culled) * stride]
     out = torch.empty(max(N * stride, 1), dtype=torch.float32, device=d_mask.device if N else "cuda")
     n = ctypes.c_int(0)
     check(_lib.load().gsplat_compact_masked_array(_p(d_source), _p(d_mask), N, stride, _p(out), ctypes.byref(n),
                                                   _stream()))
-    if num_culled is not None and int(num_culled) != n.value:
-        raise ValueError(f"num_culled={num_culled} but the mask selects {n.value}")
     return out[: n.value * stride]
 
 

@@ -4,7 +4,8 @@ MI355X_MICROARCH.md prescribes for gfx950; wave-level VALU instructions per laun
 own VALU-busy figure, rocprof's VALUBusy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * kernel cycles) with kernel cycles =
 GRBM_GUI_ACTIVE / 8 XCDs (a wave holds its SIMD's VALU for one quad-cycle per instruction; values above 1 mean two waves'
 instructions overlapping in the pipe, i.e. a saturated issue port).
-The file records the hash of the device sources it was measured on (3dgs_amd/_lib.py source_hash); bench.py reports
+The file records the hash of the device sources the measured library was built from (3dgs_amd/_lib.py
+library_source_hash: the hash embedded in the binary); bench.py reports
 the counter-derived figures only when that hash matches the library it runs.
 usage: python3 profiles/make_traffic.py profiles/r02_pmc_summary.json > profiles/traffic.json"""
 import importlib, json, os, sys
@@ -12,7 +13,8 @@ import importlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 d = json.load(open(sys.argv[1]))
-out = {"source_sha16": importlib.import_module("3dgs_amd._lib").source_hash()}
+# the hash the LOADED binary carries (gsplat_source_hash): what the counters were measured on
+out = {"source_sha16": importlib.import_module("3dgs_amd._lib").library_source_hash()}
 for name, k in (("render_backward", "render_bwd_kernel"), ("render_forward", "render_fwd_kernel")):
     v = d[k]
     out[name] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)

@@ -153,12 +153,13 @@ struct Host {
     auto scale_sel = compact_masked_array<3>(prm.d_scale, pass.d_mask, M);
     auto xyz_sel = compact_masked_array<3>(prm.d_xyz, pass.d_mask, M);
     auto rgb_sel = compact_masked_array<3>(prm.d_rgb, pass.d_mask, M);
+    laps.lap("compact_masked_array x7 (auto)");
     thrust::device_vector<float> sh_sel;
     if (l_max == 1) sh_sel = compact_masked_array<9>(prm.d_sh, pass.d_mask, M);
     else if (l_max == 2) sh_sel = compact_masked_array<24>(prm.d_sh, pass.d_mask, M);
     else if (l_max == 3) sh_sel = compact_masked_array<45>(prm.d_sh, pass.d_mask, M);
     const float3 campos = make_float3((float)image.campos[0], (float)image.campos[1], (float)image.campos[2]);
-    laps.lap("compact_masked_array x8");
+    laps.lap("compact_masked_array<45> into a thrust::device_vector (trainer.cu:950-960)");
 
     render_image_backward(raw(uv_sel), raw(opacity_sel), raw(pass.d_conic), raw(pass.d_precomputed_rgb), bg,
                           raw(pass.d_sorted_gaussians), raw(pass.d_splat_start_end_idx_by_tile_idx),

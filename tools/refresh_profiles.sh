@@ -9,6 +9,8 @@ python -c "import importlib; importlib.import_module('3dgs_amd._lib').build()"  
 export GSPLAT_NO_BUILD=1
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 export GSPLAT_BENCH_TRAIN_STEP=0   # the profiled runs: the headline workload's kernels only
+# ... and no child processes under the profiler (the C++ reference host, the one-rank RCCL rehearsal)
+export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-workloads > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats.log 2>&1
 cd $GRAFT_REPO_ROOT
