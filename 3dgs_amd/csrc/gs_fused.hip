@@ -49,11 +49,13 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero, long long zero_vec,
-                      unsigned short *masks_out);
+                      unsigned short *masks_out, const int *order, int *tops_out);
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st,
-                      const unsigned short *masks_in, hipEvent_t ev_start, hipEvent_t ev_stop);
+                      const unsigned short *masks_in, hipEvent_t ev_start, hipEvent_t ev_stop, const int *order);
+int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *order, hipStream_t st);
+bool tile_order_supported(int num_tiles);
 }  // namespace gs
 
 struct gsplat_context {
@@ -67,6 +69,10 @@ struct gsplat_context {
   gs::DeviceBuffer blockmasks;  // per instance: the 16 block bits of the compositing kernels (forward -> backward)
   // per tile / pixel
   gs::DeviceBuffer ranges, image, T_px, n_px;
+  // r04: the backward's tiles heaviest first (tile_order_kernel): per tile the largest stop index of its pixels, written
+  // by render_fwd, and the order table made from it right behind the forward (off the backward's critical path)
+  gs::DeviceBuffer tile_tops, tile_order;
+  bool order_ready = false;  // tile_order belongs to the recorded forward
   int *h_words = nullptr;  // pinned
   bool dense_route = false;  // binning route of the next forward (follows the last one's density)
   int forced_route = 0;      // gsplat_context_set_binning_route: 0 auto, 1 counting sort, 2 radix sorts
@@ -117,7 +123,7 @@ struct gsplat_context {
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept};
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -125,7 +131,7 @@ struct gsplat_context {
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept};
+                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
     for (auto *p : all) p->release();
     fork.destroy();
     if (h_words) (void)hipHostFree(h_words);
@@ -140,6 +146,12 @@ struct gsplat_context {
 namespace {
 
 constexpr int kBlock = 256;
+
+// GSPLAT_NO_TILE_ORDER=1: the backward takes its tiles in the plain XCD-run order (A/B of r04's heaviest-first order)
+bool gs_no_tile_order() {
+  static const bool v = [] { const char *e = getenv("GSPLAT_NO_TILE_ORDER"); return e && e[0] == '1'; }();
+  return v;
+}
 
 // ---- A: world -> camera -> pixel -> keep-mask, for all N, and the compaction ranks
 // kBinBlocks workgroups of kBinThreads; workgroup b owns the global indices of the chunks [C*b/kBinBlocks,
@@ -970,6 +982,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64); R(c->hitmask, N * 8);
   R(c->ranges, (T + 1) * 4); R(c->image, P * 12); R(c->T_px, P * 4); R(c->n_px, P * 4);
+  R(c->tile_tops, (T + 8) * 4); R(c->tile_order, (T + 8) * 4);
   if (!rc) {
     size_t sb1 = 0;
     (void)rocprim::exclusive_scan(nullptr, sb1, (int *)nullptr, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
@@ -1031,6 +1044,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   hipStream_t st = (hipStream_t)stream;
   c->have_forward = false;
   c->rows_ready = false;
+  c->order_ready = false;
   const int ntx = (W + 15) / 16, nty = (H + 15) / 16, num_tiles = ntx * nty;
   const float fx = cam->focal_x, fy = cam->focal_y;
   const float tan_fovx = (float)W / (2.0f * fx), tan_fovy = (float)H / (2.0f * fy);  // cuda/raster.cu:92-93
@@ -1152,12 +1166,17 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (r) return r;
     c->mark(2, true, st);
     c->mark(4, false, st);
+    const bool ordered = !ro && gs::tile_order_supported(num_tiles);
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
-                              ro ? nullptr : c->blockmasks.as<unsigned short>());
+                              ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
+                              ordered ? c->tile_tops.as<int>() : nullptr);
     if (r) return r;
     c->mark(4, true, st);
+    // the backward's tile order, behind the forward: nothing waits for it until the loss has produced dL/dimage
+    if (ordered && (r = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return r;
+    c->order_ready = ordered;
     return GSPLAT_OK;
   };
   // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
@@ -1232,12 +1251,16 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (rc) return rc;
     c->mark(2, true, st);
     c->mark(4, false, st);
+    const bool ordered = !ro && gs::tile_order_supported(num_tiles);
     rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                                c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                                c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
-                               ro ? nullptr : c->blockmasks.as<unsigned short>());
+                               ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
+                               ordered ? c->tile_tops.as<int>() : nullptr);
     if (rc) return rc;
     c->mark(4, true, st);
+    if (ordered && (rc = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return rc;
+    c->order_ready = ordered;
   }
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
   c->tan_fovx = tan_fovx; c->tan_fovy = tan_fovy; c->mh_dist = cfg->mh_dist;
@@ -1281,7 +1304,8 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,
                                  c->blockmasks.as<unsigned short>(), timed ? c->ev[c->slot][12] : nullptr,
-                                 timed ? c->ev[c->slot][13] : nullptr);
+                                 timed ? c->ev[c->slot][13] : nullptr,
+                                 (c->order_ready && !gs_no_tile_order()) ? c->tile_order.as<int>() : nullptr);
   if (rc) return rc;
   if (timed) c->pending[c->slot][6] = 1;
   if (rgb_global) {

@@ -358,5 +358,13 @@ __device__ __forceinline__ int block_to_tile(int block, int num_tiles) {
   return (block & 7) * per_xcd + (block >> 3);
 }
 static inline int tile_grid(int num_tiles) { return ((num_tiles + 7) >> 3) * 8; }
+// r04: the same map through an optional order table (tile_order_kernel, gs_render.hip): slot s of the table holds the tile
+// that the block mapped to slot s should take -- every XCD's run of tiles re-ordered heaviest first, so that the
+// launch's last round is made of its lightest tiles (entries >= num_tiles: padding)
+__device__ __forceinline__ int ordered_tile(const int *__restrict__ order, int block, int num_tiles) {
+  const int slot = block_to_tile(block, num_tiles);
+  return order ? order[slot] : slot;
+}
+constexpr int kOrderMaxRun = 2048;  // tiles per XCD run the order kernel handles (16384 tiles: the counting-sort limit)
 
 }  // namespace gs

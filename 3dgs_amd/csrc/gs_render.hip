@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
                                                               int ntx, int num_tiles, float bg,
                                                               int *__restrict__ n_out, float *__restrict__ T_out,
                                                               float *__restrict__ image, float4 *__restrict__ zero,
-                                                              long long zero_vec, unsigned short *__restrict__ masks_out) {
+                                                              long long zero_vec, unsigned short *__restrict__ masks_out,
+                                                              const int *__restrict__ order, int *__restrict__ tops_out) {
   __shared__ float4 s_r0[kBatch + 1], s_r1[kBatch + 1], s_r2[kBatch + 1];  // [kBatch]: the all-zero sentinel record
+  __shared__ int s_tile_top;
   __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride + 2];
   // Optional side job: every workgroup clears its share of `zero` (the gradient rows the backward accumulates into).
   // This kernel leaves most of the HBM bandwidth unused, so the 64 bytes per gaussian ride along for free instead of
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     const long long per = (zero_vec + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = min(lo + per, zero_vec);
     for (long long k = lo + threadIdx.x; k < hi; k += 256) zero[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  const int tile = block_to_tile(blockIdx.x, num_tiles);
+  const int tile = ordered_tile(order, blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
 #if GS_STAMP
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   if (tid == 0) {
     s_r0[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     s_r1[kBatch] = sentinel_r1();
+    s_tile_top = 0;
   }
   const int tile_x = tile % ntx, tile_y = tile / ntx;
   const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
@@ -281,6 +284,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     GS_LAP(st_bar2);
     if (all_done) break;
   }
+  if (tops_out) {
+    // the tile's work in the backward = the largest stop index of its pixels (cuda/render_backward.cu:64,74): handed to
+    // tile_order_kernel, which deals the backward's tiles heaviest first
+    int top = inside ? n : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if (lane == 0) atomicMax(&s_tile_top, top);
+    __syncthreads();
+    if (tid == 0) tops_out[tile] = s_tile_top;
+  }
   if (inside) {
     const int pid = py * width + px;
     const float Tout = T_fin >= 0.0f ? T_fin : T;  // T_fin is set by the splat that saturated the pixel
@@ -316,7 +329,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                               const float *__restrict__ T_px,
                                                               const float *__restrict__ grad_image, int width,
                                                               int height, int ntx, int num_tiles, float bg,
-                                                              GradOut out, const unsigned short *__restrict__ masks_in) {
+                                                              GradOut out, const unsigned short *__restrict__ masks_in,
+                                                              const int *__restrict__ order) {
   __shared__ float4 s_r0[kB + 1], s_r1[kB + 1];  // [kB]: the all-zero sentinel record
   // [slot][9]: rgb, S0, Sx, Sy, Sxx, Sxy, Syy.  Doubles on purpose: on gfx950 ds_add_f32 retires about one LANE
   // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   float *s_res = reinterpret_cast<float *>(s_mix);
   static_assert(kB * 9 * 4 <= 16 * kB * 2 + kB * 16, "the flush values must not reach the sentinel record");
   __shared__ int s_top;
-  const int tile = block_to_tile(blockIdx.x, num_tiles);
+  const int tile = ordered_tile(order, blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
 #if GS_STAMP
@@ -610,17 +624,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
 }
 
+// Deals every XCD's run of tiles heaviest first (r04).  The hardware starts workgroups in block order, so with the plain
+// map the launch ends on whatever tiles sit at the end of the runs, and its last round lasts as long as the heaviest of
+// them; heaviest first, the last round is made of the lightest tiles of the image.  `work[t]`: list length (forward) or
+// the largest stop index of the tile's pixels (backward).  One workgroup per XCD run (at most kOrderMaxRun tiles): a
+// counting sort on 64 classes of work relative to the run's maximum, all in LDS -- the order inside a class does not
+// matter.  order[x * per_xcd + k] = the k-th heaviest tile of run x; padding slots get num_tiles.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const int *__restrict__ work, const int *__restrict__ ranges,
+                                                          int num_tiles, int *__restrict__ order) {
+  constexpr int kClasses = 64, kPer = kOrderMaxRun / 1024;
+  __shared__ int s_max, s_count[kClasses], s_base[kClasses];
+  const int per_xcd = (num_tiles + 7) >> 3, first = blockIdx.x * per_xcd;
+  if (threadIdx.x < kClasses) s_count[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  int w[kPer], cls[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int t = first + threadIdx.x + k * 1024;
+    const bool in = threadIdx.x + k * 1024 < per_xcd && t < num_tiles;
+    w[k] = in ? (work ? work[t] : ranges[t + 1] - ranges[t]) : -1;
+  }
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) m = max(m, w[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&s_max, m);
+  __syncthreads();
+  const float scale = (float)kClasses / (float)(s_max + 1);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    // class 0 = the heaviest; padding slots (w < 0) behind everything
+    cls[k] = w[k] < 0 ? -1 : kClasses - 1 - min(kClasses - 1, (int)((float)w[k] * scale));
+    if (cls[k] >= 0) atomicAdd(&s_count[cls[k]], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < kClasses) {  // exclusive scan of the 64 class counts by one wave
+    const int c = s_count[threadIdx.x];
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if ((int)threadIdx.x >= off) incl += u;
+    }
+    s_base[threadIdx.x] = incl - c;
+    s_count[threadIdx.x] = 0;  // becomes the class cursor
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    if (cls[k] >= 0) order[first + s_base[cls[k]] + atomicAdd(&s_count[cls[k]], 1)] = first + threadIdx.x + k * 1024;
+  // padding slots of the run: the tiles of the run come first (their count = the sum of the class counts)
+  __syncthreads();
+  int total = 0;
+  if (threadIdx.x < 64) {
+    int c = s_count[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    total = c;
+    if (threadIdx.x == 0) s_max = total;
+  }
+  __syncthreads();
+  total = s_max;
+  for (int k = total + threadIdx.x; k < per_xcd; k += 1024) order[first + k] = num_tiles;
+}
+
+int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *order, hipStream_t st) {
+  if (((num_tiles + 7) >> 3) > kOrderMaxRun) return GSPLAT_ERR_INVALID_ARG;  // (callers check: no order table then)
+  tile_order_kernel<<<8, 1024, 0, st>>>(work, ranges, num_tiles, order);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+bool tile_order_supported(int num_tiles) { return ((num_tiles + 7) >> 3) <= kOrderMaxRun; }
+
 // host-side launchers shared with gs_fused.hip ------------------------------------------
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero,
-                      long long zero_vec, unsigned short *masks_out) {
+                      long long zero_vec, unsigned short *masks_out, const int *order, int *tops_out) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   if (recs) {
-    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out);
+    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out);
   } else {
-    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr);
+    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr, order, tops_out);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -629,7 +717,7 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in,
-                      hipEvent_t ev_start, hipEvent_t ev_stop) {
+                      hipEvent_t ev_start, hipEvent_t ev_stop, const int *order) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
@@ -639,15 +727,15 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
     // its completion signal.  Two hipEventRecord calls around the launch are barrier packets of their own and kept the
     // GPU idle for ~11 us before and ~6 us after the kernel in every step they were on.
     hipExtLaunchKernelGGL((render_bwd_kernel<true, true, GS_BWD_BATCH>), grid, block, 0, st, ev_start, ev_stop, 0, recs, none,
-                          sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+                          sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
   } else if (recs && rows) {
-    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
   } else if (recs) {
-    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
   } else if (rows) {  // the reference operator's input arrays, gradient rows out (gsplat_render_image_backward stages them)
-    render_bwd_kernel<false, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+    render_bwd_kernel<false, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
   } else {
-    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in);
+    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -680,7 +768,7 @@ int gsplat_render_image(const float *uv, const float *opacity, const float *coni
   gs::RawSplats raw = {uv, opacity, conic, rgb};
   return gs::launch_render_fwd(nullptr, &raw, sorted_splats, splat_range_by_tile, image_width, image_height,
                                background_opacity, splats_per_pixel, weight_per_pixel, image, (hipStream_t)stream, nullptr,
-                               0, nullptr);
+                               0, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"
@@ -760,7 +848,7 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
     GS_HIP(hipMemsetAsync(rows.ptr, 0, (size_t)bound * 64, st));
     rc = gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr);
+                               rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
     rows_to_arrays_kernel<<<gs::div_up(bound, 256), 256, 0, st>>>(rows.as<float4>(), bound, grad_rgb, grad_opacity, grad_uv,
                                                                   grad_conic);
@@ -769,7 +857,7 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
   }
   return gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, st, nullptr, nullptr, nullptr);
+                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, st, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"
