@@ -71,7 +71,7 @@ struct gsplat_context {
   gs::DeviceBuffer ranges, image, T_px, n_px;
   // r04: the backward's tiles heaviest first (tile_order_kernel): per tile the largest stop index of its pixels, written
   // by render_fwd, and the order table made from it right behind the forward (off the backward's critical path)
-  gs::DeviceBuffer tile_tops, tile_order, tile_order_fwd;
+  gs::DeviceBuffer tile_tops, tile_order;
   bool order_ready = false;  // tile_order belongs to the recorded forward
   int *h_words = nullptr;  // pinned
   bool dense_route = false;  // binning route of the next forward (follows the last one's density)
@@ -123,7 +123,7 @@ struct gsplat_context {
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order, &tile_order_fwd};
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -131,7 +131,7 @@ struct gsplat_context {
   void release() {
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order, &tile_order_fwd};
+                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
     for (auto *p : all) p->release();
     fork.destroy();
     if (h_words) (void)hipHostFree(h_words);
@@ -982,7 +982,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64); R(c->hitmask, N * 8);
   R(c->ranges, (T + 1) * 4); R(c->image, P * 12); R(c->T_px, P * 4); R(c->n_px, P * 4);
-  R(c->tile_tops, (T + 8) * 4); R(c->tile_order, (T + 8) * 4); R(c->tile_order_fwd, (T + 8) * 4);
+  R(c->tile_tops, (T + 8) * 4); R(c->tile_order, (T + 8) * 4);
   if (!rc) {
     size_t sb1 = 0;
     (void)rocprim::exclusive_scan(nullptr, sb1, (int *)nullptr, (int *)nullptr, 0, N + 1, rocprim::plus<int>(), (hipStream_t)0);
@@ -1167,17 +1167,13 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     c->mark(2, true, st);
     c->mark(4, false, st);
     const bool ordered = !ro && gs::tile_order_supported(num_tiles);
-    // The forward's own tiles heaviest first (by list length) only where it can pay for the launch in front of
-    // render_fwd (~3 us on the critical path): scenes whose longest list is several times the average -- decided, like
-    // the rest of the queued tail, by the previous forward's figures (a uniform scene such as the benchmark's: never).
-    const bool skewed = gs::tile_order_supported(num_tiles) && !gs_no_tile_order() && c->last_longest > 0 && c->S > 0 &&
-                        c->last_longest * (long long)num_tiles > 4ll * (long long)c->S;
-    if (skewed && (r = gs::launch_tile_order(nullptr, c->ranges.as<int>(), num_tiles, c->tile_order_fwd.as<int>(), st))) return r;
+    // (The forward itself keeps the plain XCD-run order: dealt heaviest first by list length it was 10-14 us SLOWER on
+    // the garden-shaped workload, profiles/r04_tile_order_ab.txt -- the list length says little about a dense tile's
+    // forward, whose pixels saturate early, and neighbouring tiles no longer run side by side on one XCD's L2.)
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
-                              ro ? nullptr : c->blockmasks.as<unsigned short>(),
-                              skewed ? c->tile_order_fwd.as<int>() : nullptr,
+                              ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
                               ordered ? c->tile_tops.as<int>() : nullptr);
     if (r) return r;
     c->mark(4, true, st);

@@ -735,3 +735,43 @@ def test_render_only_context(gpu, scene, orc):
     assert fwd["sigma"] is not None
     ctx.backward_pass(dp, dc, gi, c["bg"], L, grads)
     torch.cuda.synchronize()
+
+
+def test_tile_order_changes_nothing(gpu, scene, orc):
+    """r04: the compositing backward takes its tiles heaviest first (tile_order_kernel, from the per-tile stop indices
+    render_fwd leaves).  The order only changes WHEN a tile is processed: the gradients must meet the oracle on a scene
+    whose tiles differ wildly in work -- the benchmark's gaussians plus a dense cluster over a few tiles (longest list
+    over 4x the average) -- and equal the plain order's (GSPLAT_NO_TILE_ORDER=1 is read once per process, so the plain
+    order runs through the stand-alone operator, which never orders) up to the float atomics' summation order."""
+    torch, raster, ops = gpu, pkg("raster"), pkg("ops")
+    N, W, H, L = 40000, 480, 272, 3
+    params = scene.make_gaussians(N, W, H, L)
+    rng = np.random.default_rng(7)
+    k = 6000  # a cluster in front of the camera, projected into ~4 tiles around the image centre
+    params["xyz"][:k, 0] = rng.normal(0.0, 0.05, k)
+    params["xyz"][:k, 1] = rng.normal(0.0, 0.05, k)
+    params["xyz"][:k, 2] = rng.uniform(4.0, 9.0, k)
+    cam = scene.make_camera(W, H, 0)
+    c = scene.CONFIG
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=8)
+    bref = orc.backward_pass(ref, cam, scene.make_grad_image(W, H), c["bg"], L, threads=8)
+    lens = np.diff(ref["ranges"])
+    assert lens.max() > 4 * lens.mean(), "the scene must be skewed"
+    ctx = raster.RasterContext(N, W, H)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    _check_forward(fwd, ref)
+    M = fwd["num_culled"]
+    g = ctx.alloc_gradients(M, L, intermediates=True)
+    ctx.backward_pass(dp, dc, gi, c["bg"], L, g)          # tiles in the order of their stop indices
+    _check_backward(g, bref)
+    # the same compositing backward in the plain tile order: the stand-alone operator on the forward's arrays
+    z = lambda *s_: torch.zeros(*s_, device="cuda")
+    p_rgb, p_op, p_uv, p_conic = z(M, 3), z(M), z(M, 2), z(M, 3)
+    ops.render_image_backward(fwd["uv"], dp["opacity"][fwd["compact_to_global"].long()].contiguous(), fwd["conic"], fwd["rgb"],
+                              c["bg"], fwd["sorted"], fwd["ranges"], fwd["n"], fwd["T"], gi, W, H, p_rgb, p_op, p_uv, p_conic)
+    assert_grad_close(_np(g["precompute_rgb"]), _np(p_rgb), "ordered vs plain: grad_rgb", rel=1e-4)
+    assert_grad_close(_np(g["opacity"]), _np(p_op), "ordered vs plain: grad_opacity", rel=1e-4)
+    assert_grad_close(_np(g["uv"]), _np(p_uv), "ordered vs plain: grad_uv", rel=1e-4)
+    assert_grad_close(_np(g["conic"]), _np(p_conic), "ordered vs plain: grad_conic", rel=1e-4)
