@@ -4,6 +4,7 @@
 // (tests/cuda_data_test.cpp:38-125).
 #include <cmath>
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 #include <thrust/copy.h>
@@ -66,6 +67,27 @@ int main() {
   scatter_masked_array<3>(comp, m, dst);
   thrust::host_vector<float> hd = dst;
   EXPECT(hd[0] == 10 && hd[2] == 12 && hd[3] == -1 && hd[6] == 13 && hd[8] == 15);
+  // gsplat_shim::device_array (what ForwardPassData and compact_masked_array hand out): copy, move, resize keeps the head,
+  // conversion to thrust's vectors, storage returned to the pool and taken again
+  {
+    gsplat_shim::device_array<float> a = compact_masked_array<3>(src, m, 2);
+    gsplat_shim::device_array<float> b = a;               // deep copy
+    gsplat_shim::device_array<float> c2 = std::move(a);   // a is empty now
+    EXPECT(a.empty() && b.size() == 6 && c2.size() == 6);
+    b.resize(9);                                          // grows: the first six elements survive
+    thrust::host_vector<float> hb = b;
+    EXPECT(hb.size() == 9 && hb[0] == 1 && hb[5] == 9);
+    thrust::device_vector<float> as_thrust = c2;          // the call sites that name thrust's type (trainer.cu:950-960)
+    EXPECT(as_thrust.size() == 6 && (float)as_thrust[3] == 7.f);
+    EXPECT((float)c2[4] == 8.f);
+    const float *before = thrust::raw_pointer_cast(c2.data());
+    c2 = gsplat_shim::device_array<float>();              // back to the pool ...
+    gsplat_shim::device_array<float> again(6);            // ... and out again: same size class, same block
+    EXPECT(thrust::raw_pointer_cast(again.data()) == before);
+    gsplat_shim::device_array<float> from_thrust(as_thrust);
+    thrust::host_vector<float> hf = from_thrust;
+    EXPECT(hf.size() == 6 && hf[0] == 1 && hf[5] == 9);
+  }
   if (failures == 0) std::printf("raster_shim_test: all checks passed\n");
   return failures ? 1 : 0;
 }

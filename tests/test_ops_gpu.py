@@ -376,3 +376,51 @@ def test_error_codes_instead_of_exit(gpu):
     with pytest.raises(lib_mod.GsplatError) as e:
         ops.precompute_spherical_harmonics(good, good, good, [0, 0, 0], 7, 1, good)
     assert e.value.code == -3
+
+
+def test_device_block_pool(gpu):
+    """gsplat_pool_alloc / _free / _release (r04: what the drop-in headers' per-iteration vectors draw from): a freed block
+    is handed to the next request of its size class, a foreign or doubly freed pointer is refused, release returns the idle
+    blocks to the runtime."""
+    import ctypes
+    torch, lib = gpu, pkg("_lib").load()
+    lib.gsplat_pool_release()
+    base_idle = lib.gsplat_pool_bytes(1)
+    p1, p2, p3 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.gsplat_pool_alloc(ctypes.byref(p1), 1_000_000) == 0 and p1.value
+    assert lib.gsplat_pool_alloc(ctypes.byref(p2), 1_000_000) == 0 and p2.value and p2.value != p1.value
+    live = lib.gsplat_pool_bytes(0)
+    assert live >= 2_000_000 and live <= 2 * 1_125_000 + base_idle  # size classes: at most 12.5 % slack
+    # the blocks are ordinary device memory
+    t = torch.empty(0, device="cuda")
+    assert lib.gsplat_compute_camera_space_points(p1, p1, 0, p2, None) == 0  # (N = 0: pointer checks only)
+    assert lib.gsplat_pool_free(p1) == 0
+    assert lib.gsplat_pool_bytes(1) > base_idle
+    assert lib.gsplat_pool_alloc(ctypes.byref(p3), 950_000) == 0
+    assert p3.value == p1.value, "a request of the same size class takes the cached block"
+    assert lib.gsplat_pool_free(p3) == 0 and lib.gsplat_pool_free(p2) == 0
+    assert lib.gsplat_pool_free(p2) == -3 and b"not allocated" in lib.gsplat_last_error()  # freed twice
+    assert lib.gsplat_pool_free(ctypes.c_void_p(t.data_ptr() or 4096)) == -3              # never ours
+    zero = ctypes.c_void_p(1)
+    assert lib.gsplat_pool_alloc(ctypes.byref(zero), 0) == 0 and not zero.value
+    assert lib.gsplat_pool_release() == 0 and lib.gsplat_pool_bytes(1) == 0
+
+
+def test_compact_with_trusted_count_matches_counted(gpu, orc):
+    """compact_masked_array with num_culled given (the reference's call sites: no read-back, asynchronous) against the
+    counting form, for the strides with a compile-time instantiation and two without."""
+    torch, ops = gpu, pkg("ops")
+    rng = np.random.default_rng(9)
+    N = 70001  # not a multiple of anything: ragged last slice, last block, last wave
+    mask = rng.random(N) < 0.37
+    d_mask = _dev(torch, mask.astype(np.uint8))
+    for stride in (1, 2, 3, 4, 6, 9, 24, 45, 5, 7):
+        src = rng.normal(size=N * stride).astype(np.float32)
+        ref = orc.compact_masked_array(src, mask, stride)
+        a = ops.compact_masked_array(stride, _dev(torch, src), d_mask)
+        b = ops.compact_masked_array(stride, _dev(torch, src), d_mask, int(mask.sum()))
+        assert (a.cpu().numpy() == ref).all() and (b.cpu().numpy() == ref).all(), stride
+        dst = torch.full((N * stride,), -1.0, device="cuda")
+        ops.scatter_masked_array(stride, b, d_mask, dst)
+        want = orc.scatter_masked_array(ref, mask, stride, np.full(N * stride, -1.0, np.float32))
+        assert (dst.cpu().numpy() == want).all(), stride
