@@ -396,7 +396,7 @@ def test_device_block_pool(gpu):
     assert lib.gsplat_compute_camera_space_points(p1, p1, 0, p2, None) == 0  # (N = 0: pointer checks only)
     assert lib.gsplat_pool_free(p1) == 0
     assert lib.gsplat_pool_bytes(1) > base_idle
-    assert lib.gsplat_pool_alloc(ctypes.byref(p3), 950_000) == 0
+    assert lib.gsplat_pool_alloc(ctypes.byref(p3), 1_010_000) == 0  # same class (16 x 64 KiB)
     assert p3.value == p1.value, "a request of the same size class takes the cached block"
     assert lib.gsplat_pool_free(p3) == 0 and lib.gsplat_pool_free(p2) == 0
     assert lib.gsplat_pool_free(p2) == -3 and b"not allocated" in lib.gsplat_last_error()  # freed twice
