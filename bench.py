@@ -603,7 +603,7 @@ def run_rank(args, comm, device_index):
     # sort kernels queued on A's figures: a redo), view C 3 units further in (part of the scene behind it: a different
     # cull ratio, so the walk over compacted slots switches on and off).
     alternating = None
-    if world == 1 and do_bwd and args.workload == "config3":
+    if world == 1 and do_bwd and args.workload == "config3" and os.environ.get("GSPLAT_BENCH_ALTERNATING", "1") != "0":
         try:
             def moved(tz):
                 cm = dict(cam)

@@ -3,7 +3,7 @@
 # usage (on the GPU box, from the repo root): bash profiles/run_pmc.sh <outdir>
 set -e
 export GSPLAT_BENCH_TRAIN_STEP=0
-export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0   # no child processes under the profiler
+export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0 GSPLAT_BENCH_ALTERNATING=0   # no child processes under the profiler
 export GSPLAT_NO_BUILD=1   # the profiled process has an initialised GPU: it must not spawn make / hipcc (build before)
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT

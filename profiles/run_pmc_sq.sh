@@ -2,7 +2,7 @@
 # SQ-only counter passes (faster than run_pmc.sh); usage: bash profiles/run_pmc_sq.sh <outdir>
 set -e
 export GSPLAT_BENCH_TRAIN_STEP=0
-export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0   # no child processes under the profiler
+export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0 GSPLAT_BENCH_ALTERNATING=0   # no child processes under the profiler
 export GSPLAT_NO_BUILD=1   # the profiled process has an initialised GPU: it must not spawn make / hipcc (build before)
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT

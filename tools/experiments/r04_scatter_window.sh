@@ -5,7 +5,7 @@
 # means anything).  Per-kernel times of both libraries from rocprofv3 (kernel trace only), same box, back to back.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export GSPLAT_NO_BUILD=1 GSPLAT_BENCH_TRAIN_STEP=0 GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0
+export GSPLAT_NO_BUILD=1 GSPLAT_BENCH_TRAIN_STEP=0 GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0 GSPLAT_BENCH_ALTERNATING=0
 for tag in base scw base scw; do
   lib=$R/3dgs_amd/libgsplat_hip.so; [ $tag == scw ] && lib=$R/tools/ab/libscw.so
   rm -rf $R/gpurun_out/scw_$tag

@@ -1,7 +1,7 @@
 #!/bin/bash
 # r04: the backward's tiles heaviest first (tile_order_kernel) against the plain XCD-run order (GSPLAT_NO_TILE_ORDER=1),
 # same box, alternating; per-stage times of the headline scene and of the garden-shaped workload
-export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0 GSPLAT_BENCH_TRAIN_STEP=0
+export GSPLAT_BENCH_REFERENCE_HOST=0 GSPLAT_BENCH_EXCHANGE_HOST_COST=0 GSPLAT_BENCH_ALTERNATING=0 GSPLAT_BENCH_TRAIN_STEP=0
 for round in 1 2; do
 for off in 0 1; do
   GSPLAT_NO_TILE_ORDER=$off timeout -k 10 400 python bench.py --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
