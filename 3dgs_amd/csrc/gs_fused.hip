@@ -99,7 +99,7 @@ struct gsplat_context {
   // what the speculative forward did (gsplat_context_get_counters): forwards, forwards whose queued tail had to be redone
   // (instances outgrew the room, or the longest list needed a sort kernel that was not queued), forwards that walked the
   // compacted slots, growths of the instance buffers
-  long long n_forwards = 0, n_tail_redone = 0, n_compact_walks = 0, n_instance_growths = 0;
+  long long n_forwards = 0, n_tail_redone = 0, n_compact_walks = 0, n_instance_growths = 0, n_ordered_backwards = 0;
   int slot = 0;
   void mark(int stage, bool stop, hipStream_t st) {
     if (!((timing >> stage) & 1u)) return;
@@ -1166,7 +1166,13 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (r) return r;
     c->mark(2, true, st);
     c->mark(4, false, st);
-    const bool ordered = !ro && gs::tile_order_supported(num_tiles);
+    // Heaviest-first for the backward only where the tiles differ enough in work to pay for it: the order breaks up the
+    // XCD runs' spatial adjacency (neighbouring tiles share records in one L2), which on the uniform benchmark scene cost
+    // +39 % HBM traffic in render_bwd (594 instead of 428 MB, profiles/r04_pmc_summary_all_tiles_ordered.json) for 2 % of
+    // its time; on a skewed scene (garden-shaped workload: longest list 7x the average) it is worth 6.5 %.  Decided like
+    // the rest of the queued tail by the previous forward's figures.
+    const bool ordered = !ro && gs::tile_order_supported(num_tiles) && !gs_no_tile_order() && c->last_longest > 0 &&
+                         c->S > 0 && c->last_longest * (long long)num_tiles > 3ll * (long long)c->S;
     // (The forward itself keeps the plain XCD-run order: dealt heaviest first by list length it was 10-14 us SLOWER on
     // the garden-shaped workload, profiles/r04_tile_order_ab.txt -- the list length says little about a dense tile's
     // forward, whose pixels saturate early, and neighbouring tiles no longer run side by side on one XCD's L2.)
@@ -1254,7 +1260,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (rc) return rc;
     c->mark(2, true, st);
     c->mark(4, false, st);
-    const bool ordered = !ro && gs::tile_order_supported(num_tiles);
+    const bool ordered = false;  // (radix route: the longest list is not known; see queue_tail)
     rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                                c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                                c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
@@ -1310,6 +1316,7 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
                                  timed ? c->ev[c->slot][13] : nullptr,
                                  (c->order_ready && !gs_no_tile_order()) ? c->tile_order.as<int>() : nullptr);
   if (rc) return rc;
+  if (c->order_ready && !gs_no_tile_order()) c->n_ordered_backwards++;
   if (timed) c->pending[c->slot][6] = 1;
   if (rgb_global) {
     scatter_rgb_rows_kernel<<<gs::div_up((long long)c->N * 3, kBlock), kBlock, 0, st>>>(
@@ -1409,9 +1416,9 @@ int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask)
 
 int gsplat_context_get_counters(gsplat_context *c, long long *out, int n) {
   GS_REQUIRE(c && out && n >= 0, "null argument");
-  const long long v[4] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths};
-  for (int k = 0; k < n && k < 4; ++k) out[k] = v[k];
-  return 4;
+  const long long v[5] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards};
+  for (int k = 0; k < n && k < 5; ++k) out[k] = v[k];
+  return 5;
 }
 
 int gsplat_context_set_render_only(gsplat_context *c, int enabled) {

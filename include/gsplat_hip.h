@@ -391,8 +391,9 @@ int gsplat_context_set_lean_forward(gsplat_context *ctx, int enabled);
 /* What the forwards of this context did so far: out[0] forwards completed, out[1] forwards whose speculatively queued
  * tail (placement, per-tile sorts, compositing: queued before the host has seen the counts, from the previous forward's
  * figures) had to be redone because the instances outgrew the buffers or the longest list needed a sort kernel that
- * was not queued, out[2] forwards that walked the compacted slots, out[3] growths of the instance buffers.  Writes
- * min(n, 4) values and returns 4. */
+ * was not queued, out[2] forwards that walked the compacted slots, out[3] growths of the instance buffers, out[4]
+ * compositing backwards that took their tiles heaviest first (scenes whose longest tile list was more than three times
+ * the average in the forward before).  Writes min(n, 5) values and returns 5. */
 int gsplat_context_get_counters(gsplat_context *ctx, long long *out, int n);
 int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
 /* The same for a subset of the stages (bit k of stage_mask = stage k; 0 switches timing off).  Every timed stage

@@ -760,11 +760,17 @@ def test_tile_order_changes_nothing(gpu, scene, orc):
     lens = np.diff(ref["ranges"])
     assert lens.max() > 4 * lens.mean(), "the scene must be skewed"
     ctx = raster.RasterContext(N, W, H)
-    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)      # the first forward of a context knows no figures: plain order
     _check_forward(fwd, ref)
     M = fwd["num_culled"]
+    g0 = ctx.alloc_gradients(M, L, intermediates=True)
+    ctx.backward_pass(dp, dc, gi, c["bg"], L, g0)
+    assert ctx.counters()["ordered_backwards"] == 0
+    _check_backward(g0, bref)
+    fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)      # skewed by the first forward's figures: the order is made
     g = ctx.alloc_gradients(M, L, intermediates=True)
     ctx.backward_pass(dp, dc, gi, c["bg"], L, g)          # tiles in the order of their stop indices
+    assert ctx.counters()["ordered_backwards"] == 1, "the second step of a skewed scene orders its backward"
     _check_backward(g, bref)
     # the same compositing backward in the plain tile order: the stand-alone operator on the forward's arrays
     z = lambda *s_: torch.zeros(*s_, device="cuda")
