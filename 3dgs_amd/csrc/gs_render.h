@@ -350,6 +350,74 @@ __device__ __host__ __forceinline__ int row_moments9q_index(int lane) {
   return j < 3 ? j : (j >= 4 && j < 8) ? j - 1 : j == 8 ? 7 : j == 9 ? 8 : -1;
 }
 
+// ---- r04 (second half): the same nine row sums in 14 VALU.  The four lanes of a quad are four pixels of ONE pixel row,
+// so inside a quad cy is a constant: the quad-partials of S_cy, S_cxcy and S_cy2 are cy x S_1, cy x S_cx and cy^2 x S_1 of
+// the same quad.  The quad stage therefore builds only two registers,
+//   A from aT: lanes 0..2 of the quad -> rgb0, rgb1, rgb2           (lane 3: weight 0)
+//   B from gp: lanes 0..3             -> S_1, S_cx, S_cx2, S_1 (again)
+// (2 v_mul + 6 v_fmac_dpp), one more product forms  Q = B x (cy, cy, 0, cy^2)  = the quad-partials of S_cy, S_cxcy, -,
+// S_cy2, and the four quads of the row are summed as in row_moments9q (A | B into banks 0,2 | 1,3, Q onto itself, then
+// the halves: 5 masked DPP adds).  Bank 0 ends with the rgb totals, bank 1 with S_1 S_cx S_cx2 (S_1), bank 2 with S_cy
+// S_cxcy - S_cy2.  The wait state the last fold needs is filled by the caller's own instruction: the LDS address of the
+// atomic that follows (addr = off * 5 + acc_lane), which the loop needs anyway.
+struct RowsWeights { float a[4], b[4], q; };
+
+__device__ __forceinline__ RowsWeights make_rows_weights(int lane, float cx, float cy, float g0, float g1, float g2) {
+  const int p = lane & 3;
+  RowsWeights w;
+  auto qp = [](float v, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  auto offer = [&](int k) { const int ch = p ^ k; return ch == 0 ? g0 : ch == 1 ? g1 : ch == 2 ? g2 : 0.0f; };
+  w.a[0] = offer(0);
+  w.a[1] = qp(offer(1), std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
+  w.a[2] = qp(offer(2), std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
+  w.a[3] = qp(offer(3), std::integral_constant<int, 0x1B>{});  // quad_perm [3,2,1,0]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float cxk = cx + (float)((p ^ k) - p);  // pixel of lane ^ k (same pixel row)
+    w.b[k] = p == 1 ? cxk : p == 2 ? cxk * cxk : 1.0f;
+  }
+  w.q = p == 3 ? cy * cy : p == 2 ? 0.0f : cy;
+  return w;
+}
+
+// returns the register of the totals; `addr` <- off * 5 + acc_lane (the caller's atomic address, computed in the wait state)
+__device__ __forceinline__ float row_moments9r(float aT, float gp, const RowsWeights &w, unsigned int off, unsigned int acc_lane,
+                                               unsigned int &addr) {
+  float A, B, Q;
+  asm volatile(
+      // the two plain products first: the wait states between the instructions that wrote aT / gp and their first DPP read
+      "v_mul_f32 %[A], %[aT], %[a0]\n\t"
+      "v_mul_f32 %[B], %[gp], %[b0]\n\t"
+      "v_fmac_f32_dpp %[A], %[aT], %[a1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[B], %[gp], %[b1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[A], %[aT], %[a2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[B], %[gp], %[b2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[A], %[aT], %[a3] quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %[B], %[gp], %[b3] quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32 %[Q], %[B], %[wq]\n\t"
+      // quads 4 lanes apart: A | B into A (banks 0,2 | 1,3), Q onto itself (banks 0 and 2 end with the pair sums)
+      "v_add_f32_dpp %[A], %[A], %[A] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[A], %[B], %[B] row_shr:4 row_mask:0xf bank_mask:0xa bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[Q], %[Q], %[Q] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      // (a VGPR written by VALU may be read through DPP two wait states later: Q's fold and the address cover A)
+      "v_mad_u32_u24 %[addr], %[off], 5, %[acc]\n\t"
+      // quads 8 lanes apart: banks 0,1 keep the A | B totals, banks 2,3 take Q's (bank 2: the total, bank 3: unused)
+      "v_add_f32_dpp %[A], %[A], %[A] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %[A], %[Q], %[Q] row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:0\n\t"
+      : [A] "=&v"(A), [B] "=&v"(B), [Q] "=&v"(Q), [addr] "=&v"(addr)
+      : [aT] "v"(aT), [gp] "v"(gp), [a0] "v"(w.a[0]), [a1] "v"(w.a[1]), [a2] "v"(w.a[2]), [a3] "v"(w.a[3]),
+        [b0] "v"(w.b[0]), [b1] "v"(w.b[1]), [b2] "v"(w.b[2]), [b3] "v"(w.b[3]), [wq] "v"(w.q), [off] "v"(off),
+        [acc] "v"(acc_lane));
+  return A;
+}
+// which of the nine sums a lane holds after row_moments9r (0..2 rgb, 3 S_1, 4 S_cx, 5 S_cy, 6 S_cx2, 7 S_cxcy, 8 S_cy2; -1: none)
+__device__ __host__ __forceinline__ int row_moments9r_index(int lane) {
+  const int j = lane & 15;
+  return j < 3 ? j : j == 4 ? 3 : j == 5 ? 4 : j == 6 ? 6 : j == 8 ? 5 : j == 9 ? 7 : j == 11 ? 8 : -1;
+}
+
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
 // neighbouring tiles (which share gaussians) hit the same L2.  Returns >= num_tiles for the
 // padding blocks of the last round.

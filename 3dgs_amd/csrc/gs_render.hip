@@ -44,10 +44,11 @@
 #ifndef GS_EXTRA_FMA
 #define GS_EXTRA_FMA 0
 #endif
-// r04: the nine-value row reduction with two butterfly stages folded into the products (gs_render.h: row_moments9q,
-// 17 VALU + 1 wait state) instead of one (row_moments9, 22 + 3).  0 keeps the r01-r03 form (A/B: tools/ab).
+// r04: the nine-value row reduction with two butterfly stages folded into the products (gs_render.h: 1 = row_moments9q,
+// 17 VALU + 1 wait state; 2 = row_moments9r, 14 VALU with the quad's constant cy factored out of three of the moments
+// and the atomic's address in the wait state) instead of one (0 = row_moments9, 22 + 3: the r01-r03 form; A/B: tools/ab).
 #ifndef GS_ROWSUM_QUAD
-#define GS_ROWSUM_QUAD 1
+#define GS_ROWSUM_QUAD 2
 #endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
       // rows whose 16 pixels are all saturated (or outside) need no list
       const int big = kBatch;
       unsigned short *lists = s_list + (t >> 6) * 4 * kListStride;
-      const unsigned short *my_list = lists + ((t >> 4) & 3) * kListStride;
+      const unsigned int list_lds =
+          (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + ((t >> 4) & 3) * kListStride);
       const RowCounts rc = build_row_lists<kListStride>(s_r2, lists, count, t >> 6, t & 63,
                                            (unsigned int)(satmask & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 16) & 0xFFFFull) == 0xFFFFu ? 0 : big,
@@ -240,8 +242,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
       for (int i = 0; i < trips; i += 2) {
         // two list entries per trip: both records are fetched and both exponentials evaluated before the
         // (sequential) blending; a row past the end of its list reads the sentinel record and blends with alpha 0
-        const unsigned int two = *reinterpret_cast<const unsigned int *>(my_list + i);
-        const int off0 = two & 0xFFFFu, off1 = two >> 16;
+        // (two zero-extending 16-bit reads: one 32-bit read costs an and and a shift on the VALU, which is what bounds
+        // this loop; r04)
+        int off0, off1;
+        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(off0), "=&v"(off1) : "v"(list_lds + 2 * i) : "memory");
         const float4 a0 = *reinterpret_cast<const float4 *>(r0b + off0), c0 = *reinterpret_cast<const float4 *>(r2b + off0);
         const float2 b0 = *reinterpret_cast<const float2 *>(r1b + off0);
         const float4 a1 = *reinterpret_cast<const float4 *>(r0b + off1), c1 = *reinterpret_cast<const float4 *>(r2b + off1);
@@ -253,20 +258,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
         al1 = al1 > kAlphaMin ? al1 : 0.0f;
         // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T * (1 - alpha) < 1e-4" alone
         // decides the next T; the compare's lane mask doubles as the saturation bookkeeping.
-        const float w0 = al0 * T;
-        const float tT0 = T * (1.0f - al0);
+        // (T (1 - alpha) as one FMA, T - alpha T; the select takes the ballot's own mask: written as a ternary the
+        // compiler evaluates the inverse compare a second time for it)
+        // (volatile, like the selects: the products stay in front of them, so that the old T dies here and the new one
+        // takes its register -- the compiler sinks the colour accumulation to the loop's tail, and with it the product)
+        float w0, w1;
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w0) : "v"(al0), "v"(T));
+        const float tT0 = __builtin_fmaf(-al0, T, T);
         ar = __builtin_fmaf(c0.x, w0, ar);
         ag = __builtin_fmaf(c0.y, w0, ag);
         ab = __builtin_fmaf(c0.z, w0, ab);
         const unsigned long long s0 = __ballot(tT0 < kTMin);  // this splat was still accumulated (render.cu:76-87)
-        T = tT0 < kTMin ? 0.0f : tT0;
-        const float w1 = al1 * T;
-        const float tT1 = T * (1.0f - al1);
+        asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(T) : "v"(tT0), "s"(s0));  // T = tT0 < kTMin ? 0 : tT0
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w1) : "v"(al1), "v"(T));
+        const float tT1 = __builtin_fmaf(-al1, T, T);
         ar = __builtin_fmaf(c1.x, w1, ar);
         ag = __builtin_fmaf(c1.y, w1, ag);
         ab = __builtin_fmaf(c1.z, w1, ab);
         const unsigned long long s1 = __ballot(tT1 < kTMin);
-        T = tT1 < kTMin ? 0.0f : tT1;
+        asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(T) : "v"(tT1), "s"(s1));
         if (s1 != satmask) {  // rare: some pixel saturated in this trip
           const unsigned long long bit = 1ull << lane;
           if ((s0 & ~satmask) & bit) { T_fin = tT0; n = base + (off0 >> 4) + 1; }
@@ -382,10 +392,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     Tf = T_px[pid];
     g0 = grad_image[3 * pid]; g1 = grad_image[3 * pid + 1]; g2 = grad_image[3 * pid + 2];
   }
-  typedef float v2f __attribute__((ext_vector_type(2)));  // (c0, c1) as a register pair: one packed add / fma
-  float T = Tf, c2 = 0.0f;  // running transmittance, colour behind the current splat
-  v2f c01 = {0.0f, 0.0f};
-  const float tfb = Tf * (bg * g0 + bg * g1 + bg * g2);  // T_final * (background . grad)
+  // Running transmittance, and s = (pixel gradient) . (colour behind the current splat).  The colour behind only ever
+  // enters through that dot product, and its back-to-front recurrence c <- c + alpha (colour - c) is linear, so the
+  // kernel carries the one number instead of three.  The background is the layer behind everything: with c starting
+  // at bg instead of 0, T (colour - c) . grad already contains the reference's - T_final (bg . grad) / (1 - alpha)
+  // term (cuda/render_backward.cu:139-151: c' = c + T_final bg / T_next obeys the same recurrence and starts at bg).
+  float T = Tf, s = bg * g0 + bg * g1 + bg * g2;
   const int row_top_v = row_max_int(n);
   const int rt0 = __builtin_amdgcn_readlane(row_top_v, 0), rt1 = __builtin_amdgcn_readlane(row_top_v, 16);
   const int rt2 = __builtin_amdgcn_readlane(row_top_v, 32), rt3 = __builtin_amdgcn_readlane(row_top_v, 48);
@@ -406,7 +418,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (top <= 0) return;
   // where this lane's share of the nine row totals goes (see row_moments9), and the lane constants of the sums:
   // pixel position relative to the tile centre, pixel gradient
-#if GS_ROWSUM_QUAD
+#if GS_ROWSUM_QUAD == 2
+  const int red_idx = row_moments9r_index(lane);
+#elif GS_ROWSUM_QUAD
   const int red_idx = row_moments9q_index(lane);
 #else
   const int red_idx = row_moments9_index(lane);
@@ -464,7 +478,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       // kernel they push it past the 80-register step and the compiler spills them to scratch (+0.2 GB of traffic).
       float g0b = g0, g1b = g1, g2b = g2;
       asm volatile("" : "+v"(g0b), "+v"(g1b), "+v"(g2b));
-#if GS_ROWSUM_QUAD
+#if GS_ROWSUM_QUAD == 2
+      const RowsWeights rw = make_rows_weights(t & 63, (float)(((t >> 6) & 1) * 8 + ((t >> 4) & 1) * 4 + (t & 3)) - 7.5f,
+                                               (float)((t >> 7) * 8 + ((t >> 5) & 1) * 4 + ((t >> 2) & 3)) - 7.5f, g0b, g1b, g2b);
+#elif GS_ROWSUM_QUAD
       // (from the opaque index, like the addresses above: derived from the plain thread index the twelve weights are
       // loop-invariant for the whole kernel, get hoisted above the batch loop and spilled)
       const QuadWeights rw = make_quad_weights(t & 63, (float)(((t >> 6) & 1) * 8 + ((t >> 4) & 1) * 4 + (t & 3)) - 7.5f,
@@ -520,12 +537,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
           const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
           T *= inv;                                           // transmittance in front of this splat
           const float aT = alpha * T;
-          const v2f d01 = v2f{c.x, c.y} - c01;
-          const float d2 = c.z - c2;
-          float ga = __builtin_fmaf(d01.x, g0, __builtin_fmaf(d01.y, g1, d2 * g2));
-          ga = __builtin_fmaf(ga, T, -(tfb * inv));           // d/d alpha (cuda/render_backward.cu:139-151)
-          c01 = __builtin_elementwise_fma(v2f{alpha, alpha}, d01, c01);  // colour behind the next (nearer) splat
-          c2 = __builtin_fmaf(alpha, d2, c2);
+          // t = grad . (colour - colour behind): three FMAs on the carried dot product
+          const float t = __builtin_fmaf(c.z, g2, __builtin_fmaf(c.y, g1, __builtin_fmaf(c.x, g0, -s)));
+          const float ga = t * T;                             // d/d alpha (cuda/render_backward.cu:139-151)
+          s = __builtin_fmaf(alpha, t, s);                    // grad . colour behind the next (nearer) splat
           const float gp = og * ga;                           // d/d power
           // nine raw sums: aT x pixel gradient (d/d rgb) and the six moments of gp about the tile centre; signs, the
           // -1/2 factors, (1 - opa), the shift to the gaussian's centre and 0.5*W / 0.5*H are applied once per gaussian
@@ -533,19 +548,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #if GS_ABLATE == 2
           asm volatile("" ::"v"(aT), "v"(gp));
 #else
-#if GS_ROWSUM_QUAD
+#if GS_ROWSUM_QUAD == 2
+          unsigned int acc_addr;
+          const float red = row_moments9r(aT, gp, rw, (unsigned int)off, acc_lane, acc_addr);
+#elif GS_ROWSUM_QUAD
           const float red = row_moments9q(aT, gp, rw);
+          const unsigned int acc_addr = acc_lane + __umul24((unsigned int)off, 5u);
 #else
           const float red = row_moments9(aT, gp, rw);
+          const unsigned int acc_addr = acc_lane + __umul24((unsigned int)off, 5u);
 #endif
 #if GS_ABLATE == 1
-          asm volatile("" ::"v"(red));
+          asm volatile("" ::"v"(red), "v"(acc_addr));
 #else
           // Every lane that holds a sum adds it, zero or not (a compare to skip zeros costs more issue cycles than the
           // few extra lanes cost the LDS; rows past their list add zeros to the sentinel slot's accumulators).  32-bit
           // LDS address on purpose: through a generic pointer the compiler forms off * 5 with a 64-bit multiply-add.
           if (red_lane)
-            __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double *>(acc_lane + __umul24((unsigned int)off, 5u)),
+            __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double *>(acc_addr),
                                    (double)red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 #endif

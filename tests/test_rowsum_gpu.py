@@ -27,7 +27,7 @@ def test_rowsum_program_builds():
 def test_row_sum9_on_gpu():
     out = subprocess.run([_build()], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "row_sum9: ok" in out.stdout and "row_moments9: ok" in out.stdout \
-        and "row_moments9q: ok" in out.stdout, out.stdout + out.stderr
+        and "row_moments9q: ok" in out.stdout and "row_moments9r: ok" in out.stdout, out.stdout + out.stderr
 
 
 BH_SRC = os.path.join(ROOT, "tools", "block_hits_test.hip")

@@ -30,14 +30,32 @@ __global__ void kq(const float *in, float *out) {
   out[lane] = gs::row_moments9q(aT, gp, w);
 }
 
-static int test_moments(const float *h, float *d_in, float *d_out, bool quad = false) {
-  float o[64];
-  if (quad) kq<<<1, 64>>>(d_in, d_out);
+// row_moments9r (r04: cy is a constant inside a quad, three of the moments come from the quad-partials of S_1 and S_cx);
+// out[64 + lane]: the LDS address the block computes in its wait state (off * 5 + acc_lane)
+__global__ void kr(const float *in, float *out) {
+  const int lane = threadIdx.x;
+  const float aT = in[lane], gp = in[64 + lane], cx = in[128 + lane], cy = in[192 + lane];
+  const float g0 = in[256 + lane], g1 = in[320 + lane], g2 = in[384 + lane];
+  const gs::RowsWeights w = gs::make_rows_weights(lane, cx, cy, g0, g1, g2);
+  unsigned int addr;
+  out[lane] = gs::row_moments9r(aT, gp, w, 16u * (unsigned int)(lane >> 4), 1000u + (unsigned int)lane, addr);
+  out[64 + lane] = (float)addr;
+}
+
+static int test_moments(const float *h, float *d_in, float *d_out, int quad = 0) {
+  float o[128];
+  if (quad == 2) kr<<<1, 64>>>(d_in, d_out);
+  else if (quad) kq<<<1, 64>>>(d_in, d_out);
   else km<<<1, 64>>>(d_in, d_out);
   hipMemcpy(o, d_out, sizeof(o), hipMemcpyDeviceToHost);
   int bad = 0, active = 0;
   for (int lane = 0; lane < 64; ++lane) {
-    const int row = lane >> 4, idx = quad ? gs::row_moments9q_index(lane) : gs::row_moments9_index(lane);
+    const int row = lane >> 4, idx = quad == 2 ? gs::row_moments9r_index(lane)
+                                                : quad ? gs::row_moments9q_index(lane) : gs::row_moments9_index(lane);
+    if (quad == 2 && o[64 + lane] != (float)(80 * row + 1000 + lane)) {
+      std::printf("row_moments9r lane %d: address %g want %d\n", lane, o[64 + lane], 80 * row + 1000 + lane);
+      ++bad;
+    }
     if (idx < 0) continue;
     ++active;
     double ref = 0.0;
@@ -54,15 +72,16 @@ static int test_moments(const float *h, float *d_in, float *d_out, bool quad = f
     }
   }
   if (active != 36) { std::printf("row_moments9: %d active lanes, want 36\n", active); ++bad; }
-  if (quad) std::printf(bad ? "row_moments9q: %d mismatches\n" : "row_moments9q: ok\n", bad);
+  if (quad == 2) std::printf(bad ? "row_moments9r: %d mismatches\n" : "row_moments9r: ok\n", bad);
+  else if (quad) std::printf(bad ? "row_moments9q: %d mismatches\n" : "row_moments9q: ok\n", bad);
   else std::printf(bad ? "row_moments9: %d mismatches\n" : "row_moments9: ok\n", bad);
   return bad;
 }
 
 int main() {
-  float h[9 * 64], *d_in, *d_out, o[64];
+  float h[9 * 64], *d_in, *d_out, o[64];  // (d_out: 128 floats, the r form also returns its address)
   for (int i = 0; i < 9 * 64; ++i) h[i] = (float)((i * 37) % 101) * 0.25f - 7.0f;
-  hipMalloc(&d_in, sizeof(h)); hipMalloc(&d_out, sizeof(o));
+  hipMalloc(&d_in, sizeof(h)); hipMalloc(&d_out, 2 * sizeof(o));
   hipMemcpy(d_in, h, sizeof(h), hipMemcpyHostToDevice);
   k<<<1, 64>>>(d_in, d_out);
   hipMemcpy(o, d_out, sizeof(o), hipMemcpyDeviceToHost);
@@ -85,6 +104,7 @@ int main() {
     h[192 + lane] = (float)((row >> 1) * 4 + (j >> 2)) - 7.5f;
   }
   hipMemcpy(d_in, h, sizeof(h), hipMemcpyHostToDevice);
-  bad += test_moments(h, d_in, d_out, true);
+  bad += test_moments(h, d_in, d_out, 1);
+  bad += test_moments(h, d_in, d_out, 2);
   return bad != 0;
 }
