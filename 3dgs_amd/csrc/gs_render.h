@@ -11,6 +11,9 @@ namespace gs {
 constexpr float kAlphaMin = 0.00392156862f;  // 1/255, cuda/render.cu:74
 constexpr float kAlphaMax = 0.99f;           // cuda/render.cu:73
 constexpr float kTMin = 0.0001f;             // cuda/render.cu:77
+// log2(0.99) = -0.01449957, minus two ulps of a value near one under exp2: the forward's cap in the exponent domain
+// (render_fwd_kernel staging) -- v_exp_f32 of it is at most 0.99f
+constexpr float kLog2AlphaMax = -0.01449975f;
 
 // Everything the compositing loops need about one gaussian, as three float4:
 //   r0 = {u, v, conic00, conic01}
@@ -121,6 +124,17 @@ __device__ __forceinline__ float log2_alpha(float a2, float b2, float c2, float 
   float r;  // fminf() would first canonicalise the loaded lopa (one more VALU instruction per evaluation)
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(lopa));
   return r;
+}
+
+// the forward's form: the clamp is min(log2 opa, log2 0.99) (staged per gaussian), so the result is the CAPPED alpha
+__device__ __forceinline__ float staged_alpha_capped(float a2, float b2, float c2, float lopa, float lbound, float dx, float dy) {
+  float t = a2 * dx;
+  t = __builtin_fmaf(b2, dy, t);
+  float q = __builtin_fmaf(t, dx, lopa);  // (lopa dies here: a plain v_fmac, no copy -- and no asm, whose borders cost a wait state)
+  q = __builtin_fmaf(c2 * dy, dy, q);
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(lbound));
+  return __builtin_amdgcn_exp2f(r);
 }
 
 // the conic entries back from their staged form (flush of the backward): a = a2 * kConicDiag, b = b2 * kConicOff

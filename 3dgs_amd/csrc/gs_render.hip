@@ -105,7 +105,8 @@ __device__ __forceinline__ int wave_first_bit(int wave) { return (wave >> 1) * 8
 struct RowCounts { int c0, c1, c2, c3; };
 
 // Compacts, for each of the wave's four rows, the slots of the staged batch that hit the row's block
-// (and lie below the row's stop index `lim*` in the backward).  A list entry is the slot's byte offset into the
+// (and lie below the row's stop index `lim*` in the backward).  `s_r2`: the record array whose .w holds the 16 block bits
+// (the backward's third array, the forward's second).  A list entry is the slot's byte offset into the
 // record arrays (slot * 16), so the loop needs no shift; counts are wave-uniform.
 template <int kStride>
 __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigned short *lists, int count, int wave,
@@ -216,8 +217,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
 #endif
       const unsigned int hits = block_hits(s, tx0, ty0);
       if (masks_out) masks_out[start + base + t] = (unsigned short)hits;  // the backward stages the same instances
-      s.r2.w = __uint_as_float(hits);
       stage_record(s);
+      // The 0.99 cap goes into the exponent's own clamp (r04): alpha = exp2(min(q, log2 opa)) already has a per-gaussian
+      // upper bound on q, so min(0.99, .) in the loop becomes the bound min(log2 opa, log2 0.99), formed here once per
+      // (gaussian, tile).  It rides in r2.w, which the loop's 16-byte colour read fetches anyway; the block mask moves to
+      // r1.w (the forward's loop reads only r1.xy).  A capped alpha comes out as exp2(kLog2AlphaMax), within two ulps
+      // below 0.99f (the backward keeps its own 0.99f: it needs the uncapped value next to the capped one).  NaN stays NaN.
+      s.r1.w = __uint_as_float(hits);
+      s.r2.w = s.r1.y > kLog2AlphaMax ? kLog2AlphaMax : s.r1.y;
       s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
     }
     GS_LAP(st_stage);
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
       unsigned short *lists = s_list + (t >> 6) * 4 * kListStride;
       const unsigned int list_lds =
           (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + ((t >> 4) & 3) * kListStride);
-      const RowCounts rc = build_row_lists<kListStride>(s_r2, lists, count, t >> 6, t & 63,
+      const RowCounts rc = build_row_lists<kListStride>(s_r1, lists, count, t >> 6, t & 63,
                                            (unsigned int)(satmask & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 16) & 0xFFFFull) == 0xFFFFu ? 0 : big,
                                            (unsigned int)((satmask >> 32) & 0xFFFFull) == 0xFFFFu ? 0 : big,
@@ -251,36 +258,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
         const float2 b0 = *reinterpret_cast<const float2 *>(r1b + off0);
         const float4 a1 = *reinterpret_cast<const float4 *>(r0b + off1), c1 = *reinterpret_cast<const float4 *>(r2b + off1);
         const float2 b1 = *reinterpret_cast<const float2 *>(r1b + off1);
-        asm volatile("" ::"v"(c0.w), "v"(c1.w));  // keep 16-byte reads (ds_read_b96 costs twice the LDS cycles)
-        float al0 = fminf(kAlphaMax, staged_alpha(a0.z, a0.w, b0.x, b0.y, a0.x - fpx, a0.y - fpy));
-        float al1 = fminf(kAlphaMax, staged_alpha(a1.z, a1.w, b1.x, b1.y, a1.x - fpx, a1.y - fpy));
+        // (c.w: the exponent's bound, so the colour reads stay 16-byte reads -- a ds_read_b96 costs twice the LDS cycles)
+        float al0 = staged_alpha_capped(a0.z, a0.w, b0.x, b0.y, c0.w, a0.x - fpx, a0.y - fpy);  // <= 0.99
+        float al1 = staged_alpha_capped(a1.z, a1.w, b1.x, b1.y, c1.w, a1.x - fpx, a1.y - fpy);
         al0 = al0 > kAlphaMin ? al0 : 0.0f;
         al1 = al1 > kAlphaMin ? al1 : 0.0f;
-        // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T * (1 - alpha) < 1e-4" alone
-        // decides the next T; the compare's lane mask doubles as the saturation bookkeeping.
-        // (T (1 - alpha) as one FMA, T - alpha T; the select takes the ballot's own mask: written as a ternary the
-        // compiler evaluates the inverse compare a second time for it)
-        // (volatile, like the selects: the products stay in front of them, so that the old T dies here and the new one
-        // takes its register -- the compiler sinks the colour accumulation to the loop's tail, and with it the product)
-        float w0, w1;
-        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w0) : "v"(al0), "v"(T));
+        asm volatile("" : "+v"(al0), "+v"(al1));  // both evaluated (two independent chains) before the sequential blending
+        // Invariant: T is either 0 (saturated or outside the image) or >= 1e-4, so "T (1 - alpha) < 1e-4" alone decides
+        // whether a pixel is saturated behind this splat, and the compare's lane mask doubles as the saturation
+        // bookkeeping.  A saturated pixel has T = 0, hence T (1 - alpha) = 0 < 1e-4: it stays in the mask by itself, and
+        // the common path needs no select at all -- only the (rare) trip in which a pixel saturates zeroes its T (r04:
+        // two v_cndmask fewer per trip; T (1 - alpha) as one FMA, T - alpha T).
+        const float w0 = al0 * T;
         const float tT0 = __builtin_fmaf(-al0, T, T);
         ar = __builtin_fmaf(c0.x, w0, ar);
         ag = __builtin_fmaf(c0.y, w0, ag);
         ab = __builtin_fmaf(c0.z, w0, ab);
         const unsigned long long s0 = __ballot(tT0 < kTMin);  // this splat was still accumulated (render.cu:76-87)
-        asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(T) : "v"(tT0), "s"(s0));  // T = tT0 < kTMin ? 0 : tT0
-        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w1) : "v"(al1), "v"(T));
+        T = tT0;
+        if (s0 != satmask) {  // rare: some pixel saturated with the trip's first splat
+          if (((s0 & ~satmask) >> lane) & 1ull) { T_fin = tT0; n = base + (off0 >> 4) + 1; T = 0.0f; }
+          satmask = s0;
+        }
+        const float w1 = al1 * T;
         const float tT1 = __builtin_fmaf(-al1, T, T);
         ar = __builtin_fmaf(c1.x, w1, ar);
         ag = __builtin_fmaf(c1.y, w1, ag);
         ab = __builtin_fmaf(c1.z, w1, ab);
         const unsigned long long s1 = __ballot(tT1 < kTMin);
-        asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(T) : "v"(tT1), "s"(s1));
-        if (s1 != satmask) {  // rare: some pixel saturated in this trip
-          const unsigned long long bit = 1ull << lane;
-          if ((s0 & ~satmask) & bit) { T_fin = tT0; n = base + (off0 >> 4) + 1; }
-          if ((s1 & ~s0) & bit) { T_fin = tT1; n = base + (off1 >> 4) + 1; }
+        T = tT1;
+        if (s1 != satmask) {  // rare: ... with its second
+          if (((s1 & ~satmask) >> lane) & 1ull) { T_fin = tT1; n = base + (off1 >> 4) + 1; T = 0.0f; }
           satmask = s1;
           if (satmask == ~0ull) {
             live = 0;
