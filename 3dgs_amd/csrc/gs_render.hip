@@ -19,12 +19,16 @@
 //     gaussian has alpha < 1/255 on every pixel of the block;
 //   * forward: two list entries per trip; a row whose 16 pixels are saturated gets no list, a wave stops when its 64
 //     pixels are saturated, the workgroup when all four waves have; on the side it clears the gradient rows the
-//     backward accumulates into (the kernel leaves most of the HBM bandwidth unused);
-//   * backward: the nine partial sums of a (gaussian, block) pair are reduced across the row's 16 lanes only
-//     (gs::row_moments9: 22 VALU with the products folded into the first butterfly stage, the nine totals land in
-//     nine lanes of one register), merged across the tile's blocks with ONE ds_add_f64 per trip, converted once per
-//     gaussian and flushed per batch to HBM as whole 64-byte gradient rows (or into the reference's four gradient
-//     arrays).
+//     backward accumulates into (the kernel leaves most of the HBM bandwidth unused).  33 VALU per two-entry trip (r04:
+//     the 0.99 cap lives in the exponent's clamp, a pixel's T is zeroed only in the trip that saturates it);
+//   * backward: 39 VALU per trip (r01: 51).  The colour behind a splat is carried as ONE number, its dot product with
+//     the pixel's gradient (the recurrence is linear and nothing else ever reads the colour; the background is the
+//     layer behind everything, which also absorbs the reference's T_final (bg . grad) / (1 - alpha) term); the nine
+//     partial sums of a (gaussian, block) pair are reduced across the row's 16 lanes only (gs::row_moments9r: 14 VALU --
+//     the products are folded into the quad stage, and since the four lanes of a quad share their cy, three of the six
+//     moments are cy or cy^2 times a quad-partial of another; the nine totals land in nine lanes of one register),
+//     merged across the tile's blocks with ONE ds_add_f64 per trip, converted once per gaussian and flushed per batch
+//     to HBM as whole 64-byte gradient rows (or into the reference's four gradient arrays).
 #include <hip/hip_ext.h>
 #include "gs_common.h"
 #include "gs_render.h"
