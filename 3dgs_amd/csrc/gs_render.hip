@@ -54,6 +54,12 @@
 #ifndef GS_ROWSUM_QUAD
 #define GS_ROWSUM_QUAD 2
 #endif
+#ifndef GS_BWD_ALPHA_ASM
+#define GS_BWD_ALPHA_ASM 1
+#endif
+#ifndef GS_BWD_PREFETCH_OFF
+#define GS_BWD_PREFETCH_OFF 0
+#endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
@@ -508,10 +514,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       // "slot below the pixel's stop index" compare is dropped.
       auto run_trips = [&](auto check_n) {
         constexpr bool kCheckN = decltype(check_n)::value;
+#if GS_BWD_PREFETCH_OFF
+        // experiment: the next trip's list entry is requested before this trip's records (LDS answers in order, so the
+        // wait for the records covers it): a trip no longer starts with a dependent 16-bit read
+        int off_next;
+        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off_next) : "v"(list_lds + 2 * (trips - 1)) : "memory");
+#endif
         for (int i = trips - 1; i >= 0; --i) {
           // ds_read_u16 zero-extends; read through asm, the compiler would add an "and 0xffff" to every trip
           int off;
+#if GS_BWD_PREFETCH_OFF
+          off = off_next;
+          asm volatile("ds_read_u16 %0, %1" : "=v"(off_next) : "v"(list_lds + 2 * max(i - 1, 0)) : "memory");
+#else
           asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(list_lds + 2 * i) : "memory");
+#endif
           const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
 #if GS_ABLATE == 4
           const float4 c = make_float4(0.5f, 0.25f, 0.125f, 0.0f);
@@ -521,7 +538,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
           const float dx = a.x - fpx, dy = a.y - fpy;
           // opa * exp(power): d alpha / d gg . gg (the reference differentiates through the 0.99 cap as if absent)
+#if GS_BWD_ALPHA_ASM
+          // The exponent chain of staged_alpha (the same operations in the same order: the forward's alpha bit for bit),
+          // the exponential and -- in the wait state a transcendental's result needs before a plain VALU instruction may
+          // read it -- the first FMA of the colour dot product, as ONE block: between separate asm statements the
+          // compiler puts an s_nop per border (three per trip).
+          float og, t0;
+          {
+            float tq, uq;
+            asm("v_mul_f32 %[t], %[a2], %[dx]\n\t"
+                "v_mul_f32 %[u], %[c2], %[dy]\n\t"
+                "v_fmac_f32 %[t], %[b2], %[dy]\n\t"
+                "v_fma_f32 %[t], %[t], %[dx], %[lopa]\n\t"
+                "v_fmac_f32 %[t], %[u], %[dy]\n\t"
+                "v_min_f32 %[t], %[t], %[lopa]\n\t"
+                "v_exp_f32 %[og], %[t]\n\t"
+                "v_fma_f32 %[t0], %[cx], %[g0], -%[s]"
+                : [og] "=&v"(og), [t0] "=&v"(t0), [t] "=&v"(tq), [u] "=&v"(uq)
+                : [a2] "v"(a.z), [b2] "v"(a.w), [c2] "v"(b.x), [lopa] "v"(b.y), [dx] "v"(dx), [dy] "v"(dy), [cx] "v"(c.x),
+                  [g0] "v"(g0), [s] "v"(s));
+          }
+#else
           float og = staged_alpha(a.z, a.w, b.x, b.y, dx, dy);  // opa * exp(power), before the 0.99 cap
+          const float t0 = __builtin_fmaf(c.x, g0, -s);
+#endif
 #if GS_EXTRA_FMA > 0
           // slope experiment (tools/experiments/r03_valu_slope.sh): GS_EXTRA_FMA independent plain FMAs per trip whose
           // results die at once -- pure issue slots, no new dependency, no live register
@@ -550,7 +590,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
           T *= inv;                                           // transmittance in front of this splat
           const float aT = alpha * T;
           // t = grad . (colour - colour behind): three FMAs on the carried dot product
-          const float t = __builtin_fmaf(c.z, g2, __builtin_fmaf(c.y, g1, __builtin_fmaf(c.x, g0, -s)));
+          const float t = __builtin_fmaf(c.z, g2, __builtin_fmaf(c.y, g1, t0));
           const float ga = t * T;                             // d/d alpha (cuda/render_backward.cu:139-151)
           s = __builtin_fmaf(alpha, t, s);                    // grad . colour behind the next (nearer) splat
           const float gp = og * ga;                           // d/d power
