@@ -57,6 +57,9 @@
 #ifndef GS_BWD_ALPHA_ASM
 #define GS_BWD_ALPHA_ASM 1
 #endif
+#ifndef GS_BWD_PRIO
+#define GS_BWD_PRIO 1
+#endif
 #ifndef GS_BWD_PREFETCH_OFF
 #define GS_BWD_PREFETCH_OFF 0
 #endif
@@ -80,8 +83,10 @@ __device__ unsigned long long gs_stamp_fwd[(1 << 16) * GS_STAMP_WORDS];  // rend
 
 namespace gs {
 
+// Forward batch size: 248 slots keep the block at 20 KB of LDS = EIGHT workgroups per CU at the kernel's 62 VGPRs (256
+// slots: 20 800 B, seven).  r02 measured +-0 for this; with r04's shorter loop it is -6 us (profiles/r04_ab_priority...).
 #ifndef GS_FWD_BATCH
-#define GS_FWD_BATCH 256
+#define GS_FWD_BATCH 248
 #endif
 constexpr int kBatch = GS_FWD_BATCH;
 
@@ -155,7 +160,7 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
 }
 
 #ifndef GS_FWD_WAVES
-#define GS_FWD_WAVES 7
+#define GS_FWD_WAVES 8
 #endif
 template <bool kPacked>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVES, 8))) void render_fwd_kernel(const float4 *__restrict__ recs, RawSplats raw,
@@ -623,8 +628,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
         }
       };
+      // The trip loop issues at a raised priority (r04): a SIMD's vector issue goes to the highest priority first, then
+      // to the oldest wave, so the waves inside their loops -- the ones whose instructions bound the kernel -- are served
+      // before the waves that stage, build lists or flush next to them (levels 1, 2 and 3 measure the same: 0.2820 ->
+      // 0.2745 ms; the same in the forward's loop changed nothing).
+#if GS_BWD_PRIO
+      __builtin_amdgcn_s_setprio(GS_BWD_PRIO);
+#endif
       if (__any(n_rel < count * 16)) run_trips(std::true_type{});
       else run_trips(std::false_type{});
+#if GS_BWD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       GS_LAP(st_loop);
     }
     __syncthreads();
