@@ -537,7 +537,8 @@ def run_rank(args, comm, device_index):
                          "measured_issue_cost": {"plain_valu_cycles_per_instruction_per_simd": cyc_plain,
                                                  "row_reduction_block_cycles_per_instruction": 3.9,
                                                  "note_r04": "measured on r03's loop (51 VALU per trip, 22 of them the row "
-                                                             "reduction); r04's loop has 46 (17): profiles/r04_ab_rowsum.txt",
+                                                             "reduction); r04's loop has 39 (14 + the atomic's address): "
+                                                             "profiles/r04_ab_carried_dot_and_rows_reduction.txt",
                                                  "wave_trips_per_launch": 3606560,
                                                  "kernel_clock_ghz": clock_ghz,
                                                  "source": "profiles/r03_valu_slope.txt (same-box A/B, 300 steps, two rounds)"},
