@@ -294,6 +294,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
         if (s0 != satmask) {  // rare: some pixel saturated with the trip's first splat
           if (((s0 & ~satmask) >> lane) & 1ull) { T_fin = tT0; n = base + (off0 >> 4) + 1; T = 0.0f; }
           satmask = s0;
+          // ... the wave's last live one: this trip is its last (the second splat blends with T = 0 everywhere, and the
+          // test behind it finds nothing new: without this exit the wave walks the rest of the tile's list for nothing --
+          // the dense scenes' forward took twice as long for a day of this round)
+          if (satmask == ~0ull) { live = 0; i = trips; }
         }
         const float w1 = al1 * T;
         const float tT1 = __builtin_fmaf(-al1, T, T);
