@@ -54,14 +54,13 @@
 #ifndef GS_ROWSUM_QUAD
 #define GS_ROWSUM_QUAD 2
 #endif
+// r04 A/B switches of the backward's loop (profiles/r04_ab_*.txt): the exponent chain as one asm block; the issue priority
+// of the trip loop (0: none)
 #ifndef GS_BWD_ALPHA_ASM
 #define GS_BWD_ALPHA_ASM 1
 #endif
 #ifndef GS_BWD_PRIO
 #define GS_BWD_PRIO 1
-#endif
-#ifndef GS_BWD_PREFETCH_OFF
-#define GS_BWD_PREFETCH_OFF 0
 #endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
@@ -523,21 +522,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       // "slot below the pixel's stop index" compare is dropped.
       auto run_trips = [&](auto check_n) {
         constexpr bool kCheckN = decltype(check_n)::value;
-#if GS_BWD_PREFETCH_OFF
-        // experiment: the next trip's list entry is requested before this trip's records (LDS answers in order, so the
-        // wait for the records covers it): a trip no longer starts with a dependent 16-bit read
-        int off_next;
-        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off_next) : "v"(list_lds + 2 * (trips - 1)) : "memory");
-#endif
         for (int i = trips - 1; i >= 0; --i) {
           // ds_read_u16 zero-extends; read through asm, the compiler would add an "and 0xffff" to every trip
           int off;
-#if GS_BWD_PREFETCH_OFF
-          off = off_next;
-          asm volatile("ds_read_u16 %0, %1" : "=v"(off_next) : "v"(list_lds + 2 * max(i - 1, 0)) : "memory");
-#else
           asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(list_lds + 2 * i) : "memory");
-#endif
           const float4 a = *reinterpret_cast<const float4 *>(r0b + off), b = *reinterpret_cast<const float4 *>(r1b + off);
 #if GS_ABLATE == 4
           const float4 c = make_float4(0.5f, 0.25f, 0.125f, 0.0f);
