@@ -386,7 +386,11 @@ def run_rank(args, comm, device_index):
     want = os.environ.get("GSPLAT_EXCHANGE", "auto" if world > 1 else "split")
     exchange_ms = {}
     ctx = raster.RasterContext(N, W, H)
-    ctx.set_lean_forward(True)  # the timed step runs the fused backward only (config.forward_outputs says so)
+    # What the timed forward materialises.  Since r04 the headline stores EVERY ForwardPassData array, as the reference's
+    # rasterize_image does (2 % slower than the lean forward, which a host of the fused backward would use: that one is
+    # measured beside it, ms_per_step_lean_forward).  GSPLAT_BENCH_LEAN=1 swaps the two.
+    lean_headline = os.environ.get("GSPLAT_BENCH_LEAN", "0") == "1"
+    ctx.set_lean_forward(lean_headline)
     if world > 1 and do_bwd and want == "auto":
         errors = {}
         for mode in ("full", "factored", "split", "split_chunks4", "split_direct"):
@@ -436,15 +440,16 @@ def run_rank(args, comm, device_index):
     S_eff = tile_max_sum(torch, fwd["n"], W, H)
     M, S, num_pairs = fwd["num_culled"], fwd["num_splats"], fwd["num_pairs"]
     stages = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, max(5, min(args.steps, 50)), do_bwd)
-    # the same forward with every ForwardPassData array materialised (what the reference's own host would ask for)
-    step.ctx.set_lean_forward(False)
-    stages_full = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, 10, do_bwd)
-    step.ctx.set_lean_forward(True)
+    # the same forward in the OTHER mode (lean <-> every ForwardPassData array materialised)
+    step.ctx.set_lean_forward(not lean_headline)
+    stages_other = stage_pass(step.ctx, dp, dc, dgi, cfg, L, step.grads, 10, do_bwd)
+    step.ctx.set_lean_forward(lean_headline)
+    stages_full, stages_lean = (stages_other, stages) if lean_headline else (stages, stages_other)
 
-    # the whole step with every ForwardPassData array stored (the timed region below runs the lean forward)
-    ms_full_outputs = None
+    # the whole step in the other mode (the timed region below runs the headline's)
+    ms_other_mode = None
     if do_bwd and world == 1:
-        step.ctx.set_lean_forward(False)
+        step.ctx.set_lean_forward(not lean_headline)
         for _ in range(5):
             one_step()
         torch.cuda.synchronize()
@@ -453,8 +458,8 @@ def run_rank(args, comm, device_index):
         for _ in range(reps_f):
             one_step()
         torch.cuda.synchronize()
-        ms_full_outputs = (time.perf_counter() - tf) / reps_f * 1e3
-        step.ctx.set_lean_forward(True)
+        ms_other_mode = (time.perf_counter() - tf) / reps_f * 1e3
+        step.ctx.set_lean_forward(lean_headline)
         one_step()
 
     for _ in range(args.warmup):
@@ -715,9 +720,13 @@ def run_rank(args, comm, device_index):
                                f"{'forward+backward' if do_bwd else 'forward'}",
                    "views_per_step": world, "parallelism": f"view-sharded dp{world}" if world > 1 else "single GPU",
                    "exchange": step.describe_exchange() if world > 1 else "none", "backend": backend,
-                   "forward_outputs": "lean (gsplat_context_set_lean_forward): Sigma / J / conic / SH colour of "
-                                      "ForwardPassData are not materialised, the fused backward recomputes them; "
-                                      "preprocess with all of them stored: preprocess_ms_all_forward_outputs",
+                   "forward_outputs": ("lean (gsplat_context_set_lean_forward, GSPLAT_BENCH_LEAN=1): Sigma / J / conic / SH "
+                                       "colour of ForwardPassData are not materialised, the fused backward recomputes "
+                                       "them; the step with all of them stored: ms_per_step_full_forward_outputs"
+                                       if lean_headline else
+                                       "all: every ForwardPassData array is stored, as by the reference's rasterize_image "
+                                       "(cuda/raster.cu:12-136); the step of a host of the fused backward, which needs "
+                                       "none of Sigma / J / conic / SH colour: ms_per_step_lean_forward"),
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": num_pairs, "scene_seed": scene.SEED},
         "exchange_ms_per_step": exchange_ms or None,
         # tools/nccl_one_rank.py: every payload through RCCL with ONE rank (collectives = copies): ms per step with the
@@ -732,19 +741,21 @@ def run_rank(args, comm, device_index):
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
         "ms_per_step_stats": step_stats,
-        "ms_per_step_full_forward_outputs": ms_full_outputs,
+        "ms_per_step_full_forward_outputs": ms_other_mode if lean_headline else ms,
+        "ms_per_step_lean_forward": ms if lean_headline else ms_other_mode,
         "reference_host_path": ref_host,
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
         "preprocess_ms_all_forward_outputs": round(stages_full["preprocess"][0], 4),
+        "preprocess_ms_lean_forward": round(stages_lean["preprocess"][0], 4),
         "roofline": roofline,
         "roofline_valu_issue": roofline_valu,
         # the HBM-bound kernels either side of the compositing, from the per-stage pass (algorithmic bytes per
         # gaussian: SURVEY.md 8d / DESIGN.md section 4); not the dominant kernel, reported for completeness
         "roofline_per_gaussian_kernels": (
-            [hbm_entry("preprocess (lean: what the timed step runs)", preprocess_bytes(M, N, L, True)[0], stages["preprocess"][0],
-                       preprocess_bytes(M, N, L, True)[1]),
-             hbm_entry("preprocess (all ForwardPassData arrays stored)", preprocess_bytes(M, N, L, False)[0],
-                       stages_full["preprocess"][0], preprocess_bytes(M, N, L, False)[1])]
+            [hbm_entry("preprocess (lean)" + (": what the timed step runs" if lean_headline else ""),
+                       preprocess_bytes(M, N, L, True)[0], stages_lean["preprocess"][0], preprocess_bytes(M, N, L, True)[1]),
+             hbm_entry("preprocess (all ForwardPassData arrays stored)" + ("" if lean_headline else ": what the timed step runs"),
+                       preprocess_bytes(M, N, L, False)[0], stages_full["preprocess"][0], preprocess_bytes(M, N, L, False)[1])]
             + ([hbm_entry("preprocess_backward", 560 * M, stages["preprocess_backward"][0])] if do_bwd else [])),
         "alternating_views": alternating,
         "extra_workloads": extra,
