@@ -781,3 +781,30 @@ def test_tile_order_changes_nothing(gpu, scene, orc):
     assert_grad_close(_np(g["opacity"]), _np(p_op), "ordered vs plain: grad_opacity", rel=1e-4)
     assert_grad_close(_np(g["uv"]), _np(p_uv), "ordered vs plain: grad_uv", rel=1e-4)
     assert_grad_close(_np(g["conic"]), _np(p_conic), "ordered vs plain: grad_conic", rel=1e-4)
+
+
+
+def test_forward_stops_where_the_pixels_saturate(gpu, scene):
+    """A wave of render_fwd leaves its loop when all 64 of its pixels are saturated, a workgroup when its four waves have
+    (cuda/render.cu:76-90: "done").  The results do not depend on it -- saturated pixels blend with weight 0 -- so only the
+    clock can tell when the exit is lost: r04 lost it for trips whose FIRST splat saturates the wave's last live pixel, and
+    the forward of the scenes whose pixels saturate (large splats, dense captures) took twice as long while the benchmark
+    scene, where pixels rarely saturate, showed nothing.  The `bigsplats` workload (a capture early in training: splats
+    over many tiles, every pixel saturated long before its list ends): 0.062 ms with the exit, 0.131 ms without it
+    (profiles/r04_ab_forward_early_exit.txt); the bar sits between the two."""
+    torch, raster = gpu, pkg("raster")
+    N, W, H, L, _ = scene.WORKLOADS["bigsplats"]
+    c = scene.CONFIG
+    dp = raster.device_params(scene.make_workload_gaussians("bigsplats"))
+    dc = raster.device_camera(scene.make_camera(W, H, 0))
+    ctx = raster.RasterContext(N, W, H)
+    for _ in range(3):
+        ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    ctx.set_timing(True, stages=["render_forward"])
+    for _ in range(20):
+        ctx.rasterize_image(dp, dc, c, c["bg"], L)
+    torch.cuda.synchronize()
+    ms = ctx.get_timing()["render_forward"][0]
+    ctx.close()
+    print(f"bigsplats: render_fwd {ms:.4f} ms")
+    assert ms < 0.1, f"render_fwd takes {ms:.4f} ms on the saturating workload (0.062 with the exit, 0.131 without)"

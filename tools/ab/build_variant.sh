@@ -4,6 +4,10 @@
 # with the Makefile's flags plus the extra ones
 tag=$1; src=$(readlink -f "$2"); shift 2
 name=$(basename "$src" .hip)
+case " gs_common gs_pergaussian gs_binning gs_render gs_fused gs_loss gs_init gs_density " in
+  *" $name "*) ;;
+  *) echo "build_variant.sh: $src is not named after one of the library's objects (the basename decides which one it replaces)"; exit 1 ;;
+esac
 cd "$(dirname "$0")/../../3dgs_amd/csrc" || exit 1
 cp "$src" ./_variant_$name.hip
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -mllvm -amdgpu-atomic-optimizer-strategy=None \
