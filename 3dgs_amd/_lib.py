@@ -116,7 +116,7 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
-ABI_VERSION = 4  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
+ABI_VERSION = 5  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -157,6 +157,7 @@ SIGNATURES = {
     "gsplat_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _I, _P]),
     "gsplat_optimizer_step": (_I, [_P, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
     "gsplat_optimizer_step_packed": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "gsplat_optimizer_step_sh_factored": (_I, [_P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _F, _F, _F, _P, _P]),
     "gsplat_pack_uv_grad_norm": (_I, [_P, ctypes.POINTER(Gradients), _I, _P, _P]),
     "gsplat_initialize_gaussians": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gsplat_knn_mean_distance": (_I, [_P, _I, _I, _P, _P]),

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   if constexpr (kRest > 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    gs::rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
+    if (o.sh) gs::rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
   }
   if (!live) return;
   gx = 0.0f + gx; gy = 0.0f + gy; gz = 0.0f + gz;
@@ -1376,7 +1376,7 @@ int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g
              "backward arguments do not match the recorded forward pass");
   GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
   GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
-  if (l_max > 0) GS_REQUIRE_DEV(out->grad_sh);
+  if (l_max > 0 && out->grad_sh) GS_REQUIRE_DEV(out->grad_sh);  // NULL: the caller rebuilds them (gsplat_optimizer_step_sh_factored)
   GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int M = c->M, W = c->width, H = c->height;
@@ -1423,7 +1423,7 @@ int gsplat_backward_pass(gsplat_context *c, const gsplat_gaussians *g, const gsp
              "backward arguments do not match the recorded forward pass");
   GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
   GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
-  if (l_max > 0) GS_REQUIRE_DEV(out->grad_sh);
+  if (l_max > 0 && out->grad_sh) GS_REQUIRE_DEV(out->grad_sh);  // NULL: the caller rebuilds them (gsplat_optimizer_step_sh_factored)
   int rc = gsplat_backward_render(c, grad_image, bg_color, nullptr, stream);
   if (rc) return rc;
   return gsplat_backward_gaussians(c, g, cam, l_max, out, stream);

@@ -19,6 +19,7 @@
 // 256 spread counters (a single hot atomic would serialise the adds), summed by the host when it asks for the value.
 #include "gs_common.h"
 #include "gs_render.h"
+#include "gs_math.h"
 
 namespace {
 
@@ -382,6 +383,36 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(int rows, GroupTabl
   }
 }
 
+// The SH group of a single-view step with its gradients rebuilt in place of read: thread i owns coefficient k = i % (n - 1)
+// of row i / (n - 1), i.e. three consecutive elements (r, g, b) of the [rows, 3 (n - 1)] group -- neighbouring threads
+// touch neighbouring 12-byte pieces of the parameter and moment rows.  A gradient is grad_precompute_rgb[row][c] *
+// Y_{k+1}(direction of the row): gs::sh_bwd's own product (gs_math.h) on gs::view_dir / gs::sh_basis of the same inputs.
+// The n - 1 threads of a row evaluate the same basis (the kernel is bound by its six parameter / moment streams).
+template <int L>
+__global__ __launch_bounds__(256) void optimizer_sh_factored_kernel(int rows, const int *__restrict__ c2g,
+                                                                    float *__restrict__ sh, float *__restrict__ m,
+                                                                    float *__restrict__ v, float lr, float b1, float b2,
+                                                                    float eps, float bias1, float bias2,
+                                                                    const float *__restrict__ xyz, float cx, float cy,
+                                                                    float cz, const float *__restrict__ g_rgb) {
+  constexpr int n = (L + 1) * (L + 1), kCoef = n - 1;
+  const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned int)rows * (unsigned int)kCoef) return;
+  const unsigned int r = i / (unsigned int)kCoef, k = i - r * (unsigned int)kCoef;
+  const long long row = c2g[r];
+  float ux, uy, uz, len;
+  gs::view_dir(xyz[3 * row], xyz[3 * row + 1], xyz[3 * row + 2], cx, cy, cz, ux, uy, uz, len);
+  float Y[n];
+  gs::sh_basis<L>(ux, uy, uz, Y);
+  float yv = 0.0f;
+#pragma unroll
+  for (int q = 0; q < kCoef; ++q) yv = k == (unsigned int)q ? Y[q + 1] : yv;
+  const long long o = (row * kCoef + k) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    adam_update(&sh[o + c], &m[o + c], &v[o + c], g_rgb[3 * r + c] * yv, lr, b1, b2, eps, bias1, bias2);
+}
+
 int build_group_table(const gsplat_adam_group *groups, int n_groups, bool packed, GroupTable *t, const char *fn) {
   if (!groups || n_groups < 1 || n_groups > GSPLAT_MAX_ADAM_GROUPS) {
     gs::set_error("%s: invalid argument: need 1..%d parameter groups", fn, GSPLAT_MAX_ADAM_GROUPS);
@@ -530,6 +561,32 @@ int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gs
   const long long blocks = group_blocks(&t, num_culled);
   optimizer_step_kernel<false><<<(unsigned int)blocks, 256, 0, (hipStream_t)stream>>>(
       num_culled, t, compact_to_global, nullptr, 0, b1, b2, eps, bias1, bias2, grad_uv, uv_grad_accum, grad_accum_dur);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_optimizer_step_sh_factored(const int *compact_to_global, int num_culled, int l_max, float *sh, float *exp_avg,
+                                      float *exp_avg_sq, float lr, float b1, float b2, float eps, float bias1,
+                                      float bias2, const float *xyz, float cam_x, float cam_y, float cam_z,
+                                      const float *grad_precompute_rgb, void *stream) {
+  GS_REQUIRE(num_culled >= 0, "negative gaussian count");
+  GS_REQUIRE(l_max >= 0 && l_max <= 3, "l_max must be 0..3");
+  if (num_culled == 0 || l_max == 0) return GSPLAT_OK;  // no coefficients beyond band 0
+  GS_REQUIRE_DEV(compact_to_global); GS_REQUIRE_DEV(sh); GS_REQUIRE_DEV(exp_avg); GS_REQUIRE_DEV(exp_avg_sq);
+  GS_REQUIRE_DEV(xyz); GS_REQUIRE_DEV(grad_precompute_rgb);
+  const long long per_row = (l_max + 1) * (l_max + 1) - 1;  // threads per row: one per coefficient (three channels each)
+  GS_REQUIRE((long long)num_culled * per_row * 3 < (1ll << 31), "too many parameters for one launch");
+  const unsigned int blocks = (unsigned int)(((long long)num_culled * per_row + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+#define GS_SHF(LL)                                                                                                     \
+  optimizer_sh_factored_kernel<LL><<<blocks, 256, 0, st>>>(num_culled, compact_to_global, sh, exp_avg, exp_avg_sq, lr, b1, \
+                                                          b2, eps, bias1, bias2, xyz, cam_x, cam_y, cam_z, grad_precompute_rgb)
+  switch (l_max) {
+    case 1: GS_SHF(1); break;
+    case 2: GS_SHF(2); break;
+    default: GS_SHF(3); break;
+  }
+#undef GS_SHF
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

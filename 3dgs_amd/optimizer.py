@@ -58,10 +58,11 @@ class AdamOptimizer:
     def bias_corrections(it):
         return 1.0 - B1 ** (it + 1), 1.0 - B2 ** (it + 1)  # cuda/trainer.cu:1046-1047
 
-    def _groups(self, it, grads=None):
+    def _groups(self, it, grads=None, names=None):
         lrs = self.learning_rates(it)
-        arr = (_lib.AdamGroup * len(self.names))()
-        for k, g in enumerate(self.names):
+        names = self.names if names is None else names
+        arr = (_lib.AdamGroup * len(names))()
+        for k, g in enumerate(names):
             p = self.params[g]
             stride = self.cols[g][1] - self.cols[g][0]
             arr[k].param, arr[k].exp_avg, arr[k].exp_avg_sq = p.data_ptr(), self.exp_avg[g].data_ptr(), self.exp_avg_sq[g].data_ptr()
@@ -69,16 +70,30 @@ class AdamOptimizer:
             arr[k].stride, arr[k].packed_column, arr[k].lr = stride, self.cols[g][0], lrs[g]
         return arr
 
-    def step(self, it, fwd, grads):
+    def step(self, it, fwd, grads, campos=None):
         """One view: `fwd` is the dict RasterContext.rasterize_image returned, `grads` the dict filled by
         backward_pass (compacted order).  When grads carries the "uv" intermediate the densification statistics
-        (uv_grad_accum, grad_accum_dur) are updated as the reference does."""
+        (uv_grad_accum, grad_accum_dur) are updated as the reference does.
+
+        grads["sh"] is None (RasterContext.alloc_gradients(factored_sh=True)): the backward did not store the SH
+        gradients; they are rebuilt from grads["precompute_rgb"] and the viewing direction -- `campos`, the camera
+        position of the view, is needed then -- by gsplat_optimizer_step_sh_factored, BEFORE the xyz group moves."""
         b1c, b2c = self.bias_corrections(it)
-        arr = self._groups(it, grads)
+        names = list(self.names)
+        c2g = fwd["compact_to_global"].data_ptr() if fwd["num_culled"] else None
+        if "sh" in names and grads.get("sh") is None:
+            if campos is None or grads.get("precompute_rgb") is None:
+                raise ValueError("factored SH gradients need campos and grads['precompute_rgb']")
+            names.remove("sh")
+            check(_lib.load().gsplat_optimizer_step_sh_factored(
+                c2g, int(fwd["num_culled"]), int(self.l_max), self.params["sh"].data_ptr(), self.exp_avg["sh"].data_ptr(),
+                self.exp_avg_sq["sh"].data_ptr(), self.learning_rates(it)["sh"], B1, B2, EPS, b1c, b2c,
+                self.params["xyz"].data_ptr(), float(campos[0]), float(campos[1]), float(campos[2]),
+                grads["precompute_rgb"].data_ptr(), _stream()))
+        arr = self._groups(it, grads, names)
         uv = grads.get("uv")
         check(_lib.load().gsplat_optimizer_step(
-            fwd["compact_to_global"].data_ptr() if fwd["num_culled"] else None, int(fwd["num_culled"]), arr,
-            len(self.names), B1, B2, EPS, b1c, b2c, uv.data_ptr() if uv is not None else None,
+            c2g, int(fwd["num_culled"]), arr, len(names), B1, B2, EPS, b1c, b2c, uv.data_ptr() if uv is not None else None,
             self.uv_grad_accum.data_ptr() if uv is not None else None,
             self.grad_accum_dur.data_ptr() if uv is not None else None, _stream()))
 

@@ -208,21 +208,27 @@ class RasterContext:
         self._last = (g.num_gaussians, M, l_max)
         return out._all() if _EAGER_VIEWS else out
 
-    def alloc_gradients(self, M, l_max, intermediates=False, device="cuda"):
+    def alloc_gradients(self, M, l_max, intermediates=False, device="cuda", factored_sh=False):
         """Leaf gradients in compacted order; intermediates=True adds the reference's six intermediate gradient arrays
-        (cuda_data.cuh:28-36), an iterable of their names only those (the kernel skips the ones that are absent)."""
+        (cuda_data.cuh:28-36), an iterable of their names only those (the kernel skips the ones that are absent).
+        factored_sh: no `sh` array -- the backward skips the SH gradients and AdamOptimizer.step rebuilds them from
+        `precompute_rgb` (added) and the viewing direction (gsplat_optimizer_step_sh_factored)."""
         n_rest = (l_max + 1) ** 2 - 1
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         g = dict(xyz=z(M, 3), rgb=z(M, 3), sh=z(M, n_rest, 3), opacity=z(M), scale=z(M, 3), quaternion=z(M, 4))
         shapes = dict(conic=(M, 3), uv=(M, 2), J=(M, 6), sigma=(M, 6), xyz_c=(M, 3), precompute_rgb=(M, 3))
-        wanted = shapes if intermediates is True else (intermediates or ())  # True: all six; or an iterable of names
+        wanted = shapes if intermediates is True else tuple(intermediates or ())  # True: all six; or an iterable of names
+        if factored_sh and l_max > 0:
+            g["sh"] = None
+            if "precompute_rgb" not in wanted:
+                wanted = tuple(wanted) + ("precompute_rgb",)
         g.update({k: z(*shapes[k]) for k in wanted})
         return g
 
     @staticmethod
     def _grad_struct(grads):
         gs = _lib.Gradients()
-        gs.grad_xyz, gs.grad_rgb, gs.grad_sh = _ptr(grads["xyz"]), _ptr(grads["rgb"]), _ptr(grads["sh"])
+        gs.grad_xyz, gs.grad_rgb, gs.grad_sh = _ptr(grads["xyz"]), _ptr(grads["rgb"]), _ptr(grads.get("sh"))
         gs.grad_opacity, gs.grad_scale = _ptr(grads["opacity"]), _ptr(grads["scale"])
         gs.grad_quaternion = _ptr(grads["quaternion"])
         for k in ("conic", "uv", "J", "sigma", "xyz_c", "precompute_rgb"):

@@ -117,8 +117,11 @@ class Trainer:
         """Per-view gradient arrays in compacted order: allocated for the current gaussian count, sliced per view."""
         n = self.num_gaussians
         if self._grads is None or self._grads[0] < n or self._grads[1] != self.l_max:
-            self._grads = (n, self.l_max, ctx.alloc_gradients(n, self.l_max, intermediates=("uv",)))  # density statistics need |grad_uv|
-        return {k: v[:m] for k, v in self._grads[2].items()}
+            # density statistics need |grad_uv|; the SH gradients are not stored: the optimizer rebuilds them from the 24
+            # bytes they are made of (AdamOptimizer.step, gsplat_optimizer_step_sh_factored) -- single-GPU training only,
+            # the view-sharded step exchanges packed rows
+            self._grads = (n, self.l_max, ctx.alloc_gradients(n, self.l_max, intermediates=("uv",), factored_sh=True))
+        return {k: (v[:m] if v is not None else None) for k, v in self._grads[2].items()}
 
     def train_step(self, cam, gt_image, want_loss=True):
         if self.world > 1:
@@ -144,7 +147,7 @@ class Trainer:
         loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image, blocking=want_loss)
         grads = self._gradients_for(ctx, fwd["num_culled"])
         ctx.backward_pass(p, cam, grad_image, bg, self.l_max, grads)
-        self.opt.step(it, fwd, grads)
+        self.opt.step(it, fwd, grads, campos=cam["campos"])
         self.iter += 1
         return loss
 

@@ -604,14 +604,16 @@ def run_rank(args, comm, device_index):
         dp_train = {k: v.clone() for k, v in dp.items()}
         target = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)["image"].clone()
         opt = opt_mod.AdamOptimizer(dp_train, L, scene_extent=5.0)
-        tgrads = step.ctx.alloc_gradients(N, L, intermediates=("uv",))  # as the Trainer: density statistics need |grad_uv|
+        # as the Trainer: density statistics need |grad_uv|, the SH gradients are rebuilt by the optimizer instead of
+        # stored and read back (gsplat_optimizer_step_sh_factored)
+        tgrads = step.ctx.alloc_gradients(N, L, intermediates=("uv",), factored_sh=True)
         loss_grad = torch.empty(H, W, 3, device=dev)
 
         def train_step(it):
             f = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)
             ops.fused_loss(f["image"], target, H, W, 0.2, loss_grad, blocking=False)
             step.ctx.backward_pass(dp_train, dc, loss_grad, 0.0, L, tgrads)
-            opt.step(it, f, tgrads)
+            opt.step(it, f, tgrads, campos=dc["campos"])
 
         for it in range(10):
             train_step(it)

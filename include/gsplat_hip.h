@@ -52,7 +52,7 @@ extern "C" {
 const char *gsplat_last_error(void);
 /* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
  * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
-#define GSPLAT_ABI_VERSION 4
+#define GSPLAT_ABI_VERSION 5
 int gsplat_abi_version(void);
 /* What the loaded binary was built from: sha256 (first 16 hex digits) over the kernel sources (3dgs_amd/csrc: Makefile,
  * *.h, *.hip) at link time, and the extra compiler flags of a diagnostic build ("" for the product build).  A loader
@@ -206,6 +206,20 @@ int gsplat_optimizer_step(const int *compact_to_global, int num_culled, const gs
                           float b1, float b2, float eps, float bias1, float bias2, const float *grad_uv,
                           float *uv_grad_accum, int *grad_accum_dur, void *stream);
 
+/* The spherical-harmonics group of gsplat_optimizer_step without its gradient array.  The SH gradients of ONE view are an
+ * outer product (cuda/spherical_harmonics_backward.cu:168-209): d/d sh[k][c] = Y_{k+1}(direction) * grad_precompute_rgb[c],
+ * direction = normalised (xyz - camera position) -- the values the backward would have stored in grad_sh, bit for bit
+ * (the same basis function, the same product).  For the visible rows (compact_to_global, num_culled) this entry point
+ * rebuilds them from the 24 bytes they are made of and applies the same in-place Adam update to sh / exp_avg /
+ * exp_avg_sq [N, (l_max+1)^2 - 1, 3]; a backward that was given grad_sh == NULL plus this call replace a backward that
+ * writes grad_sh and an optimizer group that reads it back (360 bytes per visible gaussian and step at l_max 3).
+ * xyz [N,3] must still hold the positions the backward saw: call it BEFORE the step that updates the xyz group.
+ * grad_precompute_rgb [num_culled,3]: the intermediate gradient of that name (gsplat_gradients). */
+int gsplat_optimizer_step_sh_factored(const int *compact_to_global, int num_culled, int l_max, float *sh, float *exp_avg,
+                                      float *exp_avg_sq, float lr, float b1, float b2, float eps, float bias1,
+                                      float bias2, const float *xyz, float cam_x, float cam_y, float cam_z,
+                                      const float *grad_precompute_rgb, void *stream);
+
 /* Multi-view variant: gradients are rows of the all-reduced packed layout
  * (gsplat_pack_gradients_global / gsplat_unpack_gradients_factored, row width `width`, last column = number of
  * views that saw the gaussian); rows with a zero count are skipped, which is the union of the per-view masks.
@@ -329,6 +343,8 @@ typedef struct gsplat_forward_view {   /* ForwardPassData, cuda_data.cuh:70-86: 
 } gsplat_forward_view;
 
 typedef struct gsplat_gradients {      /* GaussianGradients (leaf part), compacted order [M,...], caller-owned */
+  /* grad_sh may be NULL (ABI 5): a single-view optimizer can rebuild the SH gradients from grad_precompute_rgb and the
+   * viewing direction (gsplat_optimizer_step_sh_factored); the backward then skips their 12 (l_max+1)^2 - 12 bytes. */
   float *grad_xyz, *grad_rgb, *grad_sh, *grad_opacity, *grad_scale, *grad_quaternion;
   /* optional intermediates (may be NULL): */
   float *grad_conic, *grad_uv, *grad_J, *grad_sigma, *grad_xyz_c, *grad_precompute_rgb;

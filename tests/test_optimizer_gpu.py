@@ -92,6 +92,66 @@ def test_packed_step_equals_single_view_step(gpu, scene):
         assert torch.equal(oa.exp_avg[g], ob.exp_avg[g]) and torch.equal(oa.exp_avg_sq[g], ob.exp_avg_sq[g]), g
 
 
+@pytest.mark.parametrize("name", ["small", "small_l1"])
+def test_factored_sh_step_equals_the_stored_gradient_step(gpu, scene, name):
+    """The SH gradients of one view are Y_{k+1}(direction) x grad_precompute_rgb (cuda/spherical_harmonics_backward.cu:168-209).
+    A backward that is given NO grad_sh array plus gsplat_optimizer_step_sh_factored (which rebuilds them in the optimizer)
+    must leave parameters and both moments of every group BIT-identical to the backward that stores them and the plain
+    group that reads them back -- same basis function, same product, same Adam -- and must not touch a culled row."""
+    torch, raster, opt_mod = gpu, pkg("raster"), pkg("optimizer")
+    if name == "small_l1":
+        N, W, H, L = 3000, 160, 96, 1
+    else:
+        N, W, H, L, _ = scene.WORKLOADS["small"]
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::3, 2] *= -1
+    cam = scene.make_camera(W, H, 1)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp_a, dc = raster.device_params(params), raster.device_camera(cam)
+    dp_b = {k: v.clone() for k, v in dp_a.items()}
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    fwd = ctx.rasterize_image(dp_a, dc, c, c["bg"], L)
+    M = fwd["num_culled"]
+    assert 0 < M < N
+    g_plain = ctx.alloc_gradients(M, L, intermediates=("uv", "precompute_rgb"))
+    g_fact = ctx.alloc_gradients(M, L, intermediates=("uv",), factored_sh=True)
+    assert g_fact["sh"] is None and g_fact["precompute_rgb"] is not None
+    ctx.backward_pass(dp_a, dc, gi, c["bg"], L, g_plain)
+    # the same compositing gradients for both (float atomics reorder between two launches): only the per-gaussian half again
+    ctx.backward_gaussians(dp_a, dc, L, g_fact)
+    torch.cuda.synchronize()
+    for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "uv", "precompute_rgb"):
+        assert torch.equal(g_plain[k], g_fact[k]), k  # leaving grad_sh out changes nothing else
+    oa, ob = opt_mod.AdamOptimizer(dp_a, L, scene_extent=2.5), opt_mod.AdamOptimizer(dp_b, L, scene_extent=2.5)
+    rng = np.random.default_rng(3)
+    for g in GROUPS:
+        m0 = torch.from_numpy((rng.standard_normal(tuple(oa.exp_avg[g].shape)) * 1e-4).astype(np.float32)).cuda()
+        v0 = torch.from_numpy((rng.random(tuple(oa.exp_avg_sq[g].shape)) * 1e-8).astype(np.float32)).cuda()
+        oa.exp_avg[g].copy_(m0); ob.exp_avg[g].copy_(m0)
+        oa.exp_avg_sq[g].copy_(v0); ob.exp_avg_sq[g].copy_(v0)
+    sh_before = dp_b["sh"].clone()
+    for it in (11, 12):  # two steps: the second one sees the moved positions, as the next iteration's backward would
+        if it == 12:
+            fwd = ctx.rasterize_image(dp_a, dc, c, c["bg"], L)   # both twins hold the same parameters
+            M = fwd["num_culled"]
+            g_plain = ctx.alloc_gradients(M, L, intermediates=("uv", "precompute_rgb"))
+            g_fact = ctx.alloc_gradients(M, L, intermediates=("uv",), factored_sh=True)
+            ctx.backward_pass(dp_a, dc, gi, c["bg"], L, g_plain)
+            ctx.backward_gaussians(dp_a, dc, L, g_fact)
+        oa.step(it, fwd, g_plain)
+        ob.step(it, fwd, g_fact, campos=cam["campos"])
+        torch.cuda.synchronize()
+        for g in GROUPS:
+            assert torch.equal(dp_a[g], dp_b[g]), (it, g)
+            assert torch.equal(oa.exp_avg[g], ob.exp_avg[g]) and torch.equal(oa.exp_avg_sq[g], ob.exp_avg_sq[g]), (it, g)
+    mask = _np(fwd["mask"]).astype(bool)
+    assert not torch.equal(dp_b["sh"], sh_before)
+    assert torch.equal(dp_b["sh"][torch.from_numpy(~mask).cuda()], sh_before[torch.from_numpy(~mask).cuda()])
+    with pytest.raises(ValueError):
+        ob.step(13, fwd, g_fact)  # no camera position: the direction cannot be rebuilt
+
+
 def test_training_iterations_reduce_the_loss(gpu, scene):
     """rasterize -> fused_loss -> backward -> optimizer step, 30 iterations on one view toward a target rendered
     from the unperturbed scene: the L1+SSIM loss must drop and PSNR must rise (reference loop: trainer.cu:417-516)."""

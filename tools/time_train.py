@@ -12,7 +12,7 @@ ctx = raster.RasterContext(N, W, H)
 target = ctx.rasterize_image(dp, cam, c, 0.0, L)["image"].clone()
 dp["rgb"] += 0.05 * torch.randn_like(dp["rgb"])
 opt = opt_mod.AdamOptimizer(dp, L, scene_extent=5.0)
-grads = ctx.alloc_gradients(N, L, intermediates=True)
+grads = ctx.alloc_gradients(N, L, intermediates=("uv",), factored_sh=os.environ.get("PLAIN_SH") != "1")
 grad_image = torch.empty(H, W, 3, device="cuda")
 
 
@@ -20,7 +20,7 @@ def step(it):
     fwd = ctx.rasterize_image(dp, cam, c, 0.0, L)
     ops.fused_loss(fwd["image"], target, H, W, 0.2, grad_image, blocking=False)
     ctx.backward_pass(dp, cam, grad_image, 0.0, L, grads)
-    opt.step(it, fwd, grads)
+    opt.step(it, fwd, grads, campos=cam["campos"])
 
 
 for it in range(10):
