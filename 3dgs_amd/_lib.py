@@ -48,9 +48,13 @@ def build_cpp_host(name):
     and link it with the library; returns the executable's path.  Rebuilt when the source, a header or the library is
     newer.  Used by the tests, by bench.py's reference_host_path leg and by __graft_entry__.build()."""
     root = os.path.normpath(os.path.join(_HERE, ".."))
-    lib = build()
     src = os.path.join(root, "tests", "cpp", name + ".cpp")
     exe = os.path.join(root, "tests", "cpp", name)
+    if os.environ.get("GSPLAT_NO_BUILD") == "1":  # a process with an initialised GPU (a rank, a profiled run): no compilers
+        if not os.path.exists(exe):
+            raise OSError(f"{exe} is missing and GSPLAT_NO_BUILD=1 forbids building it")
+        return exe
+    lib = build()
     inc = os.path.join(root, "include", "gsplat_cuda")
     deps = [src, lib, os.path.join(root, "include", "gsplat_hip.h")] + [os.path.join(inc, h) for h in os.listdir(inc)]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in deps):
@@ -116,7 +120,7 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
-ABI_VERSION = 5  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
+ABI_VERSION = 6  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -147,6 +151,10 @@ SIGNATURES = {
     "gsplat_render_image_backward": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gsplat_context_set_binning_route": (_I, [_P, _I]),
     "gsplat_backward_render": (_I, [_P, _P, _F, _P, _P]),
+    "gsplat_backward_render_split": (_I, [_P, _P, _F, _P, _P, _P, _P]),
+    "gsplat_backward_gaussians_split": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "gsplat_optimizer_step_sh_views": (_I, [_I, _I, _I, _P, _P, _S, _P, _P, _P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
+    "gsplat_compact_masked_array_bounded": (_I, [_P, _P, _I, _I, _P, _I, ctypes.POINTER(_I), _P]),
     "gsplat_backward_gaussians": (_I, [_P, _P, _P, _I, _P, _P]),
     "gsplat_backward_gaussians_range": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
     "gsplat_pack_gradients_split_range": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),

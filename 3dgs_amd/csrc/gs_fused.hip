@@ -489,6 +489,11 @@ __global__ __launch_bounds__(64) void publish_counts_kernel(const int *__restric
 struct BwdOut {
   float *xyz, *rgb, *sh, *opacity, *scale, *quaternion;
   float *conic, *uv, *J, *sigma, *xyz_c, *pre_rgb;
+  // r05, view-sharded step: instead of the six compacted leaf arrays the kernel writes the row the exchange sums --
+  // common[i] = {xyz 3, opacity, scale 3, quaternion 4, 1.0 (this view saw the gaussian)} at the gaussian's GLOBAL index i
+  // (48 bytes, three 16-byte stores) -- and |grad_uv| at uv_norm[i]; the rows of culled gaussians were zeroed by
+  // gsplat_backward_render_split.  No compacted gradient array, no pack pass.
+  float *common, *uv_norm;
 };
 
 // Number of entries of the increasing array c2g[0..M) that are below `key` = the first compacted slot whose global index
@@ -652,11 +657,19 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   gs::camera_space_bwd(vw, cxg, cyg, czg, wx, wy, wz);
   gx += wx; gy += wy; gz += wz;
   // stores
-  o.xyz[3 * j] = gx; o.xyz[3 * j + 1] = gy; o.xyz[3 * j + 2] = gz;
-  o.rgb[3 * j] = b0g[0]; o.rgb[3 * j + 1] = b0g[1]; o.rgb[3 * j + 2] = b0g[2];
-  o.opacity[j] = g_op;
-  o.scale[3 * j] = dSc[0]; o.scale[3 * j + 1] = dSc[1]; o.scale[3 * j + 2] = dSc[2];
-  reinterpret_cast<float4 *>(o.quaternion)[j] = make_float4(dQ[0], dQ[1], dQ[2], dQ[3]);
+  if (o.common) {  // the exchange's row, in global order (the same twelve values pack_split_kernel gathers)
+    gs::f4u *row = reinterpret_cast<gs::f4u *>(o.common + (size_t)i * 12);
+    row[0] = gs::f4u{gx, gy, gz, g_op};
+    row[1] = gs::f4u{dSc[0], dSc[1], dSc[2], dQ[0]};
+    row[2] = gs::f4u{dQ[1], dQ[2], dQ[3], 1.0f};
+    if (o.uv_norm) o.uv_norm[i] = sqrtf(g_u * g_u + g_v * g_v);  // pack_uv_norm_kernel's expression
+  } else {
+    o.xyz[3 * j] = gx; o.xyz[3 * j + 1] = gy; o.xyz[3 * j + 2] = gz;
+    o.opacity[j] = g_op;
+    o.scale[3 * j] = dSc[0]; o.scale[3 * j + 1] = dSc[1]; o.scale[3 * j + 2] = dSc[2];
+    reinterpret_cast<float4 *>(o.quaternion)[j] = make_float4(dQ[0], dQ[1], dQ[2], dQ[3]);
+  }
+  if (o.rgb) { o.rgb[3 * j] = b0g[0]; o.rgb[3 * j + 1] = b0g[1]; o.rgb[3 * j + 2] = b0g[2]; }
   if (o.conic) { o.conic[3 * j] = g_con[0]; o.conic[3 * j + 1] = g_con[1]; o.conic[3 * j + 2] = g_con[2]; }
   if (o.uv) { o.uv[2 * j] = g_u; o.uv[2 * j + 1] = g_v; }
   if (o.pre_rgb) { o.pre_rgb[3 * j] = g_rgb[0]; o.pre_rgb[3 * j + 1] = g_rgb[1]; o.pre_rgb[3 * j + 2] = g_rgb[2]; }
@@ -758,11 +771,19 @@ __global__ __launch_bounds__(kBlock) void unpack_factored_kernel(const float *__
 __global__ __launch_bounds__(kBlock) void scatter_rgb_rows_kernel(const unsigned char *__restrict__ mask,
                                                                   const int *__restrict__ rank_of, int N,
                                                                   const float *__restrict__ rows,
-                                                                  float *__restrict__ rgb) {
+                                                                  float *__restrict__ rgb, float *__restrict__ common,
+                                                                  float *__restrict__ uv_norm) {
   const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (e >= (long long)N * 3) return;
   const int i = (int)(e / 3), k = (int)(e % 3);
-  rgb[e] = mask[i] ? rows[(size_t)rank_of[i] * 16 + k] : 0.0f;
+  const bool kept = mask[i] != 0;
+  rgb[e] = kept ? rows[(size_t)rank_of[i] * 16 + k] : 0.0f;
+  // r05: the exchange's twelve common columns are written in place by preprocess_bwd_kernel for the gaussians this view
+  // saw; the rows of the culled ones are cleared here (thread k of a row: its k-th 16 bytes), where the mask is read anyway
+  if (common && !kept) {
+    reinterpret_cast<gs::f4u *>(common + (size_t)i * 12)[k] = gs::f4u{0.0f, 0.0f, 0.0f, 0.0f};
+    if (uv_norm && k == 0) uv_norm[i] = 0.0f;
+  }
 }
 
 // |grad_uv| of this view in global gaussian order (0 where culled): the densification statistic of a view-sharded step
@@ -875,6 +896,24 @@ __global__ __launch_bounds__(kBlock) void unpack_split_kernel(const float *__res
       }
     }
   }
+}
+
+// Room of the instance buffers, in INSTANCES: the smallest element count of the per-instance arrays, minus the one spare
+// slot every user keeps.  Each array is a DeviceBuffer grown by `want + want / 4 + 256` BYTES, so arrays of different
+// element size end up with different element counts for the same S (8-byte payloads: 32 entries of slack, 4-byte keys:
+// 64, 2-byte masks: 128) -- a bound taken from one array alone is not a bound for the others.  Until r05 the radix
+// route bounded its speculative tile_emit_payload_kernel by keys_a's count only, 31 entries more than pay_a holds: a
+// forward whose instances outgrew the room wrote 248 bytes past the end of pay_a (test_instance_buffers_grow's radix
+// case: a 12 266-byte allocation that ends 22 bytes before its page does; whether the next page is mapped depends on
+// what the allocator placed there -- the unexplained abort of r04's suite).
+size_t instance_room(const gsplat_context *c) {
+  size_t room = c->keys_a.bytes / sizeof(unsigned int);
+  room = std::min(room, c->keys_b.bytes / sizeof(unsigned int));
+  room = std::min(room, c->pay_a.bytes / sizeof(unsigned long long));
+  room = std::min(room, c->pay_b.bytes / sizeof(unsigned long long));
+  room = std::min(room, c->sorted.bytes / sizeof(int));
+  room = std::min(room, c->blockmasks.bytes / sizeof(unsigned short));
+  return room;
 }
 
 int reserve_instances(gsplat_context *c, size_t S, int num_tiles, hipStream_t st) {
@@ -1149,12 +1188,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   const unsigned long long ticket = ++c->ticket;
   size_t spec_cap = 0;  // sparse route: room of the instance buffers, what the kernels queued before the wait may use
   if (sparse) {
-    auto room_of = [&]() {
-      return std::min(std::min(c->pay_a.bytes / sizeof(unsigned long long), c->sorted.bytes / sizeof(int)),
-                      std::min(c->blockmasks.bytes / sizeof(unsigned short), c->keys_a.bytes / sizeof(unsigned int)));
-    };
-    if (room_of() < 2 && (rc = reserve_instances(c, 4 * (size_t)N, num_tiles, st))) return rc;
-    spec_cap = room_of() - 1;
+    if (instance_room(c) < 2 && (rc = reserve_instances(c, 4 * (size_t)N, num_tiles, st))) return rc;
+    spec_cap = instance_room(c) - 1;
     c->mark(1, true, st);
     c->mark(2, false, st);
     rc = gs::binning_offsets(ntx, nty, bin_table, c->keys_a.as<int>(), st);
@@ -1170,7 +1205,9 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   if (!sparse) {
     // Emit does not need the totals on the host, only room for its writes: launch it bounded by the buffers'
     // capacity and sleep on the read-back while it runs (the reference blocks five times per forward, GPU idle).
-    inst_cap = c->keys_a.bytes / sizeof(unsigned int) - 1;
+    // (the bound is the room of ALL instance arrays: see instance_room)
+    if (instance_room(c) < 2 && (rc = reserve_instances(c, 4 * (size_t)N, num_tiles, st))) return rc;
+    inst_cap = instance_room(c) - 1;
     c->mark(2, false, st);
     rc = gs::launch_tile_emit(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                               c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(),
@@ -1189,6 +1226,10 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : 1;
   };
   auto queue_tail = [&](size_t cap, long long longest_hint, bool publish) -> int {  // the placement publishes the record
+    if (cap + 1 > instance_room(c)) {  // every kernel below indexes the instance arrays up to `cap` (inclusive: the spare slot)
+      gs::set_error("gsplat_rasterize_image: internal: %zu instances queued into room for %zu", cap, instance_room(c));
+      return GSPLAT_ERR_CAPACITY;
+    }
     if ((longest_hint < 0 || longest_hint > 2048) && !c->fork.ready) {  // lists beyond two register-sorted runs: see SortFork
       const int fr = c->fork.create();
       if (fr) return fr;
@@ -1286,6 +1327,10 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     }
   } else {
     if ((rc = reserve_instances(c, S, num_tiles, st))) return rc;
+    if (S + 1 > instance_room(c)) {
+      gs::set_error("gsplat_rasterize_image: internal: %zu instances sorted in room for %zu", S, instance_room(c));
+      return GSPLAT_ERR_CAPACITY;
+    }
     rc = gs::emit_sort_ranges(c->uv.as<float>(), c->xyz_c.as<float>(), c->radius.as<float>(), ntx, nty, N,
                               c->mask.as<unsigned char>(), c->rank.as<int>(), c->offsets.as<int>(), S,
                               c->keys_a.as<unsigned int>(), c->keys_b.as<unsigned int>(),
@@ -1328,10 +1373,21 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
 
 int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_color, float *rgb_global,
                            void *stream) {
+  return gsplat_backward_render_split(c, grad_image, bg_color, rgb_global, nullptr, nullptr, stream);
+}
+
+int gsplat_backward_render_split(gsplat_context *c, const float *grad_image, float bg_color, float *rgb_global,
+                                 float *common, float *uv_norm, void *stream) {
   GS_REQUIRE(c != nullptr, "null context");
   GS_REQUIRE(c->have_forward, "no forward pass recorded in this context");
   GS_REQUIRE_DEV(grad_image);
   if (rgb_global) GS_REQUIRE_DEV(rgb_global);
+  if (common) {
+    GS_REQUIRE(rgb_global != nullptr, "the common rows are cleared by the pass that scatters g_rgb: rgb_global is needed");
+    GS_REQUIRE_DEV(common);
+    GS_REQUIRE(((uintptr_t)common & 15) == 0, "common must be 16-byte aligned");
+  }
+  if (uv_norm) { GS_REQUIRE(common != nullptr, "uv_norm goes with common"); GS_REQUIRE_DEV(uv_norm); }
   hipStream_t st = (hipStream_t)stream;
   const int M = c->M, W = c->width, H = c->height;
   c->rows_ready = false;
@@ -1355,7 +1411,7 @@ int gsplat_backward_render(gsplat_context *c, const float *grad_image, float bg_
   if (timed) c->pending[c->slot][6] = 1;
   if (rgb_global) {
     scatter_rgb_rows_kernel<<<gs::div_up((long long)c->N * 3, kBlock), kBlock, 0, st>>>(
-        c->mask.as<unsigned char>(), c->rank.as<int>(), c->N, c->grad_rows.as<float>(), rgb_global);
+        c->mask.as<unsigned char>(), c->rank.as<int>(), c->N, c->grad_rows.as<float>(), rgb_global, common, uv_norm);
     GS_LAUNCH_CHECK();
   }
   c->rows_ready = true;
@@ -1367,17 +1423,40 @@ int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, cons
   return gsplat_backward_gaussians_range(c, g, cam, l_max, out, 0, g ? g->num_gaussians : 0, stream);
 }
 
+static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
+                                   const gsplat_gradients *out, float *common, float *uv_norm, int first_gaussian,
+                                   int end_gaussian, void *stream);
+
 int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                     const gsplat_gradients *out, int first_gaussian, int end_gaussian, void *stream) {
-  GS_REQUIRE(c && g && cam && out, "null argument struct");
+  GS_REQUIRE(out != nullptr, "null argument struct");
+  return backward_gaussians_impl(c, g, cam, l_max, out, nullptr, nullptr, first_gaussian, end_gaussian, stream);
+}
+
+int gsplat_backward_gaussians_split(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
+                                    float *common, float *uv_norm, int first_gaussian, int end_gaussian, void *stream) {
+  GS_REQUIRE_DEV(common);
+  GS_REQUIRE(((uintptr_t)common & 15) == 0, "common must be 16-byte aligned");
+  if (uv_norm) GS_REQUIRE_DEV(uv_norm);
+  return backward_gaussians_impl(c, g, cam, l_max, nullptr, common, uv_norm, first_gaussian, end_gaussian, stream);
+}
+
+static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
+                                   const gsplat_gradients *out, float *common, float *uv_norm, int first_gaussian,
+                                   int end_gaussian, void *stream) {
+  GS_REQUIRE(c && g && cam, "null argument struct");
   GS_REQUIRE(0 <= first_gaussian && first_gaussian <= end_gaussian && end_gaussian <= g->num_gaussians, "bad gaussian range");
   GS_REQUIRE(c->have_forward && c->rows_ready, "gsplat_backward_render has not run for this forward pass");
   GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N && cam->width == c->width && cam->height == c->height,
              "backward arguments do not match the recorded forward pass");
-  GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
-  GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
+  static const gsplat_gradients kNoArrays = {};
+  if (!out) out = &kNoArrays;  // split form: the twelve common columns go to `common`, nothing else is stored
+  if (!common) {
+    GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
+    GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
+    GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
+  }
   if (l_max > 0 && out->grad_sh) GS_REQUIRE_DEV(out->grad_sh);  // NULL: the caller rebuilds them (gsplat_optimizer_step_sh_factored)
-  GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int M = c->M, W = c->width, H = c->height;
   // cuda/trainer.cu:992-995
@@ -1387,7 +1466,8 @@ int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g
   const float tan_fovx = tanf(fov_x * 0.5f), tan_fovy = tanf(fov_y * 0.5f);
   const float fwd_tan_fovx = c->tan_fovx, fwd_tan_fovy = c->tan_fovy;  // the recorded forward's (cuda/raster.cu:92-93)
   BwdOut bo = {out->grad_xyz, out->grad_rgb, out->grad_sh, out->grad_opacity, out->grad_scale, out->grad_quaternion,
-               out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb};
+               out->grad_conic, out->grad_uv, out->grad_J, out->grad_sigma, out->grad_xyz_c, out->grad_precompute_rgb,
+               common, uv_norm};
   // a range of global indices holds at most that many visible gaussians (and never more than M); the kernel finds the
   // range's compacted slots in compact_to_global on the device (first_slot_not_below)
   const bool whole = first_gaussian == 0 && end_gaussian == g->num_gaussians;

@@ -413,6 +413,76 @@ __global__ __launch_bounds__(256) void optimizer_sh_factored_kernel(int rows, co
     adam_update(&sh[o + c], &m[o + c], &v[o + c], g_rgb[3 * r + c] * yv, lr, b1, b2, eps, bias1, bias2);
 }
 
+// r05: the colour groups (band 0 and the SH coefficients) of a W-VIEW step, from what the split exchange delivers: every
+// view's g_rgb[N,3] in global order + its camera position (rgb_all) and the number of views that saw a gaussian
+// (common[., 11]).  Phase 1, one thread per gaussian: grad[k][c] = sum_r g_rgb^r[c] Y_k(dir^r) exactly as
+// unpack_split_kernel (gs_fused.hip) forms it -- views in rank order, views with an all-zero g_rgb skipped, mul then add --
+// W basis evaluations per gaussian, into the wave's LDS rows (odd pitch: a lane writing ITS row is conflict-free).
+// Phase 2, the wave streams over its 64 consecutive parameter rows as ONE linear span (the rows of rgb[N,3] and of
+// sh[N,3(n-1)] are contiguous in global order): parameter and both moments are read and written coalesced, the gradient
+// comes from LDS.  Nothing of packed[N, 12 + 3 n] is written or read: 240 B per gaussian each way at SH degree 3.
+template <int L>
+__global__ __launch_bounds__(256) void optimizer_sh_views_kernel(int N, int world, const float *__restrict__ xyz,
+                                                                 const float *__restrict__ rgb_all, size_t stride,
+                                                                 const float *__restrict__ common,
+                                                                 float *__restrict__ rgb, float *__restrict__ rgb_m,
+                                                                 float *__restrict__ rgb_v, float lr_rgb,
+                                                                 float *__restrict__ sh, float *__restrict__ sh_m,
+                                                                 float *__restrict__ sh_v, float lr_sh, float b1, float b2,
+                                                                 float eps, float bias1, float bias2) {
+  constexpr int n = (L + 1) * (L + 1), kCols = 3 * n, kPitch = kCols | 1, kRest = 3 * (n - 1);
+  __shared__ float s_g[256 * kPitch];
+  const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
+  const int iw = blockIdx.x * 256 + wave_first;  // first gaussian of this wave
+  if (iw >= N) return;
+  const int i = iw + lane;
+  float *mine = s_g + (wave_first + lane) * kPitch;
+  bool vis = false;
+  if (i < N) {
+    vis = common[(size_t)i * 12 + 11] > 0.0f;
+    float acc[n][3];
+#pragma unroll
+    for (int k = 0; k < n; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    if (vis) {
+      const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+      for (int r = 0; r < world; ++r) {
+        const float *blk = rgb_all + (size_t)r * stride;
+        const float g0 = blk[3 * (size_t)i], g1 = blk[3 * (size_t)i + 1], g2 = blk[3 * (size_t)i + 2];
+        if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+        const float *cp = blk + 3 * (size_t)N;
+        float dx, dy, dz, len, Y[n];
+        gs::view_dir(px, py, pz, cp[0], cp[1], cp[2], dx, dy, dz, len);
+        gs::sh_basis<L>(dx, dy, dz, Y);
+#pragma unroll
+        for (int k = 0; k < n; ++k) { acc[k][0] += g0 * Y[k]; acc[k][1] += g1 * Y[k]; acc[k][2] += g2 * Y[k]; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) { mine[3 * k] = acc[k][0]; mine[3 * k + 1] = acc[k][1]; mine[3 * k + 2] = acc[k][2]; }
+  }
+  const unsigned long long seen = __ballot(vis);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (seen == 0ull) return;
+  const int rows = min(64, N - iw);
+  const float *wrows = s_g + wave_first * kPitch;
+  {  // band 0: rgb[iw .. iw + rows), three floats per row
+    float *p = rgb + (size_t)iw * 3, *m = rgb_m + (size_t)iw * 3, *v = rgb_v + (size_t)iw * 3;
+    for (int e = lane; e < rows * 3; e += 64) {
+      const int r = e / 3, c = e - r * 3;
+      if ((seen >> r) & 1ull) adam_update(p + e, m + e, v + e, wrows[r * kPitch + c], lr_rgb, b1, b2, eps, bias1, bias2);
+    }
+  }
+  if constexpr (kRest > 0) {
+    float *p = sh + (size_t)iw * kRest, *m = sh_m + (size_t)iw * kRest, *v = sh_v + (size_t)iw * kRest;
+#pragma unroll 5
+    for (int e = lane; e < rows * kRest; e += 64) {
+      const int r = e / kRest, c = e - r * kRest;
+      if ((seen >> r) & 1ull) adam_update(p + e, m + e, v + e, wrows[r * kPitch + 3 + c], lr_sh, b1, b2, eps, bias1, bias2);
+    }
+  }
+}
+
 int build_group_table(const gsplat_adam_group *groups, int n_groups, bool packed, GroupTable *t, const char *fn) {
   if (!groups || n_groups < 1 || n_groups > GSPLAT_MAX_ADAM_GROUPS) {
     gs::set_error("%s: invalid argument: need 1..%d parameter groups", fn, GSPLAT_MAX_ADAM_GROUPS);
@@ -587,6 +657,35 @@ int gsplat_optimizer_step_sh_factored(const int *compact_to_global, int num_cull
     default: GS_SHF(3); break;
   }
 #undef GS_SHF
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_optimizer_step_sh_views(int l_max, int num_gaussians, int world_size, const float *xyz, const float *rgb_all,
+                                   size_t rank_stride, const float *common, float *rgb, float *rgb_exp_avg,
+                                   float *rgb_exp_avg_sq, float lr_rgb, float *sh, float *sh_exp_avg,
+                                   float *sh_exp_avg_sq, float lr_sh, float b1, float b2, float eps, float bias1,
+                                   float bias2, void *stream) {
+  GS_REQUIRE(num_gaussians >= 0 && world_size >= 1, "bad sizes");
+  GS_REQUIRE(l_max >= 0 && l_max <= 3, "l_max must be 0..3");
+  if (num_gaussians == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(xyz); GS_REQUIRE_DEV(rgb_all); GS_REQUIRE_DEV(common);
+  GS_REQUIRE_DEV(rgb); GS_REQUIRE_DEV(rgb_exp_avg); GS_REQUIRE_DEV(rgb_exp_avg_sq);
+  if (l_max > 0) { GS_REQUIRE_DEV(sh); GS_REQUIRE_DEV(sh_exp_avg); GS_REQUIRE_DEV(sh_exp_avg_sq); }
+  GS_REQUIRE(rank_stride >= 3 * (size_t)num_gaussians + 3, "rank_stride must cover [N,3] g_rgb + campos[3]");
+  const unsigned int blocks = gs::div_up(num_gaussians, 256);
+  hipStream_t st = (hipStream_t)stream;
+#define GS_SHV(LL)                                                                                                     \
+  optimizer_sh_views_kernel<LL><<<blocks, 256, 0, st>>>(num_gaussians, world_size, xyz, rgb_all, rank_stride, common, rgb, \
+                                                       rgb_exp_avg, rgb_exp_avg_sq, lr_rgb, sh, sh_exp_avg, sh_exp_avg_sq, \
+                                                       lr_sh, b1, b2, eps, bias1, bias2)
+  switch (l_max) {
+    case 0: GS_SHV(0); break;
+    case 1: GS_SHV(1); break;
+    case 2: GS_SHV(2); break;
+    default: GS_SHV(3); break;
+  }
+#undef GS_SHV
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__rest
                                                              const unsigned char *__restrict__ mask,
                                                              const int *__restrict__ ranks,
                                                              const int *__restrict__ slice_counts, int N,
-                                                             unsigned int total, int stride_rt, float *__restrict__ dst) {
+                                                             unsigned int total, int stride_rt, float *__restrict__ dst,
+                                                             unsigned int room_rows) {
   __shared__ int s_base[kMaskSlices + 1];
   mask_slice_bases(slice_counts, s_base);
   const unsigned int stride = kStride > 0 ? (unsigned int)kStride : (unsigned int)stride_rt;
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__rest
     const unsigned int i = e / stride, k = e - i * stride;
     if (!mask[i]) continue;
     const size_t slot = (size_t)(s_base[mask_slice_of(N, i, slices_per_row)] + ranks[i]);
+    if (slot >= room_rows) continue;  // the compacted side holds room_rows rows (the caller's count: cuda_data.cuh:106-127)
     if (kScatter) dst[e] = src[slot * stride + k];
     else dst[slot * stride + k] = src[e];
   }
@@ -296,14 +298,14 @@ __global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__rest
 
 template <bool kScatter>
 static int launch_masked_rows(const float *src, const unsigned char *mask, const int *ranks, const int *slice_counts, int N,
-                              int stride, float *dst, hipStream_t st) {
+                              int stride, float *dst, hipStream_t st, unsigned int room_rows = 0xFFFFFFFFu) {
   const long long total = (long long)N * stride;
   if (total > 0xFFFFFFF0ll - (long long)kRowsPer * kBlock) {
     gs::set_error("compact / scatter_masked_array: %d rows of %d elements exceed the 32-bit element index", N, stride);
     return GSPLAT_ERR_INVALID_ARG;
   }
   const dim3 grid(gs::div_up(total, (long long)kRowsPer * kBlock)), block(kBlock);
-#define GS_ROWS(S) masked_rows_kernel<kScatter, S><<<grid, block, 0, st>>>(src, mask, ranks, slice_counts, N, (unsigned int)total, stride, dst)
+#define GS_ROWS(S) masked_rows_kernel<kScatter, S><<<grid, block, 0, st>>>(src, mask, ranks, slice_counts, N, (unsigned int)total, stride, dst, room_rows)
   switch (stride) {
     case 1: GS_ROWS(1); break;
     case 2: GS_ROWS(2); break;
@@ -500,7 +502,12 @@ int gsplat_precompute_spherical_harmonics_backward(const float *xyz_c, const flo
 
 int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int N, int stride, float *dst,
                                 int *num_selected, void *stream) {
-  GS_REQUIRE(N >= 0 && stride > 0, "N < 0 or stride <= 0");
+  return gsplat_compact_masked_array_bounded(src, mask, N, stride, dst, N, num_selected, stream);
+}
+
+int gsplat_compact_masked_array_bounded(const float *src, const unsigned char *mask, int N, int stride, float *dst,
+                                        int dst_rows, int *num_selected, void *stream) {
+  GS_REQUIRE(N >= 0 && stride > 0 && dst_rows >= 0, "N < 0, stride <= 0 or dst_rows < 0");
   if (num_selected) *num_selected = 0;
   if (N == 0) return GSPLAT_OK;  // empty input is legal (tests/cuda_data_test.cpp CompactMaskedArrayEmpty)
   GS_REQUIRE_DEV(src); GS_REQUIRE_DEV(mask); GS_REQUIRE_DEV(dst);
@@ -509,7 +516,7 @@ int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int
   int *ranks = nullptr, *slice_counts = nullptr;
   int rc = gs::mask_slice_ranks(mask, N, &ranks, &slice_counts, st);
   if (rc) return rc;
-  if ((rc = launch_masked_rows<false>(src, mask, ranks, slice_counts, N, stride, dst, st))) return rc;
+  if ((rc = launch_masked_rows<false>(src, mask, ranks, slice_counts, N, stride, dst, st, (unsigned int)dst_rows))) return rc;
   if (!num_selected) return GSPLAT_OK;  // the caller knows the count (the reference's call sites pass num_culled)
   rc = gs::host_words().ensure();
   if (rc) return rc;

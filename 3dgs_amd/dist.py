@@ -50,28 +50,47 @@ class _Done:
 
 
 class TorchComm:
-    """The exchange's collectives on torch.distributed's default group (RCCL over xGMI on the GPUs, gloo in the CPU
-    tests and the one-GPU rehearsals); a single process is a group of one."""
+    """The exchange's collectives on a torch.distributed process group (RCCL over xGMI on the GPUs, gloo in the CPU
+    tests and the one-GPU rehearsals); a single process is a group of one.  group=None: the default group.
+    TorchComm.own_group() makes a group -- a communicator -- of its own over all ranks: bench.py runs its headline on one
+    and its optional payload sweep on another, so that an RCCL error in the sweep cannot reach the headline's
+    communicator (close() destroys an owned group)."""
 
-    def __init__(self):
+    def __init__(self, group=None, owned=False):
         self.on = dist.is_initialized()  # a group of ONE still goes through the backend (tools/nccl_one_rank.py)
-        self.world = dist.get_world_size() if self.on else 1
-        self.rank = dist.get_rank() if self.on else 0
+        self.group, self.owned = group, bool(owned and group is not None)
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+
+    @classmethod
+    def own_group(cls):
+        """A fresh group over all ranks of the default group (collective: every rank calls it, in the same order)."""
+        if not dist.is_initialized():
+            return cls()
+        return cls(dist.new_group(ranks=list(range(dist.get_world_size())), backend=dist.get_backend()), owned=True)
+
+    def close(self):
+        if self.owned and self.group is not None:
+            dist.destroy_process_group(self.group)
+        self.group, self.owned = None, False
 
     def all_reduce(self, t, async_op=False):
         if not self.on:
             return _Done()
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op) or _Done()
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op) or _Done()
 
     def all_gather_blocks(self, out, block, async_op=False):
-        """out[world, ...] <- every rank's `block`.  One collective; RCCL/NCCL gathers straight into the contiguous
-        buffer, gloo (CPU tests, single-GPU rehearsal) takes the list form."""
+        """out[world, ...] <- every rank's `block` (which may BE out[rank]: the in-place form).  One collective;
+        RCCL/NCCL gathers straight into the contiguous buffer, gloo (CPU tests, single-GPU rehearsal) takes the list form."""
         if not self.on:
-            out[0].copy_(block)
+            if out[0].data_ptr() != block.data_ptr():
+                out[0].copy_(block)
             return _Done()
-        if dist.get_backend() == "nccl":
-            return dist.all_gather_into_tensor(out, block, async_op=async_op) or _Done()
-        return dist.all_gather(list(out.unbind(0)), block, async_op=async_op) or _Done()
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_gather_into_tensor(out, block, group=self.group, async_op=async_op) or _Done()
+        if out[self.rank].data_ptr() == block.data_ptr():
+            block = block.clone()  # gloo's list form does not take an input that aliases its output
+        return dist.all_gather(list(out.unbind(0)), block, group=self.group, async_op=async_op) or _Done()
 
     def all_to_all_blocks(self, out, inp, async_op=False):
         """out[r] <- rank r's inp[my rank]: every rank sends block j of `inp` to rank j -- W-1 point-to-point transfers
@@ -80,29 +99,30 @@ class TorchComm:
         if not self.on:
             out[0].copy_(inp[0])
             return _Done()
-        if dist.get_backend() == "nccl":
-            return dist.all_to_all_single(out, inp, async_op=async_op) or _Done()
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_to_all_single(out, inp, group=self.group, async_op=async_op) or _Done()
         out[self.rank].copy_(inp[self.rank])
         ops = []
         for r in range(self.world):
             if r != self.rank:
-                ops.append(dist.P2POp(dist.isend, inp[r], r))
-                ops.append(dist.P2POp(dist.irecv, out[r], r))
+                peer = dist.get_global_rank(self.group, r) if self.group is not None else r
+                ops.append(dist.P2POp(dist.isend, inp[r], peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, out[r], peer, group=self.group))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return _Done()
 
     def barrier(self):
         if self.on:
-            dist.barrier()
+            dist.barrier(group=self.group)
 
     def all_reduce_max(self, t):
         if self.on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
     def backend(self):
-        return dist.get_backend() if self.world > 1 else "none"
+        return dist.get_backend(self.group) if self.world > 1 else "none"
 
 
 class ThreadGroup:
@@ -280,21 +300,30 @@ def unpack(packed, l_max):
 
 
 class ViewShardedStep:
-    """forward + backward of this rank's view, then the gradient exchange.  Device tensors in, packed[N,width] out.
+    """forward + backward of this rank's view, then the gradient exchange.  Device tensors in; out: the summed
+    per-gaussian gradients of the step's W views on every rank.
 
-    exchange="split" (default): the same factorisation as "factored" below, as two concurrent collectives with less
-    traffic: the 12 direction-independent columns are SUM all-reduced ([N,12]) and every rank's g_rgb[N,3] + camera
-    position is all-gathered ([world, N+1, 3]); at 8 ranks a rank moves 168 MB per step instead of 252 MB.
+    exchange="split" (default): every SH-coefficient gradient of a view is the outer product g_rgb[3] x Y_k(view
+    direction), so a rank ships only g_rgb.  Two concurrent collectives: the 12 direction-independent columns are SUM
+    all-reduced (common[N,12] = xyz 3, opacity, scale 3, quaternion 4, views that saw the gaussian) and every rank's
+    g_rgb[N,3] + camera position is all-gathered in place (rgb_all[world, N+1, 3]); at 8 ranks a rank moves 168 MB per
+    step instead of 420 MB.  r05: the step's OUTPUT is that factored form -- `common` and `rgb_all` -- which
+    AdamOptimizer.step_split consumes directly (gsplat_optimizer_step_sh_views rebuilds sum_r g_rgb^r x Y_k(dir^r) inside the
+    colour groups' Adam); no compacted gradient array, no pack pass and no packed[N, 12 + 3 n] rows are written: the
+    per-gaussian backward writes its twelve columns straight into common at the gaussians' global indices
+    (gsplat_backward_gaussians_split), the compositing backward's g_rgb goes straight into this rank's block of rgb_all.
+    `packed` materialises the rows on demand (tests, comparisons).
+    exchange="split_packed": the same collectives, and the packed rows materialised in every step (r04's default).
+    exchange="split_direct": the split payload with the all-reduce spelled out as its two direct halves (below).
     exchange="factored": ONE all-reduce whose buffer carries, per gaussian, the 12 non-SH gradient columns plus
     one 3-float g_rgb slot per rank (12 + 3*world floats instead of 12 + 3*n_coeffs = 60 at SH degree 3), and one
-    extra row with every rank's camera position; the SH-coefficient gradients sum_r g_rgb^r x Y(dir^r) are rebuilt
-    locally afterwards (gsplat_unpack_gradients_factored).  Still ONE all-reduce per step.
+    extra row with every rank's camera position; the SH-coefficient gradients are rebuilt locally afterwards
+    (gsplat_unpack_gradients_factored).  Still ONE all-reduce per step.
     exchange="full": all-reduce the complete packed[N, 12+3*n_coeffs] rows (the north star's single all-reduce).
 
     with_uv_norm=True (training): the all-reduced buffer carries N more floats, the per-view |grad_uv| in global
-    order (gsplat_pack_uv_grad_norm), so that after the exchange `uv_norm_sum[N]` holds the sum over the step's views:
-    what the densification statistics of cuda/trainer.cu:1136-1157 need on a view-sharded step.  Same collective,
-    no extra launch on the wire.
+    order, so that after the exchange `uv_norm_sum[N]` holds the sum over the step's views: what the densification
+    statistics of cuda/trainer.cu:1136-1157 need on a view-sharded step.  Same collective, no extra launch on the wire.
     """
 
     def __init__(self, params, l_max, width, height, config, bg, exchange="split", with_uv_norm=False, ctx=None,
@@ -311,36 +340,40 @@ class ViewShardedStep:
             ctx.set_lean_forward(True)
         self.ctx = ctx
         self.width_cols = wc = raster.packed_gradient_width(l_max)
-        dev = params["xyz"].device
+        self.dev = dev = params["xyz"].device
         self.comm = comm if comm is not None else TorchComm()  # ThreadComm: in-process ranks (ThreadGroup)
         self.world, self.rank = self.comm.world, self.comm.rank
-        if exchange not in ("split", "split_direct", "factored", "full"):
+        if exchange not in ("split", "split_packed", "split_direct", "factored", "full"):
             raise ValueError(f"unknown exchange {exchange!r}")
         # "split_direct": the split payload with the all-reduce of the twelve common columns spelled out as its two
         # direct halves -- an all-to-all of the W shards (every peer over its own xGMI link), a local sum, an all-gather of
         # the reduced shards -- instead of leaving the algorithm to RCCL (a single-link ring is per-link bound).
         self.direct = exchange == "split_direct"
-        self.exchange = exchange = "split" if self.direct else exchange
+        self.materialize = exchange == "split_packed"  # unpack into packed[N, 12 + 3 n] in every step
+        self.exchange = exchange = "split" if exchange.startswith("split") else exchange
         # a group of ONE normally skips the exchange; exchange_at_world_one runs it anyway (the collectives degenerate to
         # copies through the real backend): what tools/nccl_one_rank.py uses to rehearse and to time the host's share
         self.always_exchange = bool(exchange_at_world_one)
         self.host_s = 0.0  # host seconds spent in the exchange's own Python + collective calls (exchange_gradients etc.)
         # chunks > 1 (split exchange, more than one rank): the per-gaussian backward runs in that many ranges of global
         # indices and the all-reduce of one range's twelve common columns is in flight while the next range is computed
-        # (GSPLAT_EXCHANGE_CHUNKS; default 1: one all-reduce behind the whole backward).  Same packed rows either way.
+        # (GSPLAT_EXCHANGE_CHUNKS; default 1: one all-reduce behind the whole backward).  Same rows either way.
         self.chunks = max(1, int(chunks if chunks is not None else os.environ.get("GSPLAT_EXCHANGE_CHUNKS", "1")))
-        if self.direct:
+        if self.direct or exchange != "split":
             self.chunks = 1  # the shards of the direct exchange cut across the ranges: one exchange behind the whole backward
         self.with_uv_norm = bool(with_uv_norm)
         tail = N if with_uv_norm else 0
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         self.uv_norm_sum = None
+        self._packed = None       # split: materialised on demand (property `packed`)
+        self._packed_fresh = False
+        self._grads = None        # compacted gradient arrays: only the packed payloads and the no-exchange step need them
         # the buffer that goes through the all-reduce is flat: rows first, then (training) the N uv norms
         if exchange == "full":
             self._reduce_buf = z(N * wc + tail)
-            self.packed = self._reduce_buf[:N * wc].view(N, wc)
-        else:
-            self.packed = torch.empty(N, wc, dtype=torch.float32, device=dev)
+            self._packed = self._reduce_buf[:N * wc].view(N, wc)
+        elif exchange == "factored":
+            self._packed = torch.empty(N, wc, dtype=torch.float32, device=dev)
         self.fw = raster.factored_gradient_width(self.world)
         self.factored = None
         if exchange == "factored":
@@ -355,19 +388,45 @@ class ViewShardedStep:
                 self._shards_in = z(shard * W).view(W, shard)   # what the peers sent: their copies of this rank's shard
                 self._shard_sum = z(shard)
             self.common = self._reduce_buf[:N * 12].view(N, 12)
-            self.rgb = z((N + 1) * 3).view(N + 1, 3)          # row N: campos
             self.rgb_all = z(self.world * (N + 1) * 3).view(self.world, N + 1, 3)
+            self.rgb = self.rgb_all[self.rank]                 # this rank's block, gathered IN PLACE; row N: campos
         if with_uv_norm:
             body = N * 12 if exchange == "split" else self._reduce_buf.numel() - N  # (split_direct pads behind the tail)
             self.uv_norm_sum = self._reduce_buf[body:body + N]
-        # capacity N: never reallocated
-        self.grads = self.ctx.alloc_gradients(N, l_max)
-        self.grads["precompute_rgb"] = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        if with_uv_norm:
-            self.grads["uv"] = torch.empty(N, 2, dtype=torch.float32, device=dev)
         self._campos_of = None  # the camera whose position is already in the exchange buffers
         self._blind = False     # this rank's view saw no gaussian in the current step
         self._chunk_reduces = None  # chunked step: the all-reduces of the common rows started during the backward
+
+    # ---- buffers that only some payloads need
+    @property
+    def grads(self):
+        """Compacted per-view gradient arrays (capacity N: never reallocated): what the `full` / `factored` payloads pack
+        from and what a step without an exchange (one rank) writes.  The split payload never touches them."""
+        if self._grads is None:
+            g = self.ctx.alloc_gradients(self.N, self.l_max)
+            g["precompute_rgb"] = torch.empty(self.N, 3, dtype=torch.float32, device=self.dev)
+            if self.with_uv_norm:
+                g["uv"] = torch.empty(self.N, 2, dtype=torch.float32, device=self.dev)
+            self._grads = g
+        return self._grads
+
+    @property
+    def packed(self):
+        """packed[N, 12 + 3 n]: the summed rows in the packed layout (packed_layout).  `full` / `factored` produce them
+        in every step; the split payload rebuilds them here, on demand, from common + rgb_all
+        (gsplat_unpack_gradients_split) -- the optimizer does not need them (AdamOptimizer.step_split)."""
+        if self.exchange == "split" and not self._packed_fresh:
+            self.materialize_packed()
+        return self._packed
+
+    def materialize_packed(self):
+        N = self.N
+        if self._packed is None:
+            self._packed = torch.empty(N, self.width_cols, dtype=torch.float32, device=self.dev)
+        self.raster.unpack_gradients_split(self.params["xyz"], self.common, self.rgb_all, 3 * (N + 1), self.l_max, N,
+                                           self.world, self._packed)
+        self._packed_fresh = True
+        return self._packed
 
     def describe_exchange(self):
         mb = lambda t: f"{t.numel() * 4 / 1e6:.0f} MB"
@@ -376,34 +435,29 @@ class ViewShardedStep:
                     f"{mb(self._shard_sum)} per rank (the all-reduce's two direct halves) + all-gather of {mb(self.rgb)} per rank")
         if self.exchange == "split":
             how = f" in {self.chunks} ranges behind the ranges of the per-gaussian backward" if self.chunks > 1 else ""
-            return f"split: all-reduce of {mb(self._reduce_buf)}{how} + all-gather of {mb(self.rgb)} per rank"
+            out = ("; packed[N, 12 + 3 n] rows materialised every step" if self.materialize else
+                   "; output = common[N,12] + rgb_all[W,N+1,3] (what gsplat_optimizer_step_sh_views consumes), written in "
+                   "global order by the backward kernels themselves: no pack / unpack pass")
+            return (f"split{'_packed' if self.materialize else ''}: all-reduce of {mb(self._reduce_buf)}{how} + in-place "
+                    f"all-gather of {mb(self.rgb)} per rank{out}")
         return f"{self.exchange}: one all-reduce of {mb(self._reduce_buf)}"
 
     def exchange_gradients(self, cam):
-        """Scatter this rank's compacted gradients to global order, sum over ranks, leave the result in self.packed
-        (and, with_uv_norm, self.uv_norm_sum)."""
+        """Sum this step's gradients over the ranks.  split: leaves common (and uv_norm_sum) reduced and rgb_all gathered;
+        full / factored: leaves the packed rows."""
         N = self.N
-        if self._blind:  # nothing in view on this rank: exact zeros, but every collective is still joined
-            self._reduce_buf.zero_()
-        elif self.with_uv_norm:
-            self.raster.pack_uv_grad_norm(self.ctx, self.grads, N, self.uv_norm_sum)
+        self._packed_fresh = False
         if self.exchange == "split":
-            gather = self._rgb_gather  # started by step() behind the per-gaussian backward, or None
+            gather = self._rgb_gather  # started by step() behind the compositing backward, or None (blind rank)
             self._rgb_gather = None
-            if self._blind:
-                if gather is None:
-                    self.rgb[:N].zero_()
-                    self._set_campos(cam)
-                    gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
+            if self._blind:  # nothing in view on this rank: exact zeros, but every collective is still joined
+                self._reduce_buf.zero_()
+                self.rgb[:N].zero_()
+                self._set_campos(cam)
+                gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
                 if self.chunks > 1:  # the other ranks reduce range by range: join every one of those collectives
                     self._chunk_reduces = [self.comm.all_reduce(self.common[lo:hi], async_op=True)
                                            for lo, hi in self.chunk_bounds() if hi > lo]
-            elif gather is None:
-                self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, self.rgb)
-                self._set_campos(cam)
-                gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
-            elif self._chunk_reduces is None:
-                self.raster.pack_gradients_split(self.ctx, self.grads, N, self.common, None)
             if self._chunk_reduces is not None:
                 # chunked step: the common rows are already on their way range by range; what is left is the tail
                 # (the |grad_uv| norms, which need every range's uv gradient)
@@ -415,10 +469,7 @@ class ViewShardedStep:
                 reduces = [self.comm.all_to_all_blocks(self._shards_in, self._reduce_buf.view(self.world, -1), async_op=True)]
             else:
                 reduces = [self.comm.all_reduce(self._reduce_buf, async_op=True)]
-            # the SH columns only need the gathered g_rgb: rebuild them while the all-reduce is in flight
             gather.wait()
-            self.raster.unpack_gradients_split(self.params["xyz"], None, self.rgb_all, 3 * (N + 1), self.l_max,
-                                               N, self.world, self.packed)
             for r in reduces:
                 r.wait()
             if self.direct:
@@ -426,8 +477,14 @@ class ViewShardedStep:
                 # so every replica receives the same bits), and gathers everybody's
                 torch.sum(self._shards_in, dim=0, out=self._shard_sum)
                 self.comm.all_gather_blocks(self._reduce_buf.view(self.world, -1), self._shard_sum)
-            self.raster.unpack_gradients_split(None, self.common, None, 0, self.l_max, N, self.world, self.packed)
-        elif self.exchange == "factored":
+            if self.materialize:
+                self.materialize_packed()
+            return None
+        if self._blind:
+            self._reduce_buf.zero_()
+        elif self.with_uv_norm:
+            self.raster.pack_uv_grad_norm(self.ctx, self.grads, N, self.uv_norm_sum)
+        if self.exchange == "factored":
             f = self.factored
             if not self._blind:
                 self.raster.pack_gradients_factored(self.ctx, self.grads, N, self.rank, self.world, f)
@@ -435,12 +492,12 @@ class ViewShardedStep:
             f[N, 12 + 3 * self.rank: 15 + 3 * self.rank] = self._campos_tensor(cam)
             self.comm.all_reduce(self._reduce_buf)
             self.raster.unpack_gradients_factored(self.params["xyz"], f[N, 12:], f, self.l_max, N,
-                                                  self.world, self.packed)
+                                                  self.world, self._packed)
         else:
             if not self._blind:
-                self.ctx.pack_gradients_global(self.grads, self.l_max, N, self.packed)
+                self.ctx.pack_gradients_global(self.grads, self.l_max, N, self._packed)
             self.comm.all_reduce(self._reduce_buf)
-        return self.packed
+        return self._packed
 
     def chunk_bounds(self):
         """Global-index ranges of the chunked exchange: the same on every rank (they depend on N only)."""
@@ -448,23 +505,21 @@ class ViewShardedStep:
         return [(N * k // K, N * (k + 1) // K) for k in range(K)]
 
     def backward_gaussians_chunked(self, cam):
-        """Per-gaussian backward range by range; behind each range its rows of `common` are packed and their all-reduce
-        is started, so that only the last range's exchange is exposed.  Every rank issues the same collectives in the
-        same order (a rank without gaussians in a range packs zeros)."""
-        N = self.N
+        """Per-gaussian backward range by range; each range writes its rows of `common` in place and their all-reduce
+        is started behind it, so that only the last range's exchange is exposed.  Every rank issues the same collectives
+        in the same order (the rows of gaussians a rank culled were zeroed by the compositing backward's pass)."""
         self._chunk_reduces = []
         for lo, hi in self.chunk_bounds():
             if hi == lo:
                 continue
-            self.ctx.backward_gaussians_range(self.params, cam, self.l_max, self.grads, lo, hi)
-            self.raster.pack_gradients_split_range(self.ctx, self.grads, N, lo, hi, self.common, None)
+            self.ctx.backward_gaussians_split(self.params, cam, self.l_max, self.common, self.uv_norm_sum, lo, hi)
             self._chunk_reduces.append(self.comm.all_reduce(self.common[lo:hi], async_op=True))
 
     def _campos_tensor(self, cam):
         dev_pos = cam.get("campos_dev")  # raster.device_camera uploads it once per view
         if dev_pos is not None:
             return dev_pos
-        return torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32, device=self.packed.device)
+        return torch.as_tensor([float(c) for c in cam["campos"]], dtype=torch.float32, device=self.dev)
 
     def _set_campos(self, cam):
         if self._campos_of is cam:  # same view as the last step (the benchmark): already in place
@@ -478,8 +533,8 @@ class ViewShardedStep:
         import time
         bg = self.bg if bg is None else bg
         exchanging = self.world > 1 or self.always_exchange
-        overlap = exchanging and self.exchange == "split"
-        if overlap:
+        split = exchanging and self.exchange == "split"
+        if split:
             self._set_campos(cam)  # device-to-device (or cached): issued before the GPU has work queued
         self._blind = False
         try:
@@ -491,16 +546,17 @@ class ViewShardedStep:
         if not self._blind:
             if grad_fn is not None:
                 grad_image = grad_fn(fwd)
-            if overlap:
-                # g_rgb is final after the compositing backward: its all-gather runs behind the per-gaussian backward
-                self.ctx.backward_render(grad_image, bg, self.rgb)
+            if split:
+                # g_rgb is final after the compositing backward: it lands in this rank's block of rgb_all and its
+                # all-gather runs behind the per-gaussian backward; the same pass clears the common rows of culled gaussians
+                self.ctx.backward_render(grad_image, bg, self.rgb, self.common, self.uv_norm_sum)
                 t0 = time.perf_counter()
                 self._rgb_gather = self.comm.all_gather_blocks(self.rgb_all, self.rgb, async_op=True)
                 self.host_s += time.perf_counter() - t0
                 if self.chunks > 1:
                     self.backward_gaussians_chunked(cam)
                 else:
-                    self.ctx.backward_gaussians(self.params, cam, self.l_max, self.grads)
+                    self.ctx.backward_gaussians_split(self.params, cam, self.l_max, self.common, self.uv_norm_sum)
             else:
                 self.ctx.backward_pass(self.params, cam, grad_image, bg, self.l_max, self.grads)
         if exchanging:

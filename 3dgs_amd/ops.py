@@ -225,7 +225,9 @@ def compact_masked_array(stride, d_source, d_mask, num_culled=None):
     N = int(d_mask.numel())
     if num_culled is not None:
         out = torch.empty(max(int(num_culled) * stride, 1), dtype=torch.float32, device=d_mask.device if N else "cuda")
-        check(_lib.load().gsplat_compact_masked_array(_p(d_source), _p(d_mask), N, stride, _p(out), None, _stream()))
+        # the room of `out` is stated: a count that is too small drops rows, it does not write past the tensor (r05)
+        check(_lib.load().gsplat_compact_masked_array_bounded(_p(d_source), _p(d_mask), N, stride, _p(out), int(num_culled),
+                                                              None, _stream()))
         return out[: int(num_culled) * stride]
     out = torch.empty(max(N * stride, 1), dtype=torch.float32, device=d_mask.device if N else "cuda")
     n = ctypes.c_int(0)

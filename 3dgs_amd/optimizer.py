@@ -109,3 +109,34 @@ class AdamOptimizer:
             packed.data_ptr(), packed.shape[0], self.width, arr, len(self.names), B1, B2, EPS, b1c, b2c,
             uv_norm_sum.data_ptr() if stats else None, self.uv_grad_accum.data_ptr() if stats else None,
             self.grad_accum_dur.data_ptr() if stats else None, _stream()))
+
+    def step_split(self, it, common, rgb_all, uv_norm_sum=None):
+        """The W-view step on what the split exchange delivers (ViewShardedStep, exchange="split"): common[N,12] = the
+        all-reduced direction-independent columns {xyz 3, opacity, scale 3, quaternion 4, views that saw the gaussian},
+        rgb_all[W, N+1, 3] = every view's g_rgb in global order + its camera position.  The colour groups are rebuilt
+        and applied by gsplat_optimizer_step_sh_views (first: the directions come from xyz), the other four groups by the
+        packed kernel on common itself.  Bit-identical to step_packed on the materialised rows."""
+        assert common.is_contiguous() and common.shape[1] == 12 and rgb_all.is_contiguous()
+        N, W = int(common.shape[0]), int(rgb_all.shape[0])
+        assert rgb_all.shape[1] == N + 1 and N == int(self.params["xyz"].shape[0])
+        b1c, b2c = self.bias_corrections(it)
+        lrs = self.learning_rates(it)
+        has_sh = self.l_max > 0
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        check(_lib.load().gsplat_optimizer_step_sh_views(
+            int(self.l_max), N, W, self.params["xyz"].data_ptr(), rgb_all.data_ptr(), 3 * (N + 1), common.data_ptr(),
+            self.params["rgb"].data_ptr(), self.exp_avg["rgb"].data_ptr(), self.exp_avg_sq["rgb"].data_ptr(), lrs["rgb"],
+            ptr(self.params["sh"] if has_sh else None), ptr(self.exp_avg.get("sh")), ptr(self.exp_avg_sq.get("sh")),
+            lrs["sh"], B1, B2, EPS, b1c, b2c, _stream()))
+        names = ("xyz", "opacity", "scale", "quaternion")
+        col = dict(xyz=0, opacity=3, scale=4, quaternion=7)  # columns of common (gsplat_hip.h)
+        arr = (_lib.AdamGroup * len(names))()
+        for k, g in enumerate(names):
+            arr[k].param, arr[k].exp_avg, arr[k].exp_avg_sq = (self.params[g].data_ptr(), self.exp_avg[g].data_ptr(),
+                                                               self.exp_avg_sq[g].data_ptr())
+            arr[k].grad, arr[k].stride, arr[k].packed_column, arr[k].lr = None, self.cols[g][1] - self.cols[g][0], col[g], lrs[g]
+        stats = uv_norm_sum is not None
+        check(_lib.load().gsplat_optimizer_step_packed(
+            common.data_ptr(), N, 12, arr, len(names), B1, B2, EPS, b1c, b2c,
+            uv_norm_sum.data_ptr() if stats else None, self.uv_grad_accum.data_ptr() if stats else None,
+            self.grad_accum_dur.data_ptr() if stats else None, _stream()))

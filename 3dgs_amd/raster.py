@@ -244,10 +244,22 @@ class RasterContext:
                                              float(bg_color), int(l_max), ctypes.byref(gs), st))
         return grads
 
-    def backward_render(self, grad_image, bg_color, rgb_global=None):
-        """First half of backward_pass: compositing backward; optionally this view's g_rgb in global order [N,3]."""
+    def backward_render(self, grad_image, bg_color, rgb_global=None, common=None, uv_norm=None):
+        """First half of backward_pass: compositing backward; optionally this view's g_rgb in global order [N,3].
+        common [N,12] (and uv_norm [N]): the split exchange's rows -- the rows of the gaussians this view culled are
+        cleared here, the others are written by backward_gaussians_split (gsplat_backward_render_split)."""
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self._lib.gsplat_backward_render(self._h, _ptr(grad_image), float(bg_color), _ptr(rgb_global), st))
+        check(self._lib.gsplat_backward_render_split(self._h, _ptr(grad_image), float(bg_color), _ptr(rgb_global),
+                                                     _ptr(common), _ptr(uv_norm), st))
+
+    def backward_gaussians_split(self, params, cam, l_max, common, uv_norm=None, first=0, end=None):
+        """Second half of backward_pass for a view-sharded step: the twelve direction-independent gradient columns go
+        straight into common[N,12] at the gaussians' global indices (|grad_uv| into uv_norm[N]); no compacted gradient
+        array is written, the colour gradients are rebuilt by the optimizer from the gathered g_rgb."""
+        g, c = self._structs(params, cam, l_max)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.gsplat_backward_gaussians_split(self._h, ctypes.byref(g), ctypes.byref(c), int(l_max), _ptr(common),
+                                                        _ptr(uv_norm), int(first), int(g.num_gaussians if end is None else end), st))
 
     def backward_gaussians(self, params, cam, l_max, grads):
         """Second half of backward_pass: the per-gaussian operator chain."""

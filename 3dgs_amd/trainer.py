@@ -152,8 +152,9 @@ class Trainer:
         return loss
 
     def _train_step_sharded(self, cam, gt_image, want_loss):
-        """One iteration of a W-rank group: this rank's view -> loss -> backward -> exchange -> the same packed
-        optimizer step on every rank (gsplat_optimizer_step_packed incl. the densification statistics)."""
+        """One iteration of a W-rank group: this rank's view -> loss -> backward -> exchange -> the same optimizer step on
+        every rank, incl. the densification statistics (split exchange: AdamOptimizer.step_split on common + rgb_all;
+        the other payloads: gsplat_optimizer_step_packed on the packed rows)."""
         c, it = self.cfg, self.iter
         bg = (it % 255) / 255.0 if c["use_background"] else 0.0
         if it % c["add_sh_band_interval"] == 0 and it >= c["add_sh_band_interval"]:
@@ -175,7 +176,12 @@ class Trainer:
             return g
 
         step.step(cam, grad_fn=grad_fn, bg=bg)
-        self.opt.step_packed(it, step.packed, step.uv_norm_sum)
+        if step.exchange == "split" and not step.materialize:
+            # the exchange's own factored form feeds the optimizer: the colour groups rebuild sum_r g_rgb^r x Y_k(dir^r)
+            # inside their Adam (gsplat_optimizer_step_sh_views), no packed[N, 12 + 3 n] rows are written or read
+            self.opt.step_split(it, step.common, step.rgb_all, step.uv_norm_sum)
+        else:
+            self.opt.step_packed(it, step.packed, step.uv_norm_sum)
         self.iter += 1
         return out.get("loss")
 

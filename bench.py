@@ -49,9 +49,11 @@ def launch_ranks(args):
     """Parent of a multi-GPU run: never imports torch, never touches a GPU.  Builds the library ONCE (the children load
     it with GSPLAT_NO_BUILD=1: N ranks running `make` in one directory at the same time could dlopen a half-linked
     file), starts one child per rank with the torch.distributed environment, forwards rank 0's JSON line.  All children
-    are polled under ONE overall deadline (GSPLAT_BENCH_DEADLINE_S, default 1500 s); the first child that exits
-    non-zero, or the deadline, ends the run: the remaining children are killed (these exact processes) and the launcher
-    returns 1, so that a rank stuck in a collective its peers never joined cannot hold the GPUs."""
+    are polled under ONE overall deadline (GSPLAT_BENCH_DEADLINE_S, default 540 s: below the 600 s the driver allows a
+    run); the first child that exits non-zero, or the deadline, ends the run: the remaining children are killed (these
+    exact processes), so that a rank stuck in a collective its peers never joined cannot hold the GPUs.  The exit code
+    follows the HEADLINE: once rank 0 has printed its line with n_gpus == N (it does so only after the timed region of
+    all ranks, and whatever the optional payload sweep behind it does -- see HeadlineGuard) the run is a success."""
     import tempfile
     n = args.gpus
     importlib.import_module("3dgs_amd._lib").build()  # make only: no torch, no GPU in this process
@@ -65,7 +67,7 @@ def launch_ranks(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_NO_BUILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else None, text=True))
-    deadline = time.time() + float(os.environ.get("GSPLAT_BENCH_DEADLINE_S", "1500"))
+    deadline = time.time() + float(os.environ.get("GSPLAT_BENCH_DEADLINE_S", "540"))
     codes = [None] * n
     failed = None
     while any(c is None for c in codes):
@@ -90,22 +92,77 @@ def launch_ranks(args):
     out0.close()
     sys.stdout.write(text)
     sys.stdout.flush()
-    if failed or any(c != 0 for c in codes):
-        print(f"bench.py: {failed or 'a rank failed'}; rank exit codes {codes}", file=sys.stderr)
-        return 1
     line = [ln for ln in text.splitlines() if ln.startswith("{")]
-    if not line or json.loads(line[-1]).get("n_gpus") != n:
+    have_headline = False
+    try:
+        have_headline = bool(line) and json.loads(line[-1]).get("n_gpus") == n
+    except ValueError:
+        have_headline = False
+    if failed or any(c != 0 for c in codes):
+        print(f"bench.py: {failed or 'a rank failed'}; rank exit codes {codes}"
+              + ("; the headline line had already been printed" if have_headline else ""), file=sys.stderr)
+        return 0 if have_headline else 1
+    if not have_headline:
         print(f"bench.py: rank 0 did not report n_gpus={n}", file=sys.stderr)
         return 1
     return 0
 
 
+class SweepAbort(RuntimeError):
+    """The optional payload sweep cannot go on (a payload failed on some ranks only, or a peer went silent): the ranks'
+    collectives no longer pair up.  The headline is unaffected -- it was measured, on a communicator of its own, before."""
+
+
+class HeadlineGuard:
+    """The ONE JSON line of rank 0, printed exactly once whatever the optional legs behind the timed region do.
+    arm(): from now on a timer owns the line -- if finish() has not been called within `deadline_s`, the timer thread
+    prints the line as it stands (plus `on_timeout`) and ends the process with exit code 0 via os._exit (the main thread
+    may be stuck inside a collective that will never complete; a clean teardown of the process groups could hang too).
+    Ranks other than the reporter arm the same timer with line=None: they only leave.  finish(extra) cancels the timer
+    and prints the line with `extra` merged in."""
+
+    def __init__(self, line, deadline_s, on_timeout=None, out=None):
+        import threading
+        self.line, self.deadline_s, self.on_timeout = line, float(deadline_s), dict(on_timeout or {})
+        self.out = out if out is not None else sys.stdout
+        self._lock, self._printed, self._timer = threading.Lock(), False, None
+
+    def _emit(self, extra):
+        with self._lock:
+            if self._printed:
+                return False
+            self._printed = True
+        if self.line is not None:
+            self.out.write(json.dumps({**self.line, **extra}) + "\n")
+            self.out.flush()
+        return True
+
+    def arm(self):
+        import threading
+
+        def fire():
+            if self._emit(self.on_timeout):
+                sys.stderr.write(f"bench.py: the optional legs behind the timed region did not finish within "
+                                 f"{self.deadline_s:.0f} s; headline kept, leaving\n")
+                sys.stderr.flush()
+                os._exit(0)
+        self._timer = threading.Timer(self.deadline_s, fire)
+        self._timer.daemon = True
+        self._timer.start()
+        return self
+
+    def finish(self, extra=None):
+        if self._timer is not None:
+            self._timer.cancel()
+        return self._emit(extra or {})
+
+
 def agree_on_payload(comm, mode, ok, timeout_s=120.0):
     """Every rank reports through the group's key-value store (NOT a collective) whether payload `mode` worked for it,
     and reads all reports.  True: worked everywhere; False: failed everywhere (the mode is dropped on every rank).
-    A mixed outcome, or a rank that never reports because it is still inside a collective the failing rank left, is
-    fatal: after an asymmetric failure the ranks' collectives no longer pair up, so the run exits non-zero (the
-    launcher / torchrun then ends the other ranks) instead of limping on with mismatched collectives."""
+    A mixed outcome, or a rank that never reports because it is still inside a collective the failing rank left, ends
+    the SWEEP (SweepAbort): after an asymmetric failure the ranks' collectives no longer pair up.  The headline has been
+    measured by then and is printed regardless (HeadlineGuard)."""
     rank, world = comm.rank, comm.world
     if comm.backend() == "threads":  # in-process ranks: a shared table; a rank that died has broken the barrier
         votes = comm.group.shared
@@ -114,7 +171,7 @@ def agree_on_payload(comm, mode, ok, timeout_s=120.0):
         got = [votes[("exchange", mode, r)] for r in range(world)]
         if all(got) or not any(got):
             return all(got)
-        raise RuntimeError(f"payload '{mode}' failed on some ranks only: {got}")
+        raise SweepAbort(f"payload '{mode}' failed on some ranks only: {got}")
     from datetime import timedelta
     from torch.distributed.distributed_c10d import _get_default_store
     store = _get_default_store()
@@ -123,19 +180,56 @@ def agree_on_payload(comm, mode, ok, timeout_s=120.0):
     try:
         store.wait(keys, timedelta(seconds=timeout_s))
     except Exception as e:  # noqa: BLE001 -- a peer never reported
-        print(f"bench.py: rank {rank}: payload '{mode}': a peer did not report within {timeout_s:.0f} s ({e}); "
-              "asymmetric failure, giving up", file=sys.stderr, flush=True)
-        os._exit(3)
+        raise SweepAbort(f"payload '{mode}': a peer did not report within {timeout_s:.0f} s ({type(e).__name__})")
     votes = [store.get(k).decode() for k in keys]
     if all(v == "ok" for v in votes):
         return True
     if all(v == "fail" for v in votes):
         return False
-    print(f"bench.py: rank {rank}: payload '{mode}' failed on some ranks only ({votes}); giving up", file=sys.stderr, flush=True)
-    os._exit(3)
+    raise SweepAbort(f"payload '{mode}' failed on some ranks only ({votes})")
+
+
+# split_packed = the split payload + the packed[N, 12 + 3 n] rows materialised (what r04's default step produced)
+SWEEP_MODES = ("split", "split_packed", "split_chunks4", "split_direct", "factored", "full")
+
+
+def sweep_payloads(comm, modes, time_mode, torch, dev, vote_timeout_s=30.0):
+    """The measured comparison of the exchange payloads: time_mode(mode) -> ms per step on this rank, or raises.  A
+    payload that fails on EVERY rank is reported and left out (a decision of all ranks through the store, no collective);
+    one that fails on some ranks only raises SweepAbort (agree_on_payload).  Returns {mode: ms, MAX over the ranks}."""
+    out = {}
+    for mode in modes:
+        ms_local, err = None, None
+        try:
+            ms_local = time_mode(mode)
+        except SweepAbort:
+            raise
+        except Exception as e:  # noqa: BLE001 -- whatever the backend raises
+            err = f"{type(e).__name__}: {e}"[:200]
+            print(f"bench.py: exchange payload '{mode}' failed on rank {comm.rank}: {err}", file=sys.stderr, flush=True)
+        if agree_on_payload(comm, mode, err is None, timeout_s=vote_timeout_s):
+            t = torch.tensor([ms_local], dtype=torch.float64, device=dev)
+            comm.all_reduce_max(t)
+            out[mode] = round(float(t.item()), 4)
+        else:
+            out[mode] = "failed: " + err
+        if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+            torch.cuda.empty_cache()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ helpers
+def spawning_legs_allowed():
+    """The reference_host_path and exchange_host_cost legs start child processes (and, for the former, possibly hipcc)
+    from a process whose GPU is initialised.  Under rocprofv3 the children would run under the profiler's preload too --
+    and on this pool a profiled process that replaces or forks programs is exactly what must not happen -- so both legs
+    default OFF when a profiler preload is visible in the environment; GSPLAT_BENCH_REFERENCE_HOST=1 /
+    GSPLAT_BENCH_EXCHANGE_HOST_COST=1 force them on."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    profiled = "rocprof" in pre.lower() or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ)
+    return not profiled
+
+
 def tile_max_sum(torch, n, W, H):
     """S_eff = sum over tiles of max_px(splats_per_pixel): list entries any pixel of the tile needs."""
     ntx, nty = (W + 15) // 16, (H + 15) // 16
@@ -352,9 +446,16 @@ def main():
     if world > 1 and comm.backend() == "nccl" and ndev < world:
         raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {ndev} "
                          f"(GSPLAT_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
-    run_rank(args, comm, local_rank % ndev if world > 1 else 0)
     if world > 1:
-        comm.barrier()
+        comm = gdist.TorchComm.own_group()  # the headline's own communicator (closed before the payload sweep)
+    status = run_rank(args, comm, local_rank % ndev if world > 1 else 0)
+    if world > 1:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if status != "clean":
+            os._exit(0)  # the sweep broke the ranks' pairing: no collective teardown; the headline line is out
+        HeadlineGuard(None, 20).arm()  # a teardown that hangs must not turn a finished run into a failure
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
@@ -380,53 +481,25 @@ def run_rank(args, comm, device_index):
     gc.collect()
     gc.disable()  # a generation-2 collection in the middle of a timed loop costs tens of milliseconds
 
-    # ---- exchange payload (multi-GPU): GSPLAT_EXCHANGE = full | factored | split | auto.  "auto" (default) times each
-    # payload for a few steps before the warm-up and keeps the fastest on this node's links; all three end in
-    # the same packed rows (tests/test_dist_gpu.py), "full" is the north star's single all-reduce of whole rows.
-    want = os.environ.get("GSPLAT_EXCHANGE", "auto" if world > 1 else "split")
-    exchange_ms = {}
+    # ---- exchange payload of the HEADLINE (multi-GPU): GSPLAT_EXCHANGE = split (default) | full | factored | split_direct |
+    # split_chunks4.  The default is the conservative one -- two standard collectives, an all-gather and an all-reduce -- and
+    # nothing but the headline touches a collective before the line is safe: the measured comparison of all payloads (r02-r04
+    # ran it BEFORE the warm-up, where a hang in a payload that had never met real RCCL would have lost the number) now
+    # runs behind the timed region, on a communicator of its own, under HeadlineGuard.
+    want = os.environ.get("GSPLAT_EXCHANGE", "split")
+    want = "split" if want == "auto" else want
     ctx = raster.RasterContext(N, W, H)
     # What the timed forward materialises.  Since r04 the headline stores EVERY ForwardPassData array, as the reference's
     # rasterize_image does (2 % slower than the lean forward, which a host of the fused backward would use: that one is
     # measured beside it, ms_per_step_lean_forward).  GSPLAT_BENCH_LEAN=1 swaps the two.
     lean_headline = os.environ.get("GSPLAT_BENCH_LEAN", "0") == "1"
     ctx.set_lean_forward(lean_headline)
-    if world > 1 and do_bwd and want == "auto":
-        errors = {}
-        for mode in ("full", "factored", "split", "split_chunks4", "split_direct"):
-            ms_local, err = None, None
-            try:  # a payload whose collectives this node's backend rejects is reported and left out, not fatal
-                st = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode.replace("_chunks4", ""), ctx=ctx,
-                                           comm=comm, chunks=4 if mode.endswith("chunks4") else 1)
-                for _ in range(3):
-                    st.step(dc, dgi)
-                torch.cuda.synchronize()
-                comm.barrier()
-                ta = time.perf_counter()
-                for _ in range(10):
-                    st.step(dc, dgi)
-                torch.cuda.synchronize()
-                comm.barrier()
-                ms_local = (time.perf_counter() - ta) / 10 * 1e3
-            except Exception as e:  # noqa: BLE001 -- whatever the backend raises
-                err = f"{type(e).__name__}: {e}"[:200]
-                print(f"bench.py: exchange payload '{mode}' failed on rank {rank}: {err}", file=sys.stderr, flush=True)
-            st = None
-            # dropping a payload is a decision of ALL ranks (store votes, no collective): see agree_on_payload
-            if agree_on_payload(comm, mode, err is None):
-                t = torch.tensor([ms_local], dtype=torch.float64, device=dev)
-                comm.all_reduce_max(t)
-                exchange_ms[mode] = round(float(t.item()), 4)
-            else:
-                errors[mode] = err
-            torch.cuda.empty_cache()
-        if not exchange_ms:
-            raise RuntimeError(f"no exchange payload works on this node: {errors}")
-        want = min(exchange_ms, key=exchange_ms.get)  # the same on every rank: the times were MAX-reduced
-        exchange_ms.update({m: "failed: " + msg for m, msg in errors.items()})
-    want = want if want != "auto" else "split"
-    step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=want.replace("_chunks4", ""), ctx=ctx, comm=comm,
-                                 chunks=4 if want.endswith("chunks4") else None)
+
+    def make_step(mode, on_comm):
+        return gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], exchange=mode.replace("_chunks4", ""), ctx=ctx, comm=on_comm,
+                                     chunks=4 if mode.endswith("chunks4") else None)
+
+    step = make_step(want, comm)
 
     def one_step():
         if do_bwd:
@@ -511,12 +584,57 @@ def run_rank(args, comm, device_index):
     dom_ms = step.ctx.get_timing()[dom][0]
     step.ctx.set_timing(False)
 
+    # ---- the headline is measured.  Multi-GPU: its communicator is closed here; the optional comparison of the other
+    # payloads runs further down on a communicator of its own (rank 0 first prepares the line the guard keeps safe).
+    sweep_on = world > 1 and do_bwd and os.environ.get("GSPLAT_BENCH_SWEEP", "1") != "0"
+    sweep_deadline = float(os.environ.get("GSPLAT_BENCH_SWEEP_DEADLINE_S", "150"))
+    selftest = os.environ.get("GSPLAT_BENCH_SELFTEST", "")
+
+    def time_mode(mode, on_comm):
+        """ms per step of payload `mode` on this rank (10 steps after 3), or raises what the backend raised."""
+        what = selftest.split(":")
+        if what[0] == "raise" and what[1] == mode and (len(what) < 3 or int(what[2]) == rank):
+            raise RuntimeError(f"selftest: payload '{mode}' raises on rank {rank}")
+        if what[0] == "hangsweep":
+            time.sleep(3600)
+        st = make_step(mode, on_comm)
+        for _ in range(3):
+            st.step(dc, dgi)
+        torch.cuda.synchronize()
+        on_comm.barrier()
+        ta = time.perf_counter()
+        for _ in range(10):
+            st.step(dc, dgi)
+        torch.cuda.synchronize()
+        on_comm.barrier()
+        return (time.perf_counter() - ta) / 10 * 1e3
+
+    def run_sweep():
+        """Every payload timed on a fresh communicator; {mode: ms (MAX over ranks) | "failed: ..."}.  Raises SweepAbort /
+        whatever a broken backend raises: the caller keeps the headline either way."""
+        scomm = comm if backend == "threads" else gdist.TorchComm.own_group()
+        res = sweep_payloads(scomm, SWEEP_MODES, lambda m: time_mode(m, scomm), torch, dev)
+        if scomm is not comm:
+            scomm.close()
+        return res
+
+    if world > 1 and backend != "threads" and hasattr(comm, "close"):
+        comm.barrier()
+        comm.close()  # the headline's own communicator: gone before anything optional runs
     if rank != 0:
+        status = "clean"
+        if sweep_on:
+            guard = HeadlineGuard(None, sweep_deadline).arm() if backend != "threads" else None
+            try:
+                run_sweep()
+            except BaseException as e:  # noqa: BLE001 -- SweepAbort, RCCL errors, a broken barrier of rank threads
+                print(f"bench.py: rank {rank}: payload sweep ended: {type(e).__name__}: {e}"[:300], file=sys.stderr, flush=True)
+                status = "aborted"
+            if guard is not None:
+                guard.finish()
         if backend != "threads":
             gc.enable()
-        return
-    if backend == "threads":
-        comm = None  # rank 0 reports alone; the other rank threads have left
+        return status
 
     # ---- roofline of the dominant kernel (compositing backward): HBM on algorithmic bytes, and the bound the kernel
     # actually runs against, VALU issue (wave-level VALU instructions per launch from the SQ_INSTS_VALU pass kept in
@@ -709,14 +827,15 @@ def run_rank(args, comm, device_index):
                    "what": "host-clock intervals between consecutive steps of the timed region (each forward waits for "
                            "its count record, so an interval is one step of GPU time)"} if iv else None)
     ref_host = None
-    if world == 1 and do_bwd and os.environ.get("GSPLAT_BENCH_REFERENCE_HOST", "1") != "0":
+    legs_default = "1" if spawning_legs_allowed() else "0"
+    if world == 1 and do_bwd and os.environ.get("GSPLAT_BENCH_REFERENCE_HOST", legs_default) != "0":
         try:
             ref_host = reference_host_path(params, cam, gi, cfg, L)
         except Exception as e:  # never lose the headline line to a side measurement
             ref_host = {"error": repr(e)[:300]}
     # the exchange's HOST cost through the real backend, one rank (a child: it needs a process group of its own)
     host_cost = None
-    if world == 1 and do_bwd and args.workload == "config3" and os.environ.get("GSPLAT_BENCH_EXCHANGE_HOST_COST", "1") != "0":
+    if world == 1 and do_bwd and args.workload == "config3" and os.environ.get("GSPLAT_BENCH_EXCHANGE_HOST_COST", legs_default) != "0":
         try:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
@@ -750,7 +869,9 @@ def run_rank(args, comm, device_index):
                                        "(cuda/raster.cu:12-136); the step of a host of the fused backward, which needs "
                                        "none of Sigma / J / conic / SH colour: ms_per_step_lean_forward"),
                    "M": M, "S": S, "S_eff": S_eff, "num_pairs": num_pairs, "scene_seed": scene.SEED},
-        "exchange_ms_per_step": exchange_ms or None,
+        # (multi-GPU: filled in by the payload sweep BEHIND the timed region -- every payload's ms per step, MAX over the
+        # ranks, measured on a communicator of its own; the headline ran config.exchange)
+        "exchange_ms_per_step": None,
         # tools/nccl_one_rank.py: every payload through RCCL with ONE rank (collectives = copies): ms per step with the
         # exchange, and the microseconds of it the host spends in the exchange's Python + torch.distributed calls
         "exchange_host_cost_one_rank": host_cost,
@@ -785,7 +906,22 @@ def run_rank(args, comm, device_index):
         "cpu_baseline": cpu,
         "setup_s": round(gen_s, 1),
     }
-    print(json.dumps(line), flush=True)
+    # ---- ONE line, printed exactly once.  Multi-GPU: first the optional payload sweep, under a guard that prints the
+    # line as it stands and leaves with exit code 0 if the sweep hangs; a sweep that fails is reported inside the line.
+    status = "clean"
+    if not sweep_on:
+        HeadlineGuard(line, 0).finish()
+        return status
+    guard = HeadlineGuard(line, sweep_deadline,
+                          on_timeout={"exchange_ms_per_step": {"status": f"sweep did not finish within {sweep_deadline:.0f} s"}})
+    guard.arm()
+    try:
+        sweep = run_sweep()
+    except BaseException as e:  # noqa: BLE001
+        sweep = {"status": f"sweep ended: {type(e).__name__}: {e}"[:300]}
+        status = "aborted"
+    guard.finish({"exchange_ms_per_step": sweep})
+    return status
 
 
 if __name__ == "__main__":

@@ -197,10 +197,11 @@ gsplat_shim::device_array<typename Source::value_type> compact_masked_array(cons
   gsplat_shim::device_array<T> d_selected;
   gsplat_shim::alloc_or_exit("compact_masked_array", [&] { d_selected.resize((size_t)num_culled * STRIDE); });
   gsplat_shim::require_ok(
-      gsplat_compact_masked_array(reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_source.data())),
-                                  reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data())),
-                                  (int)d_mask.size(), STRIDE,
-                                  reinterpret_cast<float *>(thrust::raw_pointer_cast(d_selected.data())), nullptr, 0),
+      gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_source.data())),
+                                          reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data())),
+                                          (int)d_mask.size(), STRIDE,
+                                          reinterpret_cast<float *>(thrust::raw_pointer_cast(d_selected.data())), num_culled,
+                                          nullptr, 0),
       "compact_masked_array");
   return d_selected;
 }

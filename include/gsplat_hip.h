@@ -52,7 +52,7 @@ extern "C" {
 const char *gsplat_last_error(void);
 /* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
  * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
-#define GSPLAT_ABI_VERSION 5
+#define GSPLAT_ABI_VERSION 6
 int gsplat_abi_version(void);
 /* What the loaded binary was built from: sha256 (first 16 hex digits) over the kernel sources (3dgs_amd/csrc: Makefile,
  * *.h, *.hip) at link time, and the extra compiler flags of a diagnostic build ("" for the product build).  A loader
@@ -220,6 +220,23 @@ int gsplat_optimizer_step_sh_factored(const int *compact_to_global, int num_cull
                                       float bias2, const float *xyz, float cam_x, float cam_y, float cam_z,
                                       const float *grad_precompute_rgb, void *stream);
 
+/* r05 -- the colour groups of a W-view step without their gradient arrays: the band-0 group (rgb[N,3]) and the SH group
+ * (sh[N,(l_max+1)^2-1,3]) are updated in place from what the split exchange delivers -- rgb_all = W blocks of
+ * `rank_stride` floats, block r = rank r's g_rgb[N,3] in global order followed by its camera position[3] -- as
+ * grad[k][c] = sum over the views r (in rank order) of g_rgb^r[c] * Y_k(direction from camera r to the gaussian): the
+ * sums gsplat_unpack_gradients_split writes into the packed rows, formed in the same order with the same operations, so
+ * parameters and moments are bit-identical to gsplat_unpack_gradients_split + gsplat_optimizer_step_packed -- without
+ * writing and re-reading packed[N, 12 + 3 n] (240 B per gaussian at SH degree 3, each way).  A row is updated when
+ * common[i*12 + 11], the number of views that saw the gaussian, is positive (the reference's per-view masks,
+ * cuda/trainer.cu:1028-1085).  Must run BEFORE the xyz group moves (the directions are rebuilt from xyz).  The other
+ * four groups: gsplat_optimizer_step_packed on common[N,12] itself (width 12, columns xyz 0, opacity 3, scale 4,
+ * quaternion 7).  sh may be NULL at l_max == 0. */
+int gsplat_optimizer_step_sh_views(int l_max, int num_gaussians, int world_size, const float *xyz, const float *rgb_all,
+                                   size_t rank_stride, const float *common, float *rgb, float *rgb_exp_avg,
+                                   float *rgb_exp_avg_sq, float lr_rgb, float *sh, float *sh_exp_avg,
+                                   float *sh_exp_avg_sq, float lr_sh, float b1, float b2, float eps, float bias1,
+                                   float bias2, void *stream);
+
 /* Multi-view variant: gradients are rows of the all-reduced packed layout
  * (gsplat_pack_gradients_global / gsplat_unpack_gradients_factored, row width `width`, last column = number of
  * views that saw the gaussian); rows with a zero count are skipped, which is the union of the per-view masks.
@@ -287,6 +304,11 @@ int gsplat_gather_rows(int N, int stride, const int *order, const float *in, flo
  * NULL: no read-back, the call stays asynchronous. */
 int gsplat_compact_masked_array(const float *src, const unsigned char *mask, int N, int stride, float *dst,
                                 int *num_selected, void *stream);
+/* The same with the room of dst stated (r05): rows whose compacted slot is >= dst_rows are NOT written.  The reference's
+ * template trusts its caller's num_culled (cuda_data.cuh:106-127) and so do the callers here (no count read-back), but a
+ * count that is too small then drops rows instead of overwriting whatever follows dst. */
+int gsplat_compact_masked_array_bounded(const float *src, const unsigned char *mask, int N, int stride, float *dst,
+                                        int dst_rows, int *num_selected, void *stream);
 
 /* replaces scatter_masked_array<STRIDE>  (cuda_data.cuh:150-167): dst[i] <- src[rank(i)] where mask[i] */
 int gsplat_scatter_masked_array(const float *src, const unsigned char *mask, int N, int stride, float *dst,
@@ -379,6 +401,24 @@ int gsplat_backward_gaussians(gsplat_context *ctx, const gsplat_gaussians *gauss
  * the union of the chunks is exactly gsplat_backward_gaussians. */
 int gsplat_backward_gaussians_range(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
                                     int l_max, const gsplat_gradients *out, int first_gaussian, int end_gaussian,
+                                    void *stream);
+
+/* r05 -- the view-sharded step without compacted gradient arrays and without a pack pass (3dgs_amd/dist.py, exchange
+ * "split").  What the exchange sums per gaussian is common[N,12] = {grad_xyz 3, grad_opacity, grad_scale 3,
+ * grad_quaternion 4, 1.0 if this view saw the gaussian} in GLOBAL gaussian order, plus (training) uv_norm[N] =
+ * |grad_uv|; what it gathers is this view's g_rgb[N,3].
+ *   gsplat_backward_render_split  = gsplat_backward_render that, in the pass that scatters g_rgb to rgb_global, also
+ *                                   clears the rows of `common` / `uv_norm` of the gaussians this view culled;
+ *   gsplat_backward_gaussians_split = the per-gaussian operator chain (cuda/trainer.cu:979-1012) whose twelve leaf
+ *                                   values go straight into common[compact_to_global[j]] (and |grad_uv| into uv_norm);
+ *                                   the SH and band-0 gradients are not stored at all: gsplat_optimizer_step_sh_views
+ *                                   rebuilds them from the gathered g_rgb.  [first, end): a range of global indices as in
+ *                                   gsplat_backward_gaussians_range.
+ * Values are bit-identical to gsplat_backward_gaussians + gsplat_pack_gradients_split (+ gsplat_pack_uv_grad_norm). */
+int gsplat_backward_render_split(gsplat_context *ctx, const float *grad_image, float bg_color, float *rgb_global,
+                                 float *common, float *uv_norm, void *stream);
+int gsplat_backward_gaussians_split(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
+                                    int l_max, float *common, float *uv_norm, int first_gaussian, int end_gaussian,
                                     void *stream);
 
 /* Binning route of the fused forward.  0 (default): automatic -- the LDS counting sort + per-tile depth sort, or, when

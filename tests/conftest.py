@@ -59,15 +59,26 @@ def config3_case(scene, orc):
 PIXEL_L1_TOL = 1e-4      # north_star: rendered pixels within 1e-4 per-pixel L1
 GRAD_REL_TOL = 1e-3      # north_star: gradients within 1e-3 relative
 # The alpha > 1/255 and T < 1e-4 tests are step functions of float expressions: two correct implementations that round
-# an exponent differently may flip one on a (pixel, gaussian) pair whose value sits on the threshold.  Measured against
-# the oracle: 1 pixel of 2 073 600 at 1920x1080 (max 1.7e-3), 0-1 pixel on the small scenes (max 1.4e-4).  The bar below
-# is the one bar for every rendered image (r04: the looser '2e-4 of the pixels' / 'mean 1e-4' of earlier rounds are gone);
-# where the oracle's lists are at hand, tests/test_fused_gpu.py::_tight_bookkeeping additionally demands a float64
-# explanation (borderline alpha / T) for every pixel this bar lets through.
+# an exponent differently may flip one on a (pixel, gaussian) pair whose value sits on the threshold (the HIP loop
+# evaluates 2^(q + log2 sigma) where the reference evaluates sigma * __expf(p)).  Measured against the oracle: 1 pixel of
+# 2 073 600 at 1920x1080 (1.7e-3), 1 of 640 000 at 800x800 (2.8e-4), 0-1 pixel on the small scenes (max 1.4e-4).
+# r05: the bar is an ABSOLUTE count at what is measured plus one or two -- at most 3 pixels above 1e-4 at 1920x1080 and
+# larger, at most 2 on anything smaller (r04 allowed 1e-5 * P + 2 = 22 pixels at 1080p) -- and where the oracle's lists
+# are at hand (tests/test_fused_gpu.py::_tight_bookkeeping / _full_size_bookkeeping) every such pixel must additionally
+# be explained in float64 by a borderline alpha / T on its tile's list (parity_tools.explain asserts it).
 MEAN_L1_TOL = 1e-6       # mean per-pixel L1 (measured: 1.0e-7)
-ABOVE_TOL_FRACTION = 1e-5  # of the pixels may exceed PIXEL_L1_TOL (+ 2 pixels: one pixel of 64x48 is already 3e-4)
 FLIP_MAX = 2e-2          # what one flipped decision can be worth: alpha * |colour - behind| summed over three channels
-STOP_INDEX_FRACTION = 1e-4  # of the pixels may stop one splat earlier / later (+ 2)
+
+
+def max_pixels_above_tol(P):
+    """How many pixels of a P-pixel image may differ from the oracle by more than PIXEL_L1_TOL (see above)."""
+    return 3 if P >= 1920 * 1080 else 2
+
+
+def max_stop_index_mismatches(P):
+    """Pixels that may stop one splat earlier / later: 1e-5 of the image, at least 2 (measured: 6 of 2 073 600 at
+    1920x1080, 0-1 elsewhere; r04 allowed 1e-4 * P + 2 = 209)."""
+    return max(2, int(np.ceil(1e-5 * P)))
 
 
 def assert_image_close(got, ref, what="image"):
@@ -78,7 +89,7 @@ def assert_image_close(got, ref, what="image"):
     P = per_pixel_l1.size
     assert per_pixel_l1.mean() < MEAN_L1_TOL, f"{what}: mean per-pixel L1 {per_pixel_l1.mean():.3e}"
     above = int((per_pixel_l1 > PIXEL_L1_TOL).sum())
-    assert above <= ABOVE_TOL_FRACTION * P + 2, f"{what}: {above} of {P} pixels differ by more than {PIXEL_L1_TOL}"
+    assert above <= max_pixels_above_tol(P), f"{what}: {above} of {P} pixels differ by more than {PIXEL_L1_TOL}"
     assert per_pixel_l1.max() < FLIP_MAX, f"{what}: max per-pixel L1 {per_pixel_l1.max():.3e}"
 
 
@@ -86,7 +97,7 @@ def assert_stop_indices_close(got, ref, what="splats_per_pixel"):
     got, ref = np.asarray(got), np.asarray(ref)
     assert got.shape == ref.shape
     bad = int((got != ref).sum())
-    assert bad <= STOP_INDEX_FRACTION * got.size + 2, f"{what}: {bad} of {got.size} stop indices differ"
+    assert bad <= max_stop_index_mismatches(got.size), f"{what}: {bad} of {got.size} stop indices differ"
 
 
 def assert_grad_close(got, ref, what="grad", rel=GRAD_REL_TOL):

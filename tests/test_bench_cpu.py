@@ -50,3 +50,67 @@ def test_launcher_kills_the_other_ranks_when_one_fails_or_the_deadline_passes():
     out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"GSPLAT_BENCH_SELFTEST": "hang:all", "GSPLAT_BENCH_DEADLINE_S": "2"})
     assert out.returncode == 1 and time.time() - t0 < 60
     assert "deadline passed" in out.stderr and "[-9, -9]" in out.stderr
+
+
+def test_headline_guard_prints_the_line_exactly_once():
+    """bench.py's HeadlineGuard (r05): whatever the optional legs behind the timed region do, rank 0's ONE line gets out.
+    (a) finish() prints the line with the extras merged, once; (b) a main thread that never comes back (a hung
+    collective) -- the timer prints the line as it stands and leaves with exit code 0."""
+    import io
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    buf = io.StringIO()
+    g = bench.HeadlineGuard({"n_gpus": 2, "value": 3.0}, 60, out=buf).arm()
+    assert g.finish({"exchange_ms_per_step": {"split": 1.0}}) is True
+    assert g.finish({"exchange_ms_per_step": "again"}) is False
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "value": 3.0, "exchange_ms_per_step": {"split": 1.0}}
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.HeadlineGuard({'n_gpus': 2, 'value': 3.0}, 0.5, on_timeout={'exchange_ms_per_step': {'status': 'late'}}).arm(); "
+            "time.sleep(120)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["exchange_ms_per_step"] == {"status": "late"} and json.loads(lines[0])["value"] == 3.0
+
+
+def test_payload_sweep_reports_failures_and_stops_on_asymmetric_ones():
+    """bench.sweep_payloads on two in-process ranks (CPU tensors): a payload that raises on EVERY rank is reported and
+    left out, the others are timed (MAX over the ranks); one that raises on ONE rank only ends the sweep on all ranks
+    (SweepAbort) -- the caller prints the headline regardless."""
+    import importlib
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    gdist = importlib.import_module("3dgs_amd.dist")
+    dev = torch.device("cpu")
+
+    def everywhere(comm):
+        def time_mode(mode):
+            if mode == "b":
+                raise RuntimeError("backend says no")
+            return 1.0 + comm.rank
+        return bench.sweep_payloads(comm, ("a", "b", "c"), time_mode, torch, dev)
+
+    res = gdist.ThreadGroup(2).run(everywhere)
+    assert res[0] == res[1] == {"a": 2.0, "b": "failed: RuntimeError: backend says no", "c": 2.0}
+
+    def one_rank_only(comm):
+        def time_mode(mode):
+            if mode == "b" and comm.rank == 1:
+                raise RuntimeError("only here")
+            return 1.0
+        try:
+            bench.sweep_payloads(comm, ("a", "b", "c"), time_mode, torch, dev)
+        except bench.SweepAbort as e:
+            return str(e)
+        return "no abort"
+
+    res = gdist.ThreadGroup(2).run(one_rank_only)
+    assert all("some ranks only" in r for r in res), res
+
+
+def test_launcher_deadline_is_below_the_drivers_timeout():
+    src = open(BENCH).read()
+    assert 'os.environ.get("GSPLAT_BENCH_DEADLINE_S", "540")' in src  # the driver allows a run 600 s

@@ -37,18 +37,36 @@ def _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=None):
     assert sum(1 for lo, _ in step.chunk_bounds()[1:] if not mask[lo]) >= 2, "range bounds on culled indices wanted"
     torch.cuda.synchronize()
     chunked, uv_chunked = step.packed.clone(), step.uv_norm_sum.clone()
-    grads_chunked = {k: v.clone() for k, v in step.grads.items()}
-    # the same rows once more, unchunked (the context still holds this forward's compositing-backward result)
+    N, bg = step.N, c["bg"]
+    # (a) this VIEW's rows before any exchange: the ranges must add up to the whole backward, and both must be bit for bit
+    # what the compacted route gives (gsplat_backward_gaussians + gsplat_pack_gradients_split + gsplat_pack_uv_grad_norm)
+    raster = pkg("raster")
+    nan = float("nan")
+    rgb_a = torch.full((N + 1, 3), nan, device=step.dev)
+    com_r, uv_r = torch.full((N, 12), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
+    step.ctx.backward_render(gi, bg, rgb_a, com_r, uv_r)
+    for lo, hi in step.chunk_bounds():
+        step.ctx.backward_gaussians_split(step.params, cam, L, com_r, uv_r, lo, hi)
+    com_w, uv_w = torch.full((N, 12), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
+    step.ctx.backward_render(gi, bg, rgb_a, com_w, uv_w)
+    step.ctx.backward_gaussians_split(step.params, cam, L, com_w, uv_w)
+    g = step.ctx.alloc_gradients(N, L, intermediates=("uv", "precompute_rgb"))
+    step.ctx.backward_pass(step.params, cam, gi, bg, L, g)
+    com_p, rgb_p, uv_p = torch.full((N, 12), nan, device=step.dev), torch.full((N + 1, 3), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
+    raster.pack_gradients_split(step.ctx, g, N, com_p, rgb_p)
+    raster.pack_uv_grad_norm(step.ctx, g, N, uv_p)
+    torch.cuda.synchronize()
+    assert torch.equal(com_r, com_w) and torch.equal(uv_r, uv_w), "the ranges do not add up to the whole backward"
+    assert torch.equal(com_w, com_p) and torch.equal(uv_w, uv_p), "direct global-order rows differ from the packed compacted ones"
+    assert torch.equal(rgb_a[:N], rgb_p[:N])
+    # (b) the same rows once more through the exchange, unchunked: every row of the exchange buffers is rewritten
     step.chunks = 1
-    for v in step.grads.values():
-        v.fill_(float("nan"))
-    step.ctx.backward_gaussians(step.params, cam, L, step.grads)
+    step._reduce_buf.fill_(nan)
+    step.ctx.backward_render(gi, bg, step.rgb, step.common, step.uv_norm_sum)
+    step._rgb_gather = step.comm.all_gather_blocks(step.rgb_all, step.rgb, async_op=True)
+    step.ctx.backward_gaussians_split(step.params, cam, L, step.common, step.uv_norm_sum)
     step.exchange_gradients(cam)
     torch.cuda.synchronize()
-    M = step.ctx._last[1]
-    for k, v in step.grads.items():
-        a, b = grads_chunked[k][:M], v[:M]
-        assert torch.equal(a, b), f"per-view grad_{k}: the ranges do not add up to the whole backward"
     if step.world <= 2 or comm is not None:
         assert torch.equal(chunked, step.packed), "chunked exchange differs from the single all-reduce"
         assert torch.equal(uv_chunked, step.uv_norm_sum)
@@ -81,7 +99,7 @@ def _worker(rank, world, port, out_dir):
     gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
     c = scene.CONFIG
     out = {}
-    for ex in ("split", "split_direct", "factored", "full"):
+    for ex in ("split", "split_packed", "split_direct", "factored", "full"):
         step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange=ex)
         step.step(cam, gi)
         step.step(cam, gi)  # twice: buffers are reused
@@ -100,9 +118,10 @@ def test_view_sharded_step_two_ranks_one_gpu(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
-    for ex in ("split", "split_direct", "factored", "full", "chunked"):
+    for ex in ("split", "split_packed", "split_direct", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
+    assert (r[0]["split"] == r[0]["split_packed"]).all()
     full = r[0]["full"]
     scale = np.abs(full).mean()
     for ex in ("split", "split_direct", "factored", "chunked"):
@@ -203,7 +222,7 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
     def body(comm):
         cam = raster.device_camera(scene.make_camera(W, H, view_index=comm.rank + 1))
         out = {}
-        for ex in ("split", "split_direct", "factored", "full"):
+        for ex in ("split", "split_packed", "split_direct", "factored", "full"):
             step = gdist.ViewShardedStep(dp, L, W, H, c, c["bg"], exchange=ex, comm=comm)
             assert step.world == world and step.fw == 12 + 3 * world
             if ex.startswith("split"):
@@ -218,9 +237,10 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
         return out
 
     r = gdist.ThreadGroup(world).run(body)
-    for ex in ("split", "split_direct", "factored", "full", "chunked"):
+    for ex in ("split", "split_packed", "split_direct", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
+    assert (r[0]["split"] == r[0]["split_packed"]).all()
     full = r[0]["full"]
     scale = np.abs(full).mean()  # (each payload ran its own backward: float atomics, so payloads agree to rounding only)
     for ex in ("split", "split_direct", "factored", "chunked"):
@@ -295,29 +315,61 @@ def test_split_exchange_on_rccl_one_rank():
     assert out.returncode == 0 and "nccl one-rank rehearsal: ok" in out.stderr, out.stdout[-2000:] + out.stderr[-2000:]
     import json
     rep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    for payload in ("split", "split_chunks4", "split_direct", "factored", "full"):  # every payload went through RCCL
+    for payload in ("split", "split_packed", "split_chunks4", "split_direct", "factored", "full"):  # every payload went through RCCL
         assert rep[payload]["host_us_per_step_in_exchange_calls"] > 0, payload
+
+
+def _bench(world, threads, extra_env=None, steps=4):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSPLAT_EXCHANGE")}
+    env.update(GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    if threads:
+        env["GSPLAT_BENCH_THREAD_RANKS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "small", "--steps",
+                          str(steps), "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, lines, (json.loads(lines[-1]) if lines else None)
+
+
+SWEEP = {"split", "split_packed", "split_chunks4", "split_direct", "factored", "full"}
 
 
 @pytest.mark.parametrize("world,threads", [(2, False), (4, False), (8, True)])
 def test_bench_launches_its_own_ranks(world, threads):
     """`python bench.py --gpus N` with WORLD_SIZE unset starts N ranks itself (gloo lets them share this GPU; the
-    RCCL run needs one device per rank) and rank 0 reports n_gpus N with the times of all three exchange payloads.
+    RCCL run needs one device per rank) and rank 0 reports n_gpus N -- ONE line -- with the headline measured on the
+    conservative `split` payload FIRST and the times of all exchange payloads from the sweep behind the timed region.
     N = 8 runs as rank threads of one process (GSPLAT_BENCH_THREAD_RANKS=1): eight rank processes exceed this box's
     process guard; the driver's 8-GPU run uses processes over RCCL."""
-    import json
-    import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSPLAT_EXCHANGE")}
-    env.update(GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if threads:
-        env["GSPLAT_BENCH_THREAD_RANKS"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "small", "--steps", "4",
-                          "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    out, lines, line = _bench(world, threads)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len(lines) == 1, "exactly one JSON line"
     assert line["n_gpus"] == world and line["config"]["views_per_step"] == world and line["scaling"] == "weak"
     assert line["config"]["backend"] == ("threads" if threads else "gloo")
-    assert set(line["exchange_ms_per_step"]) == {"full", "factored", "split", "split_chunks4", "split_direct"}
+    assert set(line["exchange_ms_per_step"]) == SWEEP and all(isinstance(v, float) for v in line["exchange_ms_per_step"].values())
     assert line["exchange_model"]["this_run"]["world"] == world and "split_at_8_ranks" in line["exchange_model"]
-    assert line["config"]["exchange"].split(":")[0] in ("full", "factored", "split")
+    assert line["config"]["exchange"].split(":")[0] == "split"
     assert line["value"] > 0 and line["steps"] == 4
+
+
+@pytest.mark.parametrize("selftest,expect", [
+    ("raise:split_direct", "all ranks"),      # an optional payload fails on EVERY rank: reported, the rest measured
+    ("raise:factored:1", "one rank"),         # ... on ONE rank only: the sweep ends (collectives no longer pair up)
+    ("hangsweep", "hang"),                    # ... never returns: the guard prints the headline and leaves
+])
+def test_bench_headline_survives_the_payload_sweep(selftest, expect):
+    """The headline is measured and safe before anything optional touches a collective (r04 review: the sweep ran before
+    the warm-up, where a hang would have lost the number): whatever the sweep does, rank 0 prints exactly one line with
+    the headline, and the run exits 0."""
+    out, lines, line = _bench(2, False, {"GSPLAT_BENCH_SELFTEST": selftest, "GSPLAT_BENCH_SWEEP_DEADLINE_S": "25"})
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert len(lines) == 1 and line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 4
+    sweep = line["exchange_ms_per_step"]
+    if expect == "all ranks":
+        assert str(sweep["split_direct"]).startswith("failed") and isinstance(sweep["split"], float) and isinstance(sweep["full"], float)
+    elif expect == "one rank":
+        assert "status" in sweep and "sweep ended" in sweep["status"]
+    else:
+        assert "status" in sweep and "did not finish" in sweep["status"]

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import parity_tools
-from conftest import ROOT, assert_grad_close, assert_image_close, assert_stop_indices_close, pkg
+from conftest import (ROOT, assert_grad_close, assert_image_close, assert_stop_indices_close, max_pixels_above_tol,
+                      max_stop_index_mismatches, pkg)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -76,7 +77,7 @@ def _tight_bookkeeping(fwd, ref):
             f"{worst['slack_px']:.2e} px, {worst['alpha_rel']:.2e} rel")
     print(line)
     assert rep["mean_l1"] < 1e-6, line
-    assert above <= 1e-5 * P + 2 and rep["n_mismatch"] <= 1e-4 * P + 2, line
+    assert above <= max_pixels_above_tol(P) and rep["n_mismatch"] <= max_stop_index_mismatches(P), line
     assert len(rep["only_gpu"]) + len(rep["only_ref"]) <= 1e-5 * rep["S_ref"] + 2, line
 
 
@@ -85,17 +86,21 @@ def _full_size_bookkeeping(fwd, ref, W, H, what):
     borderline decision (tests/parity_tools.py); the figures land in the pytest log (-s) and in the assertion text."""
     f = {k: _np(fwd[k]) for k in ("image", "T", "n", "sorted", "ranges", "radius")}
     rep = parity_tools.forward_parity_report(f, ref, W, H)
+    # explain() ASSERTS (it does not only report): every pixel above 1e-4 and every stop-index mismatch must have an alpha
+    # within 2e-3 relative of 1/255 or a T(1 - alpha) that close to 1e-4 on its tile's list, re-evaluated in float64
     worst = parity_tools.explain(rep, f, ref, W, H)
-    line = (f"[parity {what}] per-pixel L1: max {rep['max_l1']:.3e}, 99.99th pct {rep['p9999_l1']:.3e}, mean "
+    P = W * H
+    above = int(round(rep["frac_above"] * P))
+    line = (f"[parity {what}] {above} pixels > 1e-4; per-pixel L1: max {rep['max_l1']:.3e}, 99.99th pct {rep['p9999_l1']:.3e}, mean "
             f"{rep['mean_l1']:.3e}, fraction > 1e-4: {rep['frac_above']:.3e}; n mismatches {rep['n_mismatch']} of {W * H}; "
             f"instances {rep['S_gpu']} vs {rep['S_ref']}: {len(rep['only_gpu'])} only in the HIP lists, "
             f"{len(rep['only_ref'])} only in the oracle's; ceil'ed radii differing: {len(rep['radius_diff'])}; worst "
             f"borderline margins: OBB/tile slack {worst['slack_px']:.2e} px, alpha/T {worst['alpha_rel']:.2e} relative")
     print(line)
-    # r02 figures on MI355X: config3 1 pixel of 2 073 600 above 1e-4 (max 1.7e-3), 6 stop-index mismatches, identical
-    # lists; config2 1 pixel of 640 000 (max 2.8e-4); the bars below leave a factor ~20 for other boxes / libm builds
+    # measured on MI355X: config3 1 pixel of 2 073 600 above 1e-4 (max 1.7e-3), 6 stop-index mismatches, identical lists;
+    # config2 1 pixel of 640 000 (max 2.8e-4).  r05: absolute caps (conftest.max_pixels_above_tol: 3 at 1080p, 2 below)
     assert rep["mean_l1"] < 1e-6 and rep["p9999_l1"] < 1e-4, line
-    assert rep["frac_above"] <= 1e-5 and rep["n_mismatch"] <= 1e-4 * W * H, line
+    assert above <= max_pixels_above_tol(P) and rep["n_mismatch"] <= max_stop_index_mismatches(P), line
     assert len(rep["only_gpu"]) + len(rep["only_ref"]) <= 1e-5 * rep["S_ref"] + 2, line
     return rep
 

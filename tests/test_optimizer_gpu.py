@@ -190,3 +190,54 @@ def test_optimizer_argument_errors(gpu, scene):
     assert lib.gsplat_optimizer_step(None, 4, grp, 1, 0.9, 0.999, 1e-8, 0.1, 0.001, None, None, None, None) == -3  # stride 0
     grp[0].stride = 3
     assert lib.gsplat_optimizer_step(None, 4, grp, 1, 0.9, 0.999, 1e-8, 0.1, 0.001, None, None, None, None) == -1  # NULL param
+
+
+@pytest.mark.parametrize("name,world", [("small", 3), ("small_l1", 2), ("tiny_l0", 2)])
+def test_split_step_equals_packed_rows_step(gpu, scene, name, world):
+    """A W-view step on the split exchange's own factored form -- common[N,12] summed over the views + every view's
+    g_rgb and camera position (rgb_all) -- through AdamOptimizer.step_split (gsplat_optimizer_step_sh_views rebuilds
+    sum_r g_rgb^r x Y_k(dir^r) inside the colour groups' Adam, the other four groups read common directly) must leave
+    parameters, both moments and the densification statistics BIT-identical to materialising packed[N, 12 + 3 n]
+    (gsplat_unpack_gradients_split) and running gsplat_optimizer_step_packed on it (cuda/trainer.cu:1027-1158 per view).
+    W views on one GPU, two steps (the second on moved gaussians), rows no view saw untouched."""
+    torch, raster, opt_mod = gpu, pkg("raster"), pkg("optimizer")
+    N, W, H, L = {"small": (5000, 256, 144, 3), "small_l1": (5000, 256, 144, 1), "tiny_l0": (600, 96, 64, 0)}[name]
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::3, 2] *= -1  # a third behind every camera
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    ctx.set_lean_forward(True)
+    dp = raster.device_params(params)
+    twin = {k: v.clone() for k, v in dp.items()}
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    cams = [raster.device_camera(scene.make_camera(W, H, v + 1)) for v in range(world)]
+    oa, ob = opt_mod.AdamOptimizer(dp, L), opt_mod.AdamOptimizer(twin, L)
+    wc = raster.packed_gradient_width(L)
+    for it in (0, 1):
+        common = torch.zeros(N, 12, device="cuda")
+        uv_sum = torch.zeros(N, device="cuda")
+        rgb_all = torch.full((world, N + 1, 3), float("nan"), device="cuda")
+        for r, cam in enumerate(cams):  # the exchange by hand: sum of the views' common rows, gather of their g_rgb
+            com_r, uv_r = torch.full((N, 12), float("nan"), device="cuda"), torch.full((N,), float("nan"), device="cuda")
+            ctx.rasterize_image(dp, cam, c, c["bg"], L)
+            ctx.backward_render(gi, c["bg"], rgb_all[r], com_r, uv_r)
+            ctx.backward_gaussians_split(dp, cam, L, com_r, uv_r)
+            rgb_all[r, N] = cam["campos_dev"]
+            common += com_r
+            uv_sum += uv_r
+        assert torch.isfinite(common).all() and torch.isfinite(rgb_all).all()
+        seen = common[:, 11] > 0
+        assert 0 < int(seen.sum()) < N and int(common[:, 11].max()) == world
+        packed = torch.full((N, wc), float("nan"), device="cuda")
+        raster.unpack_gradients_split(dp["xyz"], common, rgb_all, 3 * (N + 1), L, N, world, packed)
+        before = {g: twin[g].clone() for g in oa.names}
+        oa.step_split(it, common, rgb_all, uv_sum)
+        ob.step_packed(it, packed, uv_sum)
+        torch.cuda.synchronize()
+        for g in oa.names:
+            assert torch.equal(dp[g], twin[g]), (it, g)
+            assert torch.equal(oa.exp_avg[g], ob.exp_avg[g]) and torch.equal(oa.exp_avg_sq[g], ob.exp_avg_sq[g]), (it, g)
+            moved = (twin[g].reshape(N, -1) != before[g].reshape(N, -1)).any(1)
+            assert not moved[~seen].any() and moved[seen].any(), (it, g)
+        assert torch.equal(oa.uv_grad_accum, ob.uv_grad_accum) and torch.equal(oa.grad_accum_dur, ob.grad_accum_dur)
+        assert int(oa.grad_accum_dur.max()) == world * (it + 1)

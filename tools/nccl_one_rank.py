@@ -40,16 +40,19 @@ ctx = raster.RasterContext(N, W, H)
 ctx.set_lean_forward(True)
 full = torch.empty(N, raster.packed_gradient_width(L), device=dev)
 report = {"workload": workload, "backend": "nccl, one rank (collectives degenerate to copies)"}
-for name, kw in (("split", dict(exchange="split", chunks=1)), ("split_chunks4", dict(exchange="split", chunks=4)),
+ref_grads = ctx.alloc_gradients(N, L)
+for name, kw in (("split", dict(exchange="split", chunks=1)), ("split_packed", dict(exchange="split_packed", chunks=1)),
+                 ("split_chunks4", dict(exchange="split", chunks=4)),
                  ("split_direct", dict(exchange="split_direct")), ("factored", dict(exchange="factored")),
                  ("full", dict(exchange="full"))):
     step = gdist.ViewShardedStep(dp, L, W, H, cfg, cfg["bg"], ctx=ctx, exchange_at_world_one=True, **kw)
     assert step.world == 1
     step.step(cam, gi)
-    packed = step.packed.clone()
+    packed = step.packed.clone()  # (split: materialised here, on demand, from common + rgb_all)
     torch.cuda.synchronize()
-    # reference: the full rows of the same backward through one all-reduce
-    ctx.pack_gradients_global(step.grads, L, N, full)
+    # reference: the full rows of a plain backward of the same forward through one all-reduce
+    ctx.backward_pass(dp, cam, gi, cfg["bg"], L, ref_grads)
+    ctx.pack_gradients_global(ref_grads, L, N, full)
     dist.all_reduce(full)
     torch.cuda.synchronize()
     err, scale = (packed - full).abs().max().item(), full.abs().max().item()
