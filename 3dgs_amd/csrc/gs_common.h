@@ -99,7 +99,15 @@ struct DeviceBuffer {
   void *ptr = nullptr;
   size_t bytes = 0;
   unsigned long long generation = 0;  // bumped by every allocation and release: state cached about the CONTENTS keys on it
+  // r05: a POOLED buffer takes its storage from the library's block pool (gsplat_pool_alloc) instead of hipMalloc, so
+  // that its block can be handed to the caller (detach: the caller then owns it and returns it with gsplat_pool_free) and
+  // the next reserve() finds a block of the same size class in the pool without touching the allocator -- how the
+  // rasterize_image shim gives ForwardPassData the forward's own output arrays instead of copies (raster.cuh).
+  bool pooled = false;
+  size_t wanted = 0;  // the largest size ever asked for: what reserve_again() restores after a detach
   int reserve(size_t want);
+  int reserve_again() { return reserve(wanted); }
+  void *detach();
   void release();
   template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
 };

@@ -37,8 +37,23 @@ int check_device_ptr(const void *p, const char *name, const char *fn) {
 }
 
 int DeviceBuffer::reserve(size_t want) {
+  if (want > wanted) wanted = want;
   if (want <= bytes) return GSPLAT_OK;
   size_t grow = want + want / 4 + 256;
+  if (pooled) {
+    // pool blocks are reused in stream order (gsplat_hip.h): no device synchronisation, no allocator call in the steady
+    // state.  The request is the plain size when the buffer comes back after a detach (the block it gave away is of
+    // exactly that class), with headroom when it grows.
+    if (ptr) { (void)gsplat_pool_free(ptr); ptr = nullptr; bytes = 0; }
+    else grow = want;
+    ++generation;
+    void *fresh = nullptr;
+    const int rc = gsplat_pool_alloc(&fresh, grow);
+    if (rc != GSPLAT_OK) return rc;
+    ptr = fresh;
+    bytes = grow;  // (the block may be larger -- its size class -- but only this much is promised)
+    return GSPLAT_OK;
+  }
   if (ptr) {
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { set_error("scratch: hipDeviceSynchronize: %s", hipGetErrorString(e)); return GSPLAT_ERR_HIP; }
@@ -57,8 +72,19 @@ int DeviceBuffer::reserve(size_t want) {
   return GSPLAT_OK;
 }
 
+void *DeviceBuffer::detach() {
+  void *p = ptr;
+  ptr = nullptr;
+  bytes = 0;
+  ++generation;
+  return p;
+}
+
 void DeviceBuffer::release() {
-  if (ptr) (void)hipFree(ptr);
+  if (ptr) {
+    if (pooled) (void)gsplat_pool_free(ptr);
+    else (void)hipFree(ptr);
+  }
   ptr = nullptr;
   bytes = 0;
   ++generation;
@@ -125,11 +151,22 @@ size_t pool_class(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 
-int pool_drop_idle_locked() {  // hipFree of every cached block (synchronises the device)
+int pool_drop_idle_locked() {  // hipFree of every cached block (synchronises each device that owns one)
   if (g_pool_idle_bytes == 0) return GSPLAT_OK;
-  (void)hipDeviceSynchronize();
-  for (auto &kv : g_pool_idle)
+  int here = 0;
+  (void)hipGetDevice(&here);
+  int synced = -1;
+  for (auto &kv : g_pool_idle) {  // the map is ordered by (device, class): one synchronisation per device
+    if (kv.second.empty()) continue;
+    const int dev = kv.first.first;
+    if (dev != synced) {  // work that still reads a block runs on the block's OWN device
+      (void)hipSetDevice(dev);
+      (void)hipDeviceSynchronize();
+      synced = dev;
+    }
     for (void *p : kv.second) (void)hipFree(p);
+  }
+  (void)hipSetDevice(here);
   g_pool_idle.clear();
   g_pool_idle_info.clear();
   g_pool_idle_bytes = 0;

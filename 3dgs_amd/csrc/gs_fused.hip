@@ -120,6 +120,12 @@ struct gsplat_context {
   size_t S = 0;
   long long last_longest = -1;  // longest tile list of the last counting-sort forward (-1: unknown)
   bool have_forward = false;
+  // r05: the thirteen arrays of the reference's ForwardPassData (cuda_data.cuh:70-86).  They are pooled buffers, so that
+  // gsplat_context_detach_forward_outputs can hand their blocks to the caller instead of the caller copying them.
+  void forward_outputs(gs::DeviceBuffer *out[13]) {
+    gs::DeviceBuffer *all[13] = {&mask, &uv_all, &xyz_c_all, &sigma, &conic, &J, &rgb, &radius, &sorted, &ranges, &image, &T_px, &n_px};
+    for (int k = 0; k < 13; ++k) out[k] = all[k];
+  }
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
@@ -1050,6 +1056,11 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   const size_t N = (size_t)max_gaussians, P = (size_t)max_width * max_height;
   const size_t T = (size_t)((max_width + 15) / 16) * ((max_height + 15) / 16);
   int rc = GSPLAT_OK;
+  {
+    gs::DeviceBuffer *outs[13];
+    c->forward_outputs(outs);
+    for (gs::DeviceBuffer *b : outs) b->pooled = true;
+  }
   auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
   R(c->mask, N + 16); R(c->counters, 512 + gs::kBinBlocks * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
@@ -1119,6 +1130,17 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->have_forward = false;
   c->rows_ready = false;
   c->order_ready = false;
+  {  // outputs the caller took over (gsplat_context_detach_forward_outputs) come back from the pool, at their old sizes
+    gs::DeviceBuffer *outs[13];
+    c->forward_outputs(outs);
+    for (gs::DeviceBuffer *b : outs)
+      if (b->ptr == nullptr) {
+        const int r = b->reserve_again();
+        if (r) return r;
+        // a fresh `sorted` must hold valid gaussian ids wherever the speculative tail may read it (reserve_instances)
+        if (b == &c->sorted) GS_HIP(hipMemsetAsync(b->ptr, 0, b->bytes, st));
+      }
+  }
   const int ntx = (W + 15) / 16, nty = (H + 15) / 16, num_tiles = ntx * nty;
   const float fx = cam->focal_x, fy = cam->focal_y;
   const float tan_fovx = (float)W / (2.0f * fx), tan_fovy = (float)H / (2.0f * fy);  // cuda/raster.cu:92-93
@@ -1368,6 +1390,18 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     out->image = c->image.as<float>(); out->weight_per_pixel = c->T_px.as<float>();
     out->splats_per_pixel = c->n_px.as<int>();
   }
+  return GSPLAT_OK;
+}
+
+int gsplat_context_detach_forward_outputs(gsplat_context *c) {
+  GS_REQUIRE(c != nullptr, "null context");
+  GS_REQUIRE(c->n_forwards > 0 && c->mask.ptr != nullptr, "no forward whose outputs could be handed over");
+  GS_REQUIRE(!c->lean && !c->render_only, "a lean / render-only forward does not fill all ForwardPassData arrays");
+  gs::DeviceBuffer *outs[13];
+  c->forward_outputs(outs);
+  for (gs::DeviceBuffer *b : outs) (void)b->detach();  // the caller owns the blocks now (gsplat_pool_free)
+  c->have_forward = false;  // the fused backward would read arrays this context no longer has
+  c->rows_ready = false;
   return GSPLAT_OK;
 }
 

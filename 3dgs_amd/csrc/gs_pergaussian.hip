@@ -4,6 +4,8 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#include <cmath>
+
 #include "gs_common.h"
 #include "gs_math.h"
 #include "gs_rows.h"
@@ -296,6 +298,31 @@ __global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__rest
   }
 }
 
+// rows[slot] <- i for every set mask entry i (the index list of a compaction), slot < room
+__global__ __launch_bounds__(kBlock) void selected_rows_kernel(const unsigned char *__restrict__ mask,
+                                                               const int *__restrict__ ranks,
+                                                               const int *__restrict__ slice_counts, int N,
+                                                               int *__restrict__ rows, unsigned int room) {
+  __shared__ int s_base[kMaskSlices + 1];
+  mask_slice_bases(slice_counts, s_base);
+  const float slices_per_row = (float)kMaskSlices / (float)N;
+#pragma unroll
+  for (int r = 0; r < kRowsPer; ++r) {
+    const unsigned int i = (blockIdx.x * kRowsPer + r) * kBlock + threadIdx.x;
+    if (i >= (unsigned int)N) return;
+    if (!mask[i]) continue;
+    const unsigned int slot = (unsigned int)(s_base[mask_slice_of(N, i, slices_per_row)] + ranks[i]);
+    if (slot < room) rows[slot] = (int)i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_f32_kernel(float *__restrict__ dst, size_t n, float value) {
+  const size_t i = (size_t)blockIdx.x * kBlock * 4 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i + (size_t)k * kBlock < n) dst[i + (size_t)k * kBlock] = value;
+}
+
 template <bool kScatter>
 static int launch_masked_rows(const float *src, const unsigned char *mask, const int *ranks, const int *slice_counts, int N,
                               int stride, float *dst, hipStream_t st, unsigned int room_rows = 0xFFFFFFFFu) {
@@ -526,6 +553,34 @@ int gsplat_compact_masked_array_bounded(const float *src, const unsigned char *m
   int selected = 0;
   for (int k = 0; k < kMaskSlices; ++k) selected += gs::host_words().p[k];
   *num_selected = selected;
+  return GSPLAT_OK;
+}
+
+int gsplat_mask_selected_rows(const unsigned char *mask, int N, int *rows, int rows_cap, void *stream) {
+  GS_REQUIRE(N >= 0 && rows_cap >= 0, "negative size");
+  if (N == 0 || rows_cap == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(mask); GS_REQUIRE_DEV(rows);
+  hipStream_t st = (hipStream_t)stream;
+  gs::ScratchLock lock;
+  int *ranks = nullptr, *slice_counts = nullptr;
+  int rc = gs::mask_slice_ranks(mask, N, &ranks, &slice_counts, st);
+  if (rc) return rc;
+  selected_rows_kernel<<<gs::div_up(N, (long long)kRowsPer * kBlock), kBlock, 0, st>>>(mask, ranks, slice_counts, N, rows,
+                                                                                      (unsigned int)rows_cap);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
+int gsplat_fill_f32(float *dst, size_t n, float value, void *stream) {
+  if (n == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(dst);
+  hipStream_t st = (hipStream_t)stream;
+  if (value == 0.0f && !std::signbit(value)) {
+    GS_HIP(hipMemsetAsync(dst, 0, n * sizeof(float), st));
+    return GSPLAT_OK;
+  }
+  fill_f32_kernel<<<gs::div_up((long long)n, (long long)kBlock * 4), kBlock, 0, st>>>(dst, n, value);
+  GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
 

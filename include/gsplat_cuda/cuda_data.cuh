@@ -16,7 +16,28 @@
 #include "hip_compat.h"
 
 #include <thrust/device_ptr.h>
+#include <thrust/fill.h>
 #include <thrust/host_vector.h>
+#include <thrust/iterator/counting_iterator.h>
+#include <thrust/iterator/transform_iterator.h>
+
+#ifndef GSPLAT_SHIM_NO_THRUST_FILL
+// The reference host clears its gradient vectors with twelve thrust::fill_n calls per iteration (zero_grads,
+// cuda/trainer.cu:247-261).  Each is a kernel followed by a stream synchronisation inside thrust (0.27 ms per
+// iteration at 1e6 gaussians, a third of it waiting).  This overload -- more specialised than thrust's own template, so
+// overload resolution picks it for `thrust::fill_n(vec.begin(), n, 0.0f)` on a thrust::device_vector<float> -- queues
+// the fill on the default stream and returns (gsplat_fill_f32: hipMemsetAsync for zero).  Everything the reference does
+// afterwards runs on that stream or blocks on it, so the order of effects is unchanged.  -DGSPLAT_SHIM_NO_THRUST_FILL
+// switches it off.
+namespace thrust {
+template <typename Size>
+inline detail::normal_iterator<device_ptr<float>> fill_n(detail::normal_iterator<device_ptr<float>> first, Size n,
+                                                         const float &value) {
+  if (n > 0) gsplat_shim::require_ok(gsplat_fill_f32(raw_pointer_cast(first.base()), (size_t)n, value, 0), "thrust::fill_n");
+  return first + n;
+}
+}  // namespace thrust
+#endif
 
 namespace gsplat_shim {
 // A device vector for the objects the reference host creates and destroys EVERY iteration: the members of
@@ -28,6 +49,18 @@ namespace gsplat_shim {
 // from the library's block pool (gsplat_pool_alloc: a freed block is handed to the next request of its size class, in
 // stream order), so the steady state of a training loop allocates nothing.  Unlike device_vector it does NOT
 // value-initialise new elements (every user overwrites them).
+// gathers element e of a compaction on the fly: row e / STRIDE of the compacted array is row rows[e / STRIDE] of the source
+template <typename T, int STRIDE> struct gather_rows_fn {
+  const T *src;
+  const int *rows;
+  int stride_rt;
+  __host__ __device__ T operator()(unsigned int e) const {
+    const unsigned int st = STRIDE > 0 ? (unsigned int)STRIDE : (unsigned int)stride_rt;
+    const unsigned int r = e / st;
+    return src[(size_t)rows[r] * st + (e - r * st)];
+  }
+};
+
 template <typename T> class device_array {
  public:
   using value_type = T;
@@ -39,18 +72,23 @@ template <typename T> class device_array {
 
   device_array() = default;
   explicit device_array(size_t n) { resize(n); }
-  device_array(const device_array &o) { assign_raw(o.ptr_, o.size_); }
-  device_array(device_array &&o) noexcept : ptr_(o.ptr_), size_(o.size_), cap_(o.cap_) { o.ptr_ = nullptr; o.size_ = o.cap_ = 0; }
+  device_array(const device_array &o) { o.materialize(); assign_raw(o.ptr_, o.size_); }
+  device_array(device_array &&o) noexcept : ptr_(o.ptr_), size_(o.size_), cap_(o.cap_), pend_(o.pend_) {
+    o.ptr_ = nullptr; o.size_ = o.cap_ = 0; o.pend_.on = false;
+  }
   template <typename A> device_array(const thrust::device_vector<T, A> &v) { assign_raw(thrust::raw_pointer_cast(v.data()), v.size()); }
   device_array &operator=(device_array o) noexcept { swap(o); return *this; }
   ~device_array() { release(); }
 
-  void swap(device_array &o) noexcept { std::swap(ptr_, o.ptr_); std::swap(size_, o.size_); std::swap(cap_, o.cap_); }
+  void swap(device_array &o) noexcept {
+    std::swap(ptr_, o.ptr_); std::swap(size_, o.size_); std::swap(cap_, o.cap_); std::swap(pend_, o.pend_);
+  }
   size_t size() const { return size_; }
   bool empty() const { return size_ == 0; }
-  void clear() { size_ = 0; }
+  void clear() { size_ = 0; pend_.on = false; }
   // new elements are uninitialised; the first min(old, new) elements are kept
   void resize(size_t n) {
+    materialize();
     if (n > cap_) {
       void *fresh = nullptr;
       const int st = gsplat_pool_alloc(&fresh, n * sizeof(T));
@@ -62,31 +100,89 @@ template <typename T> class device_array {
     }
     size_ = n;
   }
-  pointer data() { return pointer(ptr_); }
-  const_pointer data() const { return const_pointer(ptr_); }
-  iterator begin() { return pointer(ptr_); }
-  iterator end() { return pointer(ptr_ + size_); }
-  const_iterator begin() const { return const_pointer(ptr_); }
-  const_iterator end() const { return const_pointer(ptr_ + size_); }
+  // r05: take over a block of the library's pool that already holds n elements (rasterize_image hands ForwardPassData
+  // the forward's own output arrays: gsplat_context_detach_forward_outputs) -- no allocation, no copy
+  void adopt(const void *pool_block, size_t n) {
+    release();
+    ptr_ = static_cast<T *>(const_cast<void *>(pool_block));
+    size_ = cap_ = n;
+  }
+  // r05: a compaction that has not run yet (compact_masked_array of the SH strides: cuda/trainer.cu:950-960 assigns its
+  // result to a thrust::device_vector, which the conversion below then fills with ONE gather kernel instead of a
+  // compaction into pool storage + a value-initialising allocation + a copy).  Anything else that looks at the elements
+  // -- data(), begin(), a copy -- runs the compaction into pool storage first, so the object behaves as if it had run.
+  // The source and the mask must stay as they are until then (they do at the reference's call sites).
+  void defer_compaction(const T *src, const unsigned char *mask, int N, int stride, int rows) {
+    release();
+    size_ = (size_t)rows * (size_t)stride;
+    pend_ = pending_t{src, mask, N, stride, rows, true};
+  }
+  pointer data() { materialize(); return pointer(ptr_); }
+  const_pointer data() const { materialize(); return const_pointer(ptr_); }
+  iterator begin() { materialize(); return pointer(ptr_); }
+  iterator end() { materialize(); return pointer(ptr_ + size_); }
+  const_iterator begin() const { materialize(); return const_pointer(ptr_); }
+  const_iterator end() const { materialize(); return const_pointer(ptr_ + size_); }
   const_iterator cbegin() const { return begin(); }
   const_iterator cend() const { return end(); }
   thrust::device_reference<T> operator[](size_t i) { return *(begin() + i); }
   thrust::device_reference<const T> operator[](size_t i) const { return *(begin() + i); }
 
   // copies, for the call sites that name thrust's types (`thrust::device_vector<float> d_sh_selected; d_sh_selected =
-  // compact_masked_array<45>(...)`, cuda/trainer.cu:950-960; `thrust::host_vector<bool> mask = pass.d_mask`)
+  // compact_masked_array<45>(...)`, cuda/trainer.cu:950-960; `thrust::host_vector<bool> mask = pass.d_mask`).  The
+  // vector is built from an iterator range: thrust allocates and runs one copy kernel, without the value-initialising
+  // fill (and its stream synchronisation) that `device_vector v(n)` would add.
   operator thrust::device_vector<T>() const {
-    thrust::device_vector<T> v(size_);
-    if (size_) (void)hipMemcpyAsync(thrust::raw_pointer_cast(v.data()), ptr_, size_ * sizeof(T), hipMemcpyDeviceToDevice, 0);
-    return v;
+    if (pend_.on && size_ > 0 && size_ < 0xFFFFFFFFull) {  // gather straight into the new vector
+      device_array<int> rows((size_t)pend_.rows);
+      const int st = gsplat_mask_selected_rows(pend_.mask, pend_.N, thrust::raw_pointer_cast(rows.data()), pend_.rows, 0);
+      if (st != GSPLAT_OK) throw std::bad_alloc();
+      const int *rp = thrust::raw_pointer_cast(rows.data());
+      const thrust::counting_iterator<unsigned int> zero(0u);
+      const unsigned int n = (unsigned int)size_;
+#define GSPLAT_GATHER_INTO_VECTOR(S)                                                                                   \
+  do {                                                                                                                 \
+    auto first = thrust::make_transform_iterator(zero, gather_rows_fn<T, S>{pend_.src, rp, pend_.stride});             \
+    return thrust::device_vector<T>(first, first + n);                                                                 \
+  } while (0)
+      switch (pend_.stride) {
+        case 9: GSPLAT_GATHER_INTO_VECTOR(9);
+        case 24: GSPLAT_GATHER_INTO_VECTOR(24);
+        case 45: GSPLAT_GATHER_INTO_VECTOR(45);
+        default: GSPLAT_GATHER_INTO_VECTOR(0);
+      }
+#undef GSPLAT_GATHER_INTO_VECTOR
+    }
+    return thrust::device_vector<T>(begin(), end());
   }
   operator thrust::host_vector<T>() const {
+    materialize();
     thrust::host_vector<T> v(size_);
     if (size_) (void)hipMemcpy(thrust::raw_pointer_cast(v.data()), ptr_, size_ * sizeof(T), hipMemcpyDeviceToHost);
     return v;
   }
 
  private:
+  struct pending_t {
+    const T *src = nullptr;
+    const unsigned char *mask = nullptr;
+    int N = 0, stride = 0, rows = 0;
+    bool on = false;
+  };
+  void materialize() const {
+    if (!pend_.on) return;
+    const pending_t p = pend_;
+    pend_.on = false;
+    if (size_ == 0) return;
+    void *fresh = nullptr;
+    if (gsplat_pool_alloc(&fresh, size_ * sizeof(T)) != GSPLAT_OK) throw std::bad_alloc();
+    ptr_ = static_cast<T *>(fresh);
+    cap_ = size_;
+    static_assert(sizeof(T) == 4 || sizeof(T) == 1 || sizeof(T) == 16, "element sizes of the reference's arrays");
+    require_ok(gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(p.src), p.mask, p.N, p.stride,
+                                                   reinterpret_cast<float *>(ptr_), p.rows, nullptr, 0),
+               "compact_masked_array");
+  }
   void assign_raw(const T *src, size_t n) {
     resize(n);
     if (n) (void)hipMemcpyAsync(ptr_, src, n * sizeof(T), hipMemcpyDeviceToDevice, 0);
@@ -95,9 +191,12 @@ template <typename T> class device_array {
     if (ptr_) (void)gsplat_pool_free(ptr_);
     ptr_ = nullptr;
     size_ = cap_ = 0;
+    pend_.on = false;
   }
-  T *ptr_ = nullptr;
-  size_t size_ = 0, cap_ = 0;
+  mutable T *ptr_ = nullptr;
+  size_t size_ = 0;
+  mutable size_t cap_ = 0;
+  mutable pending_t pend_;
 };
 
 template <typename F> inline void alloc_or_exit(const char *what, F &&f) {
@@ -195,6 +294,12 @@ gsplat_shim::device_array<typename Source::value_type> compact_masked_array(cons
   static_assert(sizeof(T) == 4, "rows are made of 4-byte elements (float / int)");
   static_assert(sizeof(typename Mask::value_type) == 1, "the mask is one byte per row (bool)");
   gsplat_shim::device_array<T> d_selected;
+  if constexpr (STRIDE >= 9) {  // the SH strides: deferred (see device_array::defer_compaction)
+    d_selected.defer_compaction(thrust::raw_pointer_cast(d_source.data()),
+                                reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data())),
+                                (int)d_mask.size(), STRIDE, num_culled);
+    return d_selected;
+  }
   gsplat_shim::alloc_or_exit("compact_masked_array", [&] { d_selected.resize((size_t)num_culled * STRIDE); });
   gsplat_shim::require_ok(
       gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_source.data())),

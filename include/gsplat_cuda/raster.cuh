@@ -10,10 +10,10 @@
 // camera_parameters.d_view / d_proj must already hold this view's matrices, as in the reference
 // (cuda/trainer.cu:1310-1331).  Like the reference it prints to stderr and exits when nothing is in view.
 //
-// The fused forward keeps its outputs in a gsplat_context; the reference's callers read vectors owned by pass_data,
-// so the outputs are copied there device-to-device (about 0.2 GB at 1e6 gaussians / 1080p: ~0.1 ms; the vectors come
-// from the library's block pool, cuda_data.cuh: a fresh ForwardPassData per iteration allocates nothing).  A host that
-// wants to skip the copies uses gsplat_rasterize_image / gsplat_forward_view directly.
+// The fused forward writes its outputs into blocks of the library's pool that belong to a gsplat_context; the
+// reference's callers read vectors owned by pass_data, so ownership of the thirteen blocks moves there
+// (gsplat_context_detach_forward_outputs: no copy -- r04 copied 0.2 GB per call) and the context takes replacements from
+// the pool at its next forward: a fresh ForwardPassData per iteration allocates nothing and copies nothing.
 #pragma once
 
 #include "cuda_data.cuh"
@@ -32,11 +32,6 @@ inline gsplat_context *context_for(int capacity, int width, int height) {
 }
 inline gsplat_context *&last_context() { static gsplat_context *c = nullptr; return c; }
 
-template <typename T> inline void copy_into(device_array<T> &dst, const void *src, size_t count) {
-  dst.clear();  // nothing of the previous view is worth carrying over a growth
-  alloc_or_exit("rasterize_image (ForwardPassData)", [&] { dst.resize(count); });
-  if (count) (void)hipMemcpyAsync(thrust::raw_pointer_cast(dst.data()), src, count * sizeof(T), hipMemcpyDeviceToDevice, 0);
-}
 }  // namespace gsplat_shim
 
 template <class CameraT, class ImageT, class ConfigT>
@@ -72,17 +67,21 @@ void rasterize_image(const int num_gaussians, const CameraT &camera, const Image
   const size_t N = (size_t)num_gaussians, M = v.num_culled, P = (size_t)width * height;
   const size_t T = (size_t)((width + 15) / 16) * ((height + 15) / 16);
   pass_data.num_culled = M;
-  gsplat_shim::copy_into(pass_data.d_mask, v.mask, N);
-  gsplat_shim::copy_into(pass_data.d_uv, v.uv, N * 2);
-  gsplat_shim::copy_into(pass_data.d_xyz_c, v.xyz_c, N * 3);
-  gsplat_shim::copy_into(pass_data.d_sigma, v.sigma, M * 6);
-  gsplat_shim::copy_into(pass_data.d_conic, v.conic, M * 3);
-  gsplat_shim::copy_into(pass_data.d_J, v.J, M * 6);
-  gsplat_shim::copy_into(pass_data.d_precomputed_rgb, v.precomputed_rgb, M * 3);
-  gsplat_shim::copy_into(pass_data.d_radius, v.radius, M);
-  gsplat_shim::copy_into(pass_data.d_sorted_gaussians, v.sorted_gaussians, v.num_splats);
-  gsplat_shim::copy_into(pass_data.d_splat_start_end_idx_by_tile_idx, v.splat_start_end_idx_by_tile_idx, T + 1);
-  gsplat_shim::copy_into(pass_data.d_image_buffer, v.image, P * 3);
-  gsplat_shim::copy_into(pass_data.d_weight_per_pixel, v.weight_per_pixel, P);
-  gsplat_shim::copy_into(pass_data.d_splats_per_pixel, v.splats_per_pixel, P);
+  // r05: ForwardPassData takes over the forward's OWN output arrays (blocks of the library's pool) instead of copying
+  // them: the context replaces them from the pool at its next forward -- with the very blocks this pass_data returns
+  // when the host destroys it at the end of the iteration (cuda/trainer.cu:1295).  r04 copied 0.2 GB here.
+  gsplat_shim::require_ok(gsplat_context_detach_forward_outputs(ctx), "rasterize_image (hand-over)");
+  pass_data.d_mask.adopt(v.mask, N);
+  pass_data.d_uv.adopt(v.uv, N * 2);
+  pass_data.d_xyz_c.adopt(v.xyz_c, N * 3);
+  pass_data.d_sigma.adopt(v.sigma, M * 6);
+  pass_data.d_conic.adopt(v.conic, M * 3);
+  pass_data.d_J.adopt(v.J, M * 6);
+  pass_data.d_precomputed_rgb.adopt(v.precomputed_rgb, M * 3);
+  pass_data.d_radius.adopt(v.radius, M);
+  pass_data.d_sorted_gaussians.adopt(v.sorted_gaussians, v.num_splats);
+  pass_data.d_splat_start_end_idx_by_tile_idx.adopt(v.splat_start_end_idx_by_tile_idx, T + 1);
+  pass_data.d_image_buffer.adopt(v.image, P * 3);
+  pass_data.d_weight_per_pixel.adopt(v.weight_per_pixel, P);
+  pass_data.d_splats_per_pixel.adopt(v.splats_per_pixel, P);
 }

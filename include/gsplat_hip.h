@@ -435,6 +435,22 @@ int gsplat_context_set_binning_route(gsplat_context *ctx, int route);
  * the evaluated SH colour (those four pointers of gsplat_forward_view come back NULL) and the compositing kernels'
  * block masks -- and the backward entry points answer "no forward pass recorded" until it is switched off again.
  * Image, per-pixel counts / transmittance and the sorted lists are unchanged. */
+/* r05 -- zero-copy hand-over of a forward's outputs.  The thirteen arrays of the reference's ForwardPassData
+ * (cuda_data.cuh:70-86: mask, uv, xyz_c, sigma, conic, J, precomputed_rgb, radius, sorted_gaussians,
+ * splat_start_end_idx_by_tile_idx, image, weight_per_pixel, splats_per_pixel -- the pointers the last gsplat_forward_view
+ * reported) are blocks of the library's pool; after this call the CALLER owns them and returns each with
+ * gsplat_pool_free, and the context takes fresh blocks of the same sizes from the pool at its next forward (which finds
+ * the ones the caller has returned in the meantime: no allocator call in the steady state of a training loop).  The
+ * rasterize_image shim (include/gsplat_cuda/raster.cuh) uses it instead of thirteen device-to-device copies.  The
+ * context's fused backward is unavailable for that forward afterwards (the stand-alone operators take the arrays). */
+int gsplat_context_detach_forward_outputs(gsplat_context *ctx);
+/* dst[0..n) <- value on `stream`, asynchronously (hipMemsetAsync for 0.0f).  What the drop-in headers route the host's
+ * thrust::fill_n calls on float device vectors to (cuda_data.cuh: zero_grads' twelve fills, cuda/trainer.cu:247-261, each
+ * of which otherwise ends in a stream synchronisation inside thrust). */
+int gsplat_fill_f32(float *dst, size_t n, float value, void *stream);
+/* rows[j] <- index of the j-th set entry of mask[0..N) for j < rows_cap (the row list of a compaction; what the lazy
+ * SH compaction of the drop-in headers gathers through).  No read-back. */
+int gsplat_mask_selected_rows(const unsigned char *mask, int N, int *rows, int rows_cap, void *stream);
 int gsplat_context_set_render_only(gsplat_context *ctx, int enabled);
 /* Lean forward (training through the fused entry points): gsplat_backward_pass recomputes Sigma, J and the conic from
  * the parameters and never reads the evaluated SH colour, so a caller that does not look at those four arrays of

@@ -42,16 +42,16 @@ def _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=None):
     # what the compacted route gives (gsplat_backward_gaussians + gsplat_pack_gradients_split + gsplat_pack_uv_grad_norm)
     raster = pkg("raster")
     nan = float("nan")
+    # (ONE compositing backward for all three: its float atomics land in a different order every launch)
     rgb_a = torch.full((N + 1, 3), nan, device=step.dev)
     com_r, uv_r = torch.full((N, 12), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
-    step.ctx.backward_render(gi, bg, rgb_a, com_r, uv_r)
+    step.ctx.backward_render(gi, bg, rgb_a, com_r, uv_r)  # clears the culled gaussians' rows of com_r / uv_r
     for lo, hi in step.chunk_bounds():
         step.ctx.backward_gaussians_split(step.params, cam, L, com_r, uv_r, lo, hi)
-    com_w, uv_w = torch.full((N, 12), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
-    step.ctx.backward_render(gi, bg, rgb_a, com_w, uv_w)
+    com_w, uv_w = torch.zeros(N, 12, device=step.dev), torch.zeros(N, device=step.dev)
     step.ctx.backward_gaussians_split(step.params, cam, L, com_w, uv_w)
     g = step.ctx.alloc_gradients(N, L, intermediates=("uv", "precompute_rgb"))
-    step.ctx.backward_pass(step.params, cam, gi, bg, L, g)
+    step.ctx.backward_gaussians(step.params, cam, L, g)
     com_p, rgb_p, uv_p = torch.full((N, 12), nan, device=step.dev), torch.full((N + 1, 3), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
     raster.pack_gradients_split(step.ctx, g, N, com_p, rgb_p)
     raster.pack_uv_grad_norm(step.ctx, g, N, uv_p)
@@ -59,10 +59,11 @@ def _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=None):
     assert torch.equal(com_r, com_w) and torch.equal(uv_r, uv_w), "the ranges do not add up to the whole backward"
     assert torch.equal(com_w, com_p) and torch.equal(uv_w, uv_p), "direct global-order rows differ from the packed compacted ones"
     assert torch.equal(rgb_a[:N], rgb_p[:N])
-    # (b) the same rows once more through the exchange, unchunked: every row of the exchange buffers is rewritten
+    # (b) the same compositing-backward rows once more through the exchange, unchunked.  The all-reduce is in place, so
+    # `common` holds sums by now: cleared here (what the compositing backward's pass does for the culled rows in a step);
+    # this rank's block of rgb_all still holds its own g_rgb (an in-place all-gather leaves the sender's block alone).
     step.chunks = 1
-    step._reduce_buf.fill_(nan)
-    step.ctx.backward_render(gi, bg, step.rgb, step.common, step.uv_norm_sum)
+    step._reduce_buf.zero_()
     step._rgb_gather = step.comm.all_gather_blocks(step.rgb_all, step.rgb, async_op=True)
     step.ctx.backward_gaussians_split(step.params, cam, L, step.common, step.uv_norm_sum)
     step.exchange_gradients(cam)
