@@ -42,10 +42,10 @@ def _chunked_vs_unchunked(torch, gdist, dp, L, W, H, c, cam, gi, comm=None):
     # what the compacted route gives (gsplat_backward_gaussians + gsplat_pack_gradients_split + gsplat_pack_uv_grad_norm)
     raster = pkg("raster")
     nan = float("nan")
-    # (ONE compositing backward for all three: its float atomics land in a different order every launch)
-    rgb_a = torch.full((N + 1, 3), nan, device=step.dev)
-    com_r, uv_r = torch.full((N, 12), nan, device=step.dev), torch.full((N,), nan, device=step.dev)
-    step.ctx.backward_render(gi, bg, rgb_a, com_r, uv_r)  # clears the culled gaussians' rows of com_r / uv_r
+    # (all on the compositing-backward rows of the step above: its float atomics land in a different order every launch,
+    # so it is NOT run again; the culled gaussians' rows, which its pass clears in a step, are zeros from the start here)
+    rgb_a = step.rgb.clone()  # this rank's block of rgb_all: its own g_rgb, untouched by the in-place all-gather
+    com_r, uv_r = torch.zeros(N, 12, device=step.dev), torch.zeros(N, device=step.dev)
     for lo, hi in step.chunk_bounds():
         step.ctx.backward_gaussians_split(step.params, cam, L, com_r, uv_r, lo, hi)
     com_w, uv_w = torch.zeros(N, 12, device=step.dev), torch.zeros(N, device=step.dev)
@@ -122,10 +122,9 @@ def test_view_sharded_step_two_ranks_one_gpu(tmp_path, world):
     for ex in ("split", "split_packed", "split_direct", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
-    assert (r[0]["split"] == r[0]["split_packed"]).all()
     full = r[0]["full"]
     scale = np.abs(full).mean()
-    for ex in ("split", "split_direct", "factored", "chunked"):
+    for ex in ("split", "split_packed", "split_direct", "factored", "chunked"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()  # views that saw each gaussian
@@ -241,10 +240,9 @@ def test_view_sharded_step_eight_thread_ranks(gpu, scene):
     for ex in ("split", "split_packed", "split_direct", "factored", "full", "chunked"):
         for k in range(1, world):
             assert (r[0][ex] == r[k][ex]).all(), f"{ex}: ranks 0 and {k} disagree"
-    assert (r[0]["split"] == r[0]["split_packed"]).all()
     full = r[0]["full"]
     scale = np.abs(full).mean()  # (each payload ran its own backward: float atomics, so payloads agree to rounding only)
-    for ex in ("split", "split_direct", "factored", "chunked"):
+    for ex in ("split", "split_packed", "split_direct", "factored", "chunked"):
         err = np.abs(r[0][ex] - full)
         assert err.max() <= 1e-4 * np.abs(full).max() + 1e-3 * scale, (ex, err.max())
         assert (r[0][ex][:, -1] == full[:, -1]).all()
@@ -371,6 +369,8 @@ def test_bench_headline_survives_the_payload_sweep(selftest, expect):
     if expect == "all ranks":
         assert str(sweep["split_direct"]).startswith("failed") and isinstance(sweep["split"], float) and isinstance(sweep["full"], float)
     elif expect == "one rank":
-        assert "status" in sweep and "sweep ended" in sweep["status"]
+        # rank 1 reports the failure through the store; rank 0 either sees the mixed votes ("sweep ended") or is still
+        # inside the payload's collective that rank 1 never joined, where only the guard's deadline ends it
+        assert "status" in sweep and ("sweep ended" in sweep["status"] or "did not finish" in sweep["status"])
     else:
         assert "status" in sweep and "did not finish" in sweep["status"]
