@@ -152,6 +152,8 @@ SIGNATURES = {
     "gsplat_context_set_binning_route": (_I, [_P, _I]),
     "gsplat_backward_render": (_I, [_P, _P, _F, _P, _P]),
     "gsplat_context_detach_forward_outputs": (_I, [_P]),
+    "gsplat_context_last_compaction": (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "gsplat_compact_rows_ranked": (_I, [_P, _P, _P, _I, _I, _P, _I, _P]),
     "gsplat_fill_f32": (_I, [_P, _S, _F, _P]),
     "gsplat_mask_selected_rows": (_I, [_P, _I, _P, _I, _P]),
     "gsplat_backward_render_split": (_I, [_P, _P, _F, _P, _P, _P, _P]),

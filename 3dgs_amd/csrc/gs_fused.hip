@@ -73,6 +73,7 @@ struct gsplat_context {
   // by render_fwd, and the order table made from it right behind the forward (off the backward's critical path)
   gs::DeviceBuffer tile_tops, tile_order;
   bool order_ready = false;  // tile_order belongs to the recorded forward
+  const unsigned char *last_mask = nullptr;  // the mask array the last COMPLETED forward wrote (gsplat_context_last_compaction)
   int *h_words = nullptr;  // pinned
   bool dense_route = false;  // binning route of the next forward (follows the last one's density)
   int forced_route = 0;      // gsplat_context_set_binning_route: 0 auto, 1 counting sort, 2 radix sorts
@@ -1130,6 +1131,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->have_forward = false;
   c->rows_ready = false;
   c->order_ready = false;
+  c->last_mask = nullptr;  // rank[] and compact_to_global are about to be overwritten
   {  // outputs the caller took over (gsplat_context_detach_forward_outputs) come back from the pool, at their old sizes
     gs::DeviceBuffer *outs[13];
     c->forward_outputs(outs);
@@ -1374,6 +1376,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     c->order_ready = ordered;
   }
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
+  c->last_mask = c->mask.as<unsigned char>();
   c->tan_fovx = tan_fovx; c->tan_fovy = tan_fovy; c->mh_dist = cfg->mh_dist;
   c->have_forward = !ro;  // a render-only forward leaves nothing for a backward
   if (out) {
@@ -1390,6 +1393,18 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     out->image = c->image.as<float>(); out->weight_per_pixel = c->T_px.as<float>();
     out->splats_per_pixel = c->n_px.as<int>();
   }
+  return GSPLAT_OK;
+}
+
+int gsplat_context_last_compaction(gsplat_context *c, const unsigned char **mask, const int **slots,
+                                   const int **compact_to_global, int *num_gaussians, int *num_culled) {
+  GS_REQUIRE(c != nullptr, "null context");
+  const bool have = c->n_forwards > 0 && c->last_mask != nullptr;
+  if (mask) *mask = have ? c->last_mask : nullptr;
+  if (slots) *slots = have ? c->rank.as<int>() : nullptr;
+  if (compact_to_global) *compact_to_global = have ? c->c2g.as<int>() : nullptr;
+  if (num_gaussians) *num_gaussians = have ? c->N : 0;
+  if (num_culled) *num_culled = have ? c->M : 0;
   return GSPLAT_OK;
 }
 

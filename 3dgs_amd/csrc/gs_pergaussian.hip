@@ -298,6 +298,34 @@ __global__ __launch_bounds__(kBlock) void masked_rows_kernel(const float *__rest
   }
 }
 
+// r05: compaction when the compacted slot of every kept row is already known (slots[i] = exclusive scan of the mask:
+// what a forward leaves in its context, gsplat_context_last_compaction) -- one launch, one thread per ROW for the narrow
+// strides (its slot is looked up once and its 4..24 bytes copied), one thread per element for the wide ones.
+template <int kStride>
+__global__ __launch_bounds__(kBlock) void ranked_rows_kernel(const float *__restrict__ src,
+                                                             const unsigned char *__restrict__ mask,
+                                                             const int *__restrict__ slots, int N, int stride_rt,
+                                                             float *__restrict__ dst, unsigned int room_rows) {
+  const unsigned int stride = kStride > 0 ? (unsigned int)kStride : (unsigned int)stride_rt;
+  if constexpr (kStride > 0 && kStride <= 6) {
+    const unsigned int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (unsigned int)N || !mask[i]) return;
+    const unsigned int slot = (unsigned int)slots[i];
+    if (slot >= room_rows) return;
+    const float *s = src + (size_t)i * kStride;
+    float *d = dst + (size_t)slot * kStride;
+#pragma unroll
+    for (int k = 0; k < kStride; ++k) d[k] = s[k];
+  } else {
+    const unsigned int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= (unsigned int)N * stride) return;
+    const unsigned int i = e / stride, k = e - i * stride;
+    if (!mask[i]) return;
+    const unsigned int slot = (unsigned int)slots[i];
+    if (slot < room_rows) dst[(size_t)slot * stride + k] = src[e];
+  }
+}
+
 // rows[slot] <- i for every set mask entry i (the index list of a compaction), slot < room
 __global__ __launch_bounds__(kBlock) void selected_rows_kernel(const unsigned char *__restrict__ mask,
                                                                const int *__restrict__ ranks,
@@ -553,6 +581,31 @@ int gsplat_compact_masked_array_bounded(const float *src, const unsigned char *m
   int selected = 0;
   for (int k = 0; k < kMaskSlices; ++k) selected += gs::host_words().p[k];
   *num_selected = selected;
+  return GSPLAT_OK;
+}
+
+int gsplat_compact_rows_ranked(const float *src, const unsigned char *mask, const int *slots, int N, int stride,
+                               float *dst, int dst_rows, void *stream) {
+  GS_REQUIRE(N >= 0 && stride > 0 && dst_rows >= 0, "N < 0, stride <= 0 or dst_rows < 0");
+  if (N == 0 || dst_rows == 0) return GSPLAT_OK;
+  GS_REQUIRE_DEV(src); GS_REQUIRE_DEV(mask); GS_REQUIRE_DEV(slots); GS_REQUIRE_DEV(dst);
+  GS_REQUIRE((long long)N * stride < 0xFFFFFFF0ll, "rows x stride exceed the 32-bit element index");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned int room = (unsigned int)dst_rows;
+#define GS_RANKED(S, THREADS) ranked_rows_kernel<S><<<gs::div_up((long long)(THREADS), kBlock), kBlock, 0, st>>>(src, mask, slots, N, stride, dst, room)
+  switch (stride) {
+    case 1: GS_RANKED(1, N); break;
+    case 2: GS_RANKED(2, N); break;
+    case 3: GS_RANKED(3, N); break;
+    case 4: GS_RANKED(4, N); break;
+    case 6: GS_RANKED(6, N); break;
+    case 9: GS_RANKED(9, (long long)N * 9); break;
+    case 24: GS_RANKED(24, (long long)N * 24); break;
+    case 45: GS_RANKED(45, (long long)N * 45); break;
+    default: GS_RANKED(0, (long long)N * stride); break;
+  }
+#undef GS_RANKED
+  GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
 

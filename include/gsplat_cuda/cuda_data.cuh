@@ -49,6 +49,29 @@ namespace gsplat_shim {
 // from the library's block pool (gsplat_pool_alloc: a freed block is handed to the next request of its size class, in
 // stream order), so the steady state of a training loop allocates nothing.  Unlike device_vector it does NOT
 // value-initialise new elements (every user overwrites them).
+// the workspace of the last rasterize_image call (raster.cuh sets it)
+inline gsplat_context *&last_context() { static gsplat_context *c = nullptr; return c; }
+
+// The compaction the last forward already computed, if `mask` IS the mask array that forward produced (ForwardPassData's
+// d_mask owns that very block since r05): slot of every kept row and the row of every slot, valid until the next
+// rasterize_image.  The reference host compacts ~25 arrays per iteration by pass_data.d_mask (cuda/trainer.cu:941-964,
+// 1028-1044); with the slots known each is ONE launch and no scan of the mask.
+struct known_compaction { const int *slots = nullptr, *rows = nullptr; };
+inline known_compaction compaction_of(const unsigned char *mask, size_t n, int num_culled) {
+  known_compaction k;
+  if (gsplat_context *ctx = last_context()) {
+    const unsigned char *m = nullptr;
+    const int *slots = nullptr, *c2g = nullptr;
+    int N = 0, M = 0;
+    if (gsplat_context_last_compaction(ctx, &m, &slots, &c2g, &N, &M) == GSPLAT_OK && m != nullptr && m == mask &&
+        (size_t)N == n && M == num_culled) {
+      k.slots = slots;
+      k.rows = c2g;
+    }
+  }
+  return k;
+}
+
 // gathers element e of a compaction on the fly: row e / STRIDE of the compacted array is row rows[e / STRIDE] of the source
 template <typename T, int STRIDE> struct gather_rows_fn {
   const T *src;
@@ -112,10 +135,10 @@ template <typename T> class device_array {
   // compaction into pool storage + a value-initialising allocation + a copy).  Anything else that looks at the elements
   // -- data(), begin(), a copy -- runs the compaction into pool storage first, so the object behaves as if it had run.
   // The source and the mask must stay as they are until then (they do at the reference's call sites).
-  void defer_compaction(const T *src, const unsigned char *mask, int N, int stride, int rows) {
+  void defer_compaction(const T *src, const unsigned char *mask, int N, int stride, int rows, known_compaction known) {
     release();
     size_ = (size_t)rows * (size_t)stride;
-    pend_ = pending_t{src, mask, N, stride, rows, true};
+    pend_ = pending_t{src, mask, N, stride, rows, true, known};
   }
   pointer data() { materialize(); return pointer(ptr_); }
   const_pointer data() const { materialize(); return const_pointer(ptr_); }
@@ -134,10 +157,14 @@ template <typename T> class device_array {
   // fill (and its stream synchronisation) that `device_vector v(n)` would add.
   operator thrust::device_vector<T>() const {
     if (pend_.on && size_ > 0 && size_ < 0xFFFFFFFFull) {  // gather straight into the new vector
-      device_array<int> rows((size_t)pend_.rows);
-      const int st = gsplat_mask_selected_rows(pend_.mask, pend_.N, thrust::raw_pointer_cast(rows.data()), pend_.rows, 0);
-      if (st != GSPLAT_OK) throw std::bad_alloc();
-      const int *rp = thrust::raw_pointer_cast(rows.data());
+      device_array<int> rows;
+      const int *rp = pend_.known.rows;  // the forward's compact_to_global, when the mask is the forward's own
+      if (!rp) {
+        rows.resize((size_t)pend_.rows);
+        const int st = gsplat_mask_selected_rows(pend_.mask, pend_.N, thrust::raw_pointer_cast(rows.data()), pend_.rows, 0);
+        if (st != GSPLAT_OK) throw std::bad_alloc();
+        rp = thrust::raw_pointer_cast(rows.data());
+      }
       const thrust::counting_iterator<unsigned int> zero(0u);
       const unsigned int n = (unsigned int)size_;
 #define GSPLAT_GATHER_INTO_VECTOR(S)                                                                                   \
@@ -168,6 +195,7 @@ template <typename T> class device_array {
     const unsigned char *mask = nullptr;
     int N = 0, stride = 0, rows = 0;
     bool on = false;
+    known_compaction known;
   };
   void materialize() const {
     if (!pend_.on) return;
@@ -179,9 +207,13 @@ template <typename T> class device_array {
     ptr_ = static_cast<T *>(fresh);
     cap_ = size_;
     static_assert(sizeof(T) == 4 || sizeof(T) == 1 || sizeof(T) == 16, "element sizes of the reference's arrays");
-    require_ok(gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(p.src), p.mask, p.N, p.stride,
-                                                   reinterpret_cast<float *>(ptr_), p.rows, nullptr, 0),
-               "compact_masked_array");
+    if (p.known.slots)
+      require_ok(gsplat_compact_rows_ranked(reinterpret_cast<const float *>(p.src), p.mask, p.known.slots, p.N, p.stride,
+                                            reinterpret_cast<float *>(ptr_), p.rows, 0), "compact_masked_array");
+    else
+      require_ok(gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(p.src), p.mask, p.N, p.stride,
+                                                     reinterpret_cast<float *>(ptr_), p.rows, nullptr, 0),
+                 "compact_masked_array");
   }
   void assign_raw(const T *src, size_t n) {
     resize(n);
@@ -294,20 +326,23 @@ gsplat_shim::device_array<typename Source::value_type> compact_masked_array(cons
   static_assert(sizeof(T) == 4, "rows are made of 4-byte elements (float / int)");
   static_assert(sizeof(typename Mask::value_type) == 1, "the mask is one byte per row (bool)");
   gsplat_shim::device_array<T> d_selected;
+  const unsigned char *mask_ptr = reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data()));
+  const gsplat_shim::known_compaction known = gsplat_shim::compaction_of(mask_ptr, d_mask.size(), num_culled);
   if constexpr (STRIDE >= 9) {  // the SH strides: deferred (see device_array::defer_compaction)
-    d_selected.defer_compaction(thrust::raw_pointer_cast(d_source.data()),
-                                reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data())),
-                                (int)d_mask.size(), STRIDE, num_culled);
+    d_selected.defer_compaction(thrust::raw_pointer_cast(d_source.data()), mask_ptr, (int)d_mask.size(), STRIDE, num_culled,
+                                known);
     return d_selected;
   }
   gsplat_shim::alloc_or_exit("compact_masked_array", [&] { d_selected.resize((size_t)num_culled * STRIDE); });
-  gsplat_shim::require_ok(
-      gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_source.data())),
-                                          reinterpret_cast<const unsigned char *>(thrust::raw_pointer_cast(d_mask.data())),
-                                          (int)d_mask.size(), STRIDE,
-                                          reinterpret_cast<float *>(thrust::raw_pointer_cast(d_selected.data())), num_culled,
-                                          nullptr, 0),
-      "compact_masked_array");
+  const float *src = reinterpret_cast<const float *>(thrust::raw_pointer_cast(d_source.data()));
+  float *dst = reinterpret_cast<float *>(thrust::raw_pointer_cast(d_selected.data()));
+  if (known.slots)
+    gsplat_shim::require_ok(gsplat_compact_rows_ranked(src, mask_ptr, known.slots, (int)d_mask.size(), STRIDE, dst, num_culled, 0),
+                            "compact_masked_array");
+  else
+    gsplat_shim::require_ok(gsplat_compact_masked_array_bounded(src, mask_ptr, (int)d_mask.size(), STRIDE, dst, num_culled,
+                                                                nullptr, 0),
+                            "compact_masked_array");
   return d_selected;
 }
 

@@ -30,7 +30,6 @@ inline gsplat_context *context_for(int capacity, int width, int height) {
   }
   return ctx;
 }
-inline gsplat_context *&last_context() { static gsplat_context *c = nullptr; return c; }
 
 }  // namespace gsplat_shim
 

@@ -444,6 +444,20 @@ int gsplat_context_set_binning_route(gsplat_context *ctx, int route);
  * rasterize_image shim (include/gsplat_cuda/raster.cuh) uses it instead of thirteen device-to-device copies.  The
  * context's fused backward is unavailable for that forward afterwards (the stand-alone operators take the arrays). */
 int gsplat_context_detach_forward_outputs(gsplat_context *ctx);
+/* The compaction the last completed forward of `ctx` already computed for its cull mask: *mask = the mask array that
+ * forward wrote (the pointer gsplat_forward_view reported, whoever owns the block now), *slots[i] = compacted slot of
+ * gaussian i where mask[i] is set (its exclusive scan; the entries of culled gaussians are unspecified),
+ * *compact_to_global[j] = gaussian of slot j, for N = *num_gaussians and M = *num_culled.  All of it is valid until the
+ * context's NEXT forward and describes the mask's contents as that forward wrote them.  NULL pointers when there is none.
+ * The drop-in compact_masked_array uses it when it is handed that very mask array (cuda/trainer.cu:941-964, 1028-1044:
+ * the host compacts ~25 arrays per iteration by pass_data.d_mask): gsplat_compact_rows_ranked then needs one launch and
+ * no scan of the mask. */
+int gsplat_context_last_compaction(gsplat_context *ctx, const unsigned char **mask, const int **slots,
+                                   const int **compact_to_global, int *num_gaussians, int *num_culled);
+/* compact_masked_array with the slots given: dst[slots[i], :] <- src[i, :] for every i with mask[i] set and
+ * slots[i] < dst_rows.  One launch. */
+int gsplat_compact_rows_ranked(const float *src, const unsigned char *mask, const int *slots, int N, int stride,
+                               float *dst, int dst_rows, void *stream);
 /* dst[0..n) <- value on `stream`, asynchronously (hipMemsetAsync for 0.0f).  What the drop-in headers route the host's
  * thrust::fill_n calls on float device vectors to (cuda_data.cuh: zero_grads' twelve fills, cuda/trainer.cu:247-261, each
  * of which otherwise ends in a stream synchronisation inside thrust). */

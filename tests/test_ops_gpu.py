@@ -424,3 +424,88 @@ def test_compact_with_trusted_count_matches_counted(gpu, orc):
         ops.scatter_masked_array(stride, b, d_mask, dst)
         want = orc.scatter_masked_array(ref, mask, stride, np.full(N * stride, -1.0, np.float32))
         assert (dst.cpu().numpy() == want).all(), stride
+
+
+def test_compaction_helpers_of_the_drop_in_headers(gpu, orc):
+    """r05 entry points behind include/gsplat_cuda/cuda_data.cuh: the bounded compaction (a count that is too small drops
+    rows instead of writing past dst), the compaction with known slots (gsplat_compact_rows_ranked: what a forward's
+    context already knows about its mask), the row list of a mask, and the asynchronous fill the thrust::fill_n overload
+    routes to -- each against the oracle's compaction / numpy."""
+    import ctypes
+    torch, lib = gpu, pkg("_lib").load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(11)
+    N = 70001
+    mask = rng.random(N) < 0.37
+    M = int(mask.sum())
+    d_mask = _dev(torch, mask.astype(np.uint8))
+    slots = _dev(torch, (np.cumsum(mask) - mask).astype(np.int32))  # exclusive scan of the mask
+    slots[~torch.as_tensor(mask).cuda()] = 2 ** 30  # entries of culled rows are unspecified: must never be used
+    rows = torch.full((M + 5,), -7, dtype=torch.int32, device="cuda")
+    assert lib.gsplat_mask_selected_rows(P(d_mask), N, P(rows), M, None) == 0
+    assert (rows[:M].cpu().numpy() == np.nonzero(mask)[0]).all() and (rows[M:] == -7).all()
+    for stride in (1, 2, 3, 4, 6, 9, 24, 45, 5):
+        src = rng.normal(size=N * stride).astype(np.float32)
+        ref = orc.compact_masked_array(src, mask, stride)
+        d_src = _dev(torch, src)
+        out = torch.full((M * stride + 64,), -3.0, device="cuda")
+        assert lib.gsplat_compact_rows_ranked(P(d_src), P(d_mask), P(slots), N, stride, P(out), M, None) == 0
+        assert (out[:M * stride].cpu().numpy() == ref).all() and (out[M * stride:] == -3.0).all(), stride
+        # room for fewer rows than are selected: the rest is dropped, nothing behind dst is touched (ADVICE r04)
+        short = M // 2
+        for fn, extra in ((lib.gsplat_compact_rows_ranked, (P(slots),)), (lib.gsplat_compact_masked_array_bounded, ())):
+            out = torch.full((M * stride + 64,), -3.0, device="cuda")
+            tail = (short, None) if extra else (short, None, None)
+            assert fn(P(d_src), P(d_mask), *extra, N, stride, P(out), *tail) == 0
+            assert (out[:short * stride].cpu().numpy() == ref[:short * stride]).all(), stride
+            assert (out[short * stride:] == -3.0).all(), stride
+    buf = torch.full((1000,), 5.0, device="cuda")
+    assert lib.gsplat_fill_f32(ctypes.c_void_p(buf.data_ptr() + 4 * 10), 900, 0.0, None) == 0
+    assert lib.gsplat_fill_f32(ctypes.c_void_p(buf.data_ptr() + 4 * 910), 37, -2.5, None) == 0
+    b = buf.cpu().numpy()
+    assert (b[:10] == 5).all() and (b[10:910] == 0).all() and (b[910:947] == -2.5).all() and (b[947:] == 5).all()
+
+
+def test_forward_outputs_can_be_handed_over(gpu, scene, orc):
+    """gsplat_context_detach_forward_outputs (r05: how the rasterize_image shim fills ForwardPassData without copies): the
+    thirteen output blocks stay valid in the caller's hands while the context runs its next forward into fresh pool
+    blocks -- and finds the returned ones there afterwards; gsplat_context_last_compaction describes the handed-over mask
+    until that next forward."""
+    import ctypes
+    torch, raster, lib = gpu, pkg("raster"), pkg("_lib").load()
+    N, W, H, L, _ = scene.WORKLOADS["small"]
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::4, 2] *= -1
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp = raster.device_params(params)
+    cams = [raster.device_camera(scene.make_camera(W, H, v)) for v in (0, 3)]
+    refs = [orc.rasterize(params, scene.make_camera(W, H, v), c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=8)
+            for v in (0, 3)]
+    f0 = ctx.rasterize_image(dp, cams[0], c, c["bg"], L)
+    ALL = ("mask", "uv_all", "xyz_c_all", "sigma", "conic", "J", "rgb", "radius", "sorted", "ranges", "image", "T", "n")
+    held = {k: f0[k] for k in ALL}  # views of the context's thirteen output blocks
+    ptrs = {k: v.data_ptr() for k, v in held.items()}
+    m, s, r = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    n_, m_ = ctypes.c_int(), ctypes.c_int()
+    assert lib.gsplat_context_last_compaction(ctx._h, ctypes.byref(m), ctypes.byref(s), ctypes.byref(r), ctypes.byref(n_), ctypes.byref(m_)) == 0
+    assert m.value == ptrs["mask"] and n_.value == N and m_.value == f0["num_culled"]
+    assert lib.gsplat_context_detach_forward_outputs(ctx._h) == 0
+    f1 = ctx.rasterize_image(dp, cams[1], c, c["bg"], L)  # runs into OTHER blocks
+    assert all(f1[k].data_ptr() != ptrs[k] for k in ptrs)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(held["image"].cpu().numpy(), refs[0]["image"], atol=2e-5)
+    assert (held["sorted"].cpu().numpy() == refs[0]["sorted"]).all() and (held["mask"].cpu().numpy().astype(bool) == refs[0]["mask"]).all()
+    np.testing.assert_allclose(f1["image"].cpu().numpy(), refs[1]["image"], atol=2e-5)
+    assert (f1["sorted"].cpu().numpy() == refs[1]["sorted"]).all()
+    lib.gsplat_context_last_compaction(ctx._h, ctypes.byref(m), None, None, None, None)
+    assert m.value == f1["mask"].data_ptr()  # the association moved on with the forward
+    for p in ptrs.values():  # the caller returns its blocks ...
+        assert lib.gsplat_pool_free(ctypes.c_void_p(p)) == 0
+    assert lib.gsplat_context_detach_forward_outputs(ctx._h) == 0
+    f2 = ctx.rasterize_image(dp, cams[0], c, c["bg"], L)  # ... and the next forward finds them in the pool
+    assert {f2[k].data_ptr() for k in ptrs} & set(ptrs.values())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(f2["image"].cpu().numpy(), refs[0]["image"], atol=2e-5)
+    for k in ALL:
+        assert lib.gsplat_pool_free(ctypes.c_void_p(f1[k].data_ptr())) == 0  # (the second forward's blocks, handed over above)
