@@ -273,6 +273,44 @@ def preprocess_bytes(M, N, L, lean):
     return alg, (read + write) * M + (12 + (5 if lean else 25)) * N
 
 
+def profiled_counters(workload):
+    """(counters dict | None, note | None) for `workload` from profiles/traffic.json -- the PMC passes of
+    tools/refresh_profiles.sh: HBM bytes per launch ((2 FETCH_SIZE + WRITE_SIZE) * 1024) and SQ_INSTS_VALU of the
+    compositing kernels -- reported only when they were measured on the sources the LOADED library was built from."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None, None
+    try:
+        tj = json.load(open(tfile))
+        have = importlib.import_module("3dgs_amd._lib").library_source_hash()
+        if tj.get("source_sha16") != have:
+            return None, (f"profile stale: profiles/traffic.json was measured on sources {tj.get('source_sha16')}, "
+                          f"this library is built from {have}; traffic / VALU counters not reported")
+        return (tj if workload == "config3" else tj.get("workloads", {}).get(workload)), None
+    except Exception:
+        return None, None
+
+
+def compositing_rooflines(S_eff, P, fwd_ms, bwd_ms, counters):
+    """HBM roofline entries of the two compositing kernels on SURVEY 8d's algorithmic bytes (40 / 76 B per needed list
+    entry + 20 B per pixel), with the PMC traffic and -- against the bound they actually run at -- the VALU issue figures
+    when counters of this build are at hand."""
+    out = {}
+    for key, kern, per, ms in (("render_forward", "render_fwd", 40, fwd_ms), ("render_backward", "render_bwd", 76, bwd_ms)):
+        if not ms or ms <= 0:
+            continue
+        e = hbm_entry(kern, per * S_eff + 20 * P, ms)
+        if counters and counters.get(key):
+            e["traffic"] = counters[key]
+            e["traffic_over_algorithmic"] = round(counters[key] / e["algorithmic_bytes"], 3)
+        if counters and counters.get(key + "_valu_insts"):
+            ginst = counters[key + "_valu_insts"] / (ms * 1e-3) / 1e9
+            e["valu_issue"] = {"valu_instructions_per_launch": counters[key + "_valu_insts"], "achieved": ginst,
+                               "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST}
+        out[key] = e
+    return out
+
+
 def extra_workload(torch, scene, raster, name, dev, reps=20):
     """A non-headline workload, per-stage times only (outside every timed region)."""
     N, W, H, L, _ = scene.WORKLOADS[name]
@@ -288,6 +326,7 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
         fwd = ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
         ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
     M, S = fwd["num_culled"], fwd["num_splats"]
+    S_eff = tile_max_sum(torch, fwd["n"], W, H)
     st = stage_pass(ctx, dp, dc, dgi, cfg, L, grads, reps)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -323,14 +362,27 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
             train_step(5 + it)
         torch.cuda.synchronize()
         train_it_s = reps / (time.perf_counter() - t0)
+        # the compositing kernels INSIDE that training iteration (loss and optimizer between them): their launch times
+        ctx.set_timing(True, stages=["render_forward", "render_backward"])
+        for it in range(reps):
+            train_step(5 + reps + it)
+        train_stage = ctx.get_timing()
+        ctx.set_timing(False)
         del dpt, opt, tg, lg, target
     out = {"N": N, "M": M, "S": S, "num_pairs": fwd["num_pairs"], "tile_list_mean": round(float(lens.float().mean().item()), 1),
            "tile_list_max": int(lens.max().item()), "ms_per_step": round(ms, 4), "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
            "preprocess": hbm_entry("preprocess (lean)", preprocess_bytes(M, N, L, True)[0], st["preprocess"][0],
                                    preprocess_bytes(M, N, L, True)[1]),
            "preprocess_backward": hbm_entry("preprocess_backward", 560 * M, st["preprocess_backward"][0])}
+    counters, note = profiled_counters(name)
+    out["S_eff"] = S_eff
+    out["roofline"] = compositing_rooflines(S_eff, W * H, st["render_forward"][0], st["render_backward"][0], counters)
+    if note:
+        out["roofline"]["note"] = note
     if train_it_s is not None:
         out["train_it_s"] = round(train_it_s, 1)
+        out["roofline_in_training_iteration"] = compositing_rooflines(S_eff, W * H, train_stage["render_forward"][0],
+                                                                      train_stage["render_backward"][0], counters)
     ctx.close()
     del dp, dgi, grads
     torch.cuda.empty_cache()
@@ -642,21 +694,9 @@ def run_rank(args, comm, device_index):
     alg_bytes = (76 * S_eff + 20 * P) if do_bwd else (40 * S_eff + 20 * P)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = valu_insts = valu_busy = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")  # filled from the rocprofv3 --pmc passes (profiles/README.md)
-    profile_note = None
-    if os.path.exists(tfile) and args.workload == "config3":
-        try:
-            tj = json.load(open(tfile))
-            # counters are per-launch properties of ONE build: only reported when the profile was taken on these sources
-            # ... and that build is the LOADED binary (its embedded hash), not merely the sources next to it
-            have = importlib.import_module("3dgs_amd._lib").library_source_hash()
-            if tj.get("source_sha16") == have:
-                traffic, valu_insts, valu_busy = tj.get(dom), tj.get(dom + "_valu_insts"), tj.get(dom + "_valu_busy")
-            else:
-                profile_note = (f"profile stale: profiles/traffic.json was measured on sources {tj.get('source_sha16')}, "
-                                f"this library is built from {have}; traffic / VALU counters not reported")
-        except Exception:
-            traffic = valu_insts = valu_busy = None
+    counters, profile_note = profiled_counters(args.workload)
+    if counters:
+        traffic, valu_insts, valu_busy = counters.get(dom), counters.get(dom + "_valu_insts"), counters.get(dom + "_valu_busy")
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                 "avg_launch_ms": dom_ms}

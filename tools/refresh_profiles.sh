@@ -4,7 +4,7 @@
 # tracing), traffic.json from them -- and THEN the bench line, so that it carries the counters of this very build;
 # everything lands under gpurun_out/<tag>_*, from where the summaries are copied to profiles/.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 python -c "import importlib; importlib.import_module('3dgs_amd._lib').build()"   # once, before anything touches the GPU
 export GSPLAT_NO_BUILD=1
@@ -19,7 +19,13 @@ export GSPLAT_NO_BUILD=1
   cp "$(ls -t gpurun_out/${TAG}_stats/*/*kernel_stats.csv | head -1)" gpurun_out/${TAG}_kernel_stats.csv
   bash profiles/run_pmc.sh gpurun_out/${TAG}_pmc > gpurun_out/${TAG}_pmc.log 2>&1
   python3 profiles/summarize_pmc.py gpurun_out/${TAG}_pmc > gpurun_out/${TAG}_pmc_summary.json
-  python3 profiles/make_traffic.py gpurun_out/${TAG}_pmc_summary.json > gpurun_out/${TAG}_traffic.json
+  # r05: the same counters and kernel summary on the garden-shaped workload (a trained capture's density: large splats,
+  # lists of ~1150 entries, 40 % culled), whose roofline entries the bench line carries next to the uniform scene's
+  bash profiles/run_pmc.sh gpurun_out/${TAG}_pmc_garden1200k garden1200k > gpurun_out/${TAG}_pmc_garden1200k.log 2>&1
+  python3 profiles/summarize_pmc.py gpurun_out/${TAG}_pmc_garden1200k > gpurun_out/${TAG}_pmc_summary_garden1200k.json
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats_garden1200k -- python3 $GRAFT_REPO_ROOT/tools/workload_stats.py garden1200k 30 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stats_garden1200k.log 2>&1)
+  cp "$(ls -t gpurun_out/${TAG}_stats_garden1200k/*/*kernel_stats.csv | head -1)" gpurun_out/${TAG}_garden1200k_kernel_stats.csv
+  python3 profiles/make_traffic.py gpurun_out/${TAG}_pmc_summary.json garden1200k=gpurun_out/${TAG}_pmc_summary_garden1200k.json > gpurun_out/${TAG}_traffic.json
 )
 cp gpurun_out/${TAG}_traffic.json profiles/traffic.json   # (on the box's copy of the tree: bench.py reads it from there)
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
