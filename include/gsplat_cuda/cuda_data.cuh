@@ -84,6 +84,24 @@ template <typename T, int STRIDE> struct gather_rows_fn {
   }
 };
 
+#ifndef GSPLAT_SHIM_NO_RAW_THRUST_VECTOR
+// A thrust::device_vector<T> whose n elements are allocated but NOT value-initialised: thrust's own `device_vector v(n)`
+// runs a fill kernel over the new elements and synchronises the stream behind it.  The conversions below fill such a
+// vector with their own (asynchronous) kernel or copy and move it into the thrust::device_vector<T> the host named --
+// the only cost left of `thrust::device_vector<float> d_sh_selected = compact_masked_array<45>(...)`
+// (cuda/trainer.cu:950-960) is then the vector's hipMalloc and, when the host destroys it, its hipFree.
+// Uses vector_base's protected members m_storage / m_size (a derived class may): if a rocThrust release renames them
+// this fails to compile -- -DGSPLAT_SHIM_NO_RAW_THRUST_VECTOR then selects the gather-iterator construction instead.
+template <typename T> struct uninitialized_device_vector : thrust::device_vector<T> {
+  explicit uninitialized_device_vector(size_t n) {
+    if (n) {
+      this->m_storage.allocate(n);
+      this->m_size = n;
+    }
+  }
+};
+#endif
+
 template <typename T> class device_array {
  public:
   using value_type = T;
@@ -156,6 +174,27 @@ template <typename T> class device_array {
   // vector is built from an iterator range: thrust allocates and runs one copy kernel, without the value-initialising
   // fill (and its stream synchronisation) that `device_vector v(n)` would add.
   operator thrust::device_vector<T>() const {
+#ifndef GSPLAT_SHIM_NO_RAW_THRUST_VECTOR
+    {
+      uninitialized_device_vector<T> v(size_);
+      if (size_) {
+        T *dst = thrust::raw_pointer_cast(v.data());
+        if (pend_.on) {  // the deferred compaction runs straight into the host's vector: no intermediate, no copy
+          const pending_t &p = pend_;
+          if (p.known.slots)
+            require_ok(gsplat_compact_rows_ranked(reinterpret_cast<const float *>(p.src), p.mask, p.known.slots, p.N, p.stride,
+                                                  reinterpret_cast<float *>(dst), p.rows, 0), "compact_masked_array");
+          else
+            require_ok(gsplat_compact_masked_array_bounded(reinterpret_cast<const float *>(p.src), p.mask, p.N, p.stride,
+                                                           reinterpret_cast<float *>(dst), p.rows, nullptr, 0),
+                       "compact_masked_array");
+        } else {
+          (void)hipMemcpyAsync(dst, ptr_, size_ * sizeof(T), hipMemcpyDeviceToDevice, 0);
+        }
+      }
+      return thrust::device_vector<T>(std::move(v));
+    }
+#endif
     if (pend_.on && size_ > 0 && size_ < 0xFFFFFFFFull) {  // gather straight into the new vector
       device_array<int> rows;
       const int *rp = pend_.known.rows;  // the forward's compact_to_global, when the mask is the forward's own
