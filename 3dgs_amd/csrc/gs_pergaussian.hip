@@ -316,6 +316,25 @@ __global__ __launch_bounds__(kBlock) void ranked_rows_kernel(const float *__rest
     float *d = dst + (size_t)slot * kStride;
 #pragma unroll
     for (int k = 0; k < kStride; ++k) d[k] = s[k];
+  } else if constexpr (kStride > 6) {
+    // wide rows (the SH strides 9 / 24 / 45): a thread moves one 16-byte piece of a row (rows are 4-byte aligned only:
+    // gs::f4u), so a 180-byte row is twelve lanes and a wave instruction moves five whole rows
+    constexpr unsigned int kPieces = (kStride + 3) / 4;
+    const unsigned int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= (unsigned int)N * kPieces) return;
+    const unsigned int i = e / kPieces, piece = e - i * kPieces;
+    if (!mask[i]) return;
+    const unsigned int slot = (unsigned int)slots[i];
+    if (slot >= room_rows) return;
+    const float *s = src + (size_t)i * kStride + 4 * piece;
+    float *d = dst + (size_t)slot * kStride + 4 * piece;
+    if (4 * piece + 3 < (unsigned int)kStride) {
+      *reinterpret_cast<gs::f4u *>(d) = *reinterpret_cast<const gs::f4u *>(s);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (4 * piece + k < (unsigned int)kStride) d[k] = s[k];
+    }
   } else {
     const unsigned int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= (unsigned int)N * stride) return;
@@ -606,9 +625,9 @@ int gsplat_compact_rows_ranked(const float *src, const unsigned char *mask, cons
     case 3: GS_RANKED(3, N); break;
     case 4: GS_RANKED(4, N); break;
     case 6: GS_RANKED(6, N); break;
-    case 9: GS_RANKED(9, (long long)N * 9); break;
-    case 24: GS_RANKED(24, (long long)N * 24); break;
-    case 45: GS_RANKED(45, (long long)N * 45); break;
+    case 9: GS_RANKED(9, (long long)N * 3); break;    // one thread per 16-byte piece of a row
+    case 24: GS_RANKED(24, (long long)N * 6); break;
+    case 45: GS_RANKED(45, (long long)N * 12); break;
     default: GS_RANKED(0, (long long)N * stride); break;
   }
 #undef GS_RANKED
