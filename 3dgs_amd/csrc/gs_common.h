@@ -112,6 +112,13 @@ struct DeviceBuffer {
   template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
 };
 
+// "Tell me when this pool block is returned": *slot is set to nullptr when `block` goes back to the pool
+// (gsplat_pool_free) -- a context remembers the mask array of its last forward by POINTER (gsplat_context_last_compaction),
+// and once the caller has freed that block the pointer may name somebody else's data.  One watch per slot: watching
+// again replaces the previous block; pool_unwatch(slot) before the slot's owner dies.
+void pool_watch(const void *block, const unsigned char **slot);
+void pool_unwatch(const unsigned char **slot);
+
 // Scratch slots of the stand-alone operators (the reference allocates thrust::device_vector
 // temporaries inside the same operators: cuda/culling.cu:400-463, cuda/spherical_harmonics.cu:76-79).
 enum ScratchSlot {

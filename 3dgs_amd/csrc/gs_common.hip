@@ -41,11 +41,20 @@ int DeviceBuffer::reserve(size_t want) {
   if (want <= bytes) return GSPLAT_OK;
   size_t grow = want + want / 4 + 256;
   if (pooled) {
-    // pool blocks are reused in stream order (gsplat_hip.h): no device synchronisation, no allocator call in the steady
-    // state.  The request is the plain size when the buffer comes back after a detach (the block it gave away is of
-    // exactly that class), with headroom when it grows.
-    if (ptr) { (void)gsplat_pool_free(ptr); ptr = nullptr; bytes = 0; }
-    else grow = want;
+    // The request is the plain size when the buffer comes back after a detach (the block it gave away is of exactly
+    // that class: no allocator call in the steady state of a loop that hands its outputs over every iteration), with
+    // headroom when it grows.  GROWING returns the old block to the pool, whose next taker may sit on another stream
+    // (two contexts on two torch streams): the device is synchronised first, as the hipMalloc path does before its
+    // hipFree -- growth only happens while sizes are still settling.
+    if (ptr) {
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) { set_error("scratch: hipDeviceSynchronize: %s", hipGetErrorString(e)); return GSPLAT_ERR_HIP; }
+      (void)gsplat_pool_free(ptr);
+      ptr = nullptr;
+      bytes = 0;
+    } else {
+      grow = want;
+    }
     ++generation;
     void *fresh = nullptr;
     const int rc = gsplat_pool_alloc(&fresh, grow);
@@ -140,6 +149,8 @@ std::mutex g_pool_mutex;
 std::unordered_map<void *, PoolBlock> g_pool_live, g_pool_idle_info;
 std::map<std::pair<int, size_t>, std::vector<void *>> g_pool_idle;  // (device, class size) -> cached blocks
 size_t g_pool_idle_bytes = 0, g_pool_live_bytes = 0;
+std::unordered_map<const void *, const unsigned char **> g_pool_watch;      // block -> slot to clear when it is freed
+std::unordered_map<const unsigned char **, const void *> g_pool_watch_of;   // slot -> the block it watches
 
 // size classes with three mantissa bits: at most 12.5 % of a block is slack, and the per-view sizes of a training run
 // (they follow the visible count and the instance count, which change a little from view to view) fall into the same
@@ -173,6 +184,26 @@ int pool_drop_idle_locked() {  // hipFree of every cached block (synchronises ea
   return GSPLAT_OK;
 }
 }  // namespace
+}  // namespace gs
+
+namespace gs {
+void pool_unwatch(const unsigned char **slot) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  auto it = g_pool_watch_of.find(slot);
+  if (it == g_pool_watch_of.end()) return;
+  g_pool_watch.erase(it->second);
+  g_pool_watch_of.erase(it);
+}
+void pool_watch(const void *block, const unsigned char **slot) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  auto it = g_pool_watch_of.find(slot);
+  if (it != g_pool_watch_of.end()) { g_pool_watch.erase(it->second); g_pool_watch_of.erase(it); }
+  if (!block) return;
+  auto old = g_pool_watch.find(block);  // (another slot watched this block: the newest watcher wins, the old one is cleared)
+  if (old != g_pool_watch.end()) { *old->second = nullptr; g_pool_watch_of.erase(old->second); g_pool_watch.erase(old); }
+  g_pool_watch[block] = slot;
+  g_pool_watch_of[slot] = block;
+}
 }  // namespace gs
 
 extern "C" {
@@ -223,6 +254,14 @@ int gsplat_pool_free(void *ptr) {
   }
   const gs::PoolBlock b = it->second;
   gs::g_pool_live.erase(it);
+  {
+    auto w = gs::g_pool_watch.find(ptr);
+    if (w != gs::g_pool_watch.end()) {  // somebody remembered this block by pointer: it stops meaning what it meant
+      *w->second = nullptr;
+      gs::g_pool_watch_of.erase(w->second);
+      gs::g_pool_watch.erase(w);
+    }
+  }
   gs::g_pool_live_bytes -= b.cls;
   gs::g_pool_idle[{b.device, b.cls}].push_back(ptr);
   gs::g_pool_idle_info[ptr] = b;

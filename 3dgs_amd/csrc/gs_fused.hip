@@ -136,6 +136,8 @@ struct gsplat_context {
     return b;
   }
   void release() {
+    gs::pool_unwatch(&last_mask);
+    last_mask = nullptr;
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
@@ -1131,6 +1133,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   c->have_forward = false;
   c->rows_ready = false;
   c->order_ready = false;
+  gs::pool_unwatch(&c->last_mask);
   c->last_mask = nullptr;  // rank[] and compact_to_global are about to be overwritten
   {  // outputs the caller took over (gsplat_context_detach_forward_outputs) come back from the pool, at their old sizes
     gs::DeviceBuffer *outs[13];
@@ -1377,6 +1380,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   }
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
   c->last_mask = c->mask.as<unsigned char>();
+  gs::pool_watch(c->last_mask, &c->last_mask);  // cleared when whoever ends up owning the block returns it to the pool
   c->tan_fovx = tan_fovx; c->tan_fovy = tan_fovy; c->mh_dist = cfg->mh_dist;
   c->have_forward = !ro;  // a render-only forward leaves nothing for a backward
   if (out) {

@@ -509,3 +509,17 @@ def test_forward_outputs_can_be_handed_over(gpu, scene, orc):
     np.testing.assert_allclose(f2["image"].cpu().numpy(), refs[0]["image"], atol=2e-5)
     for k in ALL:
         assert lib.gsplat_pool_free(ctypes.c_void_p(f1[k].data_ptr())) == 0  # (the second forward's blocks, handed over above)
+    # once the caller has returned the mask block of a forward, the context forgets that it described it: the pointer may
+    # name somebody else's data from now on
+    f3 = ctx.rasterize_image(dp, cams[1], c, c["bg"], L)
+    lib.gsplat_context_last_compaction(ctx._h, ctypes.byref(m), None, None, None, None)
+    assert m.value == f3["mask"].data_ptr()
+    assert lib.gsplat_context_detach_forward_outputs(ctx._h) == 0
+    assert lib.gsplat_pool_free(ctypes.c_void_p(f3["mask"].data_ptr())) == 0
+    lib.gsplat_context_last_compaction(ctx._h, ctypes.byref(m), None, None, None, None)
+    assert m.value is None
+    for k in ALL:
+        if k != "mask":
+            assert lib.gsplat_pool_free(ctypes.c_void_p(f3[k].data_ptr())) == 0
+    # (f2's arrays were the context's own when f3 overwrote them: the same blocks, returned just now)
+    assert lib.gsplat_pool_free(ctypes.c_void_p(f2["image"].data_ptr())) != 0  # already returned: refused, not freed twice
