@@ -1108,6 +1108,9 @@ int gsplat_context_destroy(gsplat_context *ctx) {
   (void)hipDeviceSynchronize();
   ctx->release();
   delete ctx;
+  // the context's pooled output arrays went back to the pool's idle lists: hand them to the runtime, or a process that
+  // creates and destroys contexts of different sizes would hoard one set of blocks per size
+  (void)gsplat_pool_release();
   return GSPLAT_OK;
 }
 

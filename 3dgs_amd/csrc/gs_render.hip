@@ -62,6 +62,9 @@
 #ifndef GS_BWD_PRIO
 #define GS_BWD_PRIO 1
 #endif
+#ifndef GS_BWD_CAP_AS_FORWARD
+#define GS_BWD_CAP_AS_FORWARD 1
+#endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
@@ -452,6 +455,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int red_idx = row_moments9_index(lane);
 #endif
   const bool red_lane = red_idx >= 0;
+#if GS_BWD_CAP_AS_FORWARD
+  const float alpha_cap = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_amdgcn_exp2f(kLog2AlphaMax))));
+#endif
   const unsigned int acc_lane = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)accb + (unsigned int)(red_idx * 8);
 
   for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
@@ -581,8 +587,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
           og = valid ? og : 0.0f;
           float alpha;  // fminf() would first canonicalise the selected value (a v_max_f32 og, og): the instruction saved
+#if GS_BWD_CAP_AS_FORWARD
+          // the cap the FORWARD composed with: it folds min(0.99, .) into the exponent, so a capped alpha is
+          // v_exp_f32(kLog2AlphaMax), two ulps below 0.99f -- rebuilding T with the exact 0.99f would drift from the
+          // forward's T by 1.5e-5 relative per capped splat; the same value from the same instruction here
+          asm("v_min_f32 %0, %2, %1" : "=v"(alpha) : "v"(og), "s"(alpha_cap));
+#else
           asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(alpha) : "v"(og));  // min(0.99f, og), kAlphaMax
           static_assert(kAlphaMax == 0.99f, "the literal above is 0.99f");
+#endif
           const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
           T *= inv;                                           // transmittance in front of this splat
           const float aT = alpha * T;
