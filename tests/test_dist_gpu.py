@@ -374,3 +374,23 @@ def test_bench_headline_survives_the_payload_sweep(selftest, expect):
         assert "status" in sweep and ("sweep ended" in sweep["status"] or "did not finish" in sweep["status"])
     else:
         assert "status" in sweep and "did not finish" in sweep["status"]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver starts the multi-GPU bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: the ranks come from the environment (no launcher of
+    ours in between), rank 0 prints the one line, every rank leaves with exit code 0 (gloo here: two ranks on one GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSPLAT_EXCHANGE")}
+    env.update(GSPLAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_NO_BUILD="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--workload", "small", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["backend"] == "gloo" and line["value"] > 0
+    assert set(line["exchange_ms_per_step"]) == SWEEP
