@@ -393,7 +393,7 @@ def reference_host_path(params, cam, gi, cfg, L, iterations=20):
     """The path the REFERENCE host drives, timed outside the timed region: tests/cpp/reference_host.cpp is a C++ host
     written against the drop-in headers only (include/gsplat_cuda/raster.cuh, cuda_data.cuh, cuda_backward.cuh) that runs,
     per iteration, what TrainerImpl::train does around the rasterizer (cuda/trainer.cu:1294-1360): a fresh
-    ForwardPassData, zero_grads, rasterize_image (the shim: full forward + 13 device-to-device copies into pass_data),
+    ForwardPassData, zero_grads, rasterize_image (the shim: full forward, its output blocks handed to pass_data),
     then backward_pass' eight compact_masked_array calls and the seven stand-alone backward operators
     (cuda/trainer.cu:941-1012).  A child process (its own HIP context); parity of the same binary at this size:
     tests/test_reference_host_gpu.py."""
@@ -412,8 +412,9 @@ def reference_host_path(params, cam, gi, cfg, L, iterations=20):
             out[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     f = out["fresh"]
     return {"what": "tests/cpp/reference_host.cpp: C++ host against include/gsplat_cuda/*.cuh, per iteration a fresh "
-                    "ForwardPassData + zero_grads + rasterize_image shim (all ForwardPassData arrays, 13 copies) + "
-                    "8 compact_masked_array + the 7 stand-alone backward operators (cuda/trainer.cu:941-1012, 1294-1360)",
+                    "ForwardPassData + zero_grads + rasterize_image shim (all ForwardPassData arrays, handed over without "
+                    "copies since r05) + 8 compact_masked_array + the 7 stand-alone backward operators "
+                    "(cuda/trainer.cu:941-1012, 1294-1360)",
             "ms_per_iteration": f["ms_per_iteration"], "it_s": 1e3 / f["ms_per_iteration"],
             "ms_zero_grads_and_rasterize_image": f["ms_zero_grads_and_rasterize_image"],
             "ms_backward_pass": f["ms_backward_pass"],
