@@ -83,6 +83,22 @@ def _worker(rank, world, port, out_dir):
     comm.all_gather_blocks(buf.view(world, shard), got_sum).wait()
     assert torch.equal(buf, want), "direct exchange differs from the all-reduce"
     np.save(os.path.join(out_dir, f"direct{rank}.npy"), buf.numpy())
+    # r05: the in-place all-gather (every rank's block IS its slot of the output) on a communicator of its own -- what
+    # the split exchange's headline step does; closing that group leaves the default group usable
+    own = gdist.TorchComm.own_group()
+    assert own.owned and own.world == world and own.rank == rank
+    slots = torch.zeros(world, N + 1, 3)
+    slots[rank] = float(10 + rank)
+    own.all_gather_blocks(slots, slots[rank], async_op=True).wait()
+    for rr in range(world):
+        assert (slots[rr] == float(10 + rr)).all()
+    t = torch.tensor([float(rank)])
+    own.all_reduce_max(t)
+    assert t.item() == world - 1
+    own.barrier()
+    own.close()
+    assert own.group is None
+    torch.distributed.all_reduce(torch.ones(2))  # the default group still works
     un = gdist.unpack(packed, L)
     assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3) and un["visible"].shape == (N,)
     assert params_all["xyz"].shape == (N, 3)
