@@ -65,6 +65,19 @@
 #ifndef GS_BWD_CAP_AS_FORWARD
 #define GS_BWD_CAP_AS_FORWARD 1
 #endif
+// r05: waves 2 and 3 -- idle while waves 0 and 1 staged a batch and while they run the flush's first step (124 slots
+// occupy two waves: 10 % of the kernel's wave cycles were waves 2 and 3 waiting at those two barriers) -- take the staging
+// over and REQUEST the next batch's list entries and records while the flush of the current batch runs; the values wait
+// in registers (live only between the trip loops: 12 bytes of scratch, touched twice per batch) for the LDS arrays to
+// become free.  The two dependent global round trips of a batch leave the tile's critical path: launch 0.2764 -> 0.2719 ms
+// on the benchmark scene, garden-shaped workload 0.319 -> 0.308 ms (profiles/r05_ab_split_staging.txt).  0: staging by the
+// slots' own threads (waves 0, 1) at the top of the batch (r04).
+#ifndef GS_BWD_SPLIT_STAGING
+#define GS_BWD_SPLIT_STAGING 1
+#endif
+#ifndef GS_BWD_ACC_CLEAR
+#define GS_BWD_ACC_CLEAR 0  // who clears the batch's sums under split staging: 0 waves 2-3 (measured best), 1 all four, 2 waves 0-1
+#endif
 #if GS_STAMP
 #define GS_STAMP_WORDS 16
 __device__ unsigned long long gs_stamp_buf[(1 << 16) * GS_STAMP_WORDS];
@@ -460,6 +473,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
   const unsigned int acc_lane = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)accb + (unsigned int)(red_idx * 8);
 
+#if GS_BWD_SPLIT_STAGING
+  // what waves 2 and 3 hold for the NEXT batch: slot (thread - 128)'s list entry, record and block mask
+  SplatRec pre = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  int pre_g = 0;
+  auto prefetch = [&](int next_base, int tt) {
+    const int slot = tt - 128;
+    if (tt >= 128 && next_base >= 0 && slot < min(kB, top - next_base)) {
+      pre_g = sorted[start + next_base + slot];
+      pre = load_record<kPacked>(pre_g, recs, raw);
+      if constexpr (kPacked) pre.r2.w = __uint_as_float((unsigned int)masks_in[start + next_base + slot]);
+    }
+  };
+  prefetch(((top - 1) / kB) * kB, tid);
+#endif
   for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
     const int count = min(kB, top - base);
     // an opaque per-batch copy of the thread index: the LDS addresses of staging and flush derive from it and are
@@ -473,6 +500,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
     __syncthreads();
     GS_LAP(st_bar);
+#if GS_BWD_SPLIT_STAGING
+    if (t >= 128) {  // waves 2, 3: the records requested during the previous flush go to LDS; they also clear the sums
+      const int slot = t - 128;
+      if (slot < count) {
+        SplatRec s = pre;
+        if constexpr (!kPacked) s.r2.w = __uint_as_float(block_hits(s, tx0, ty0));
+        stage_record(s);
+        s_r0[slot] = s.r0; s_r1[slot] = s.r1; s_r2[slot] = s.r2;
+        s_id[slot] = pre_g;
+      }
+#if GS_BWD_ACC_CLEAR == 0
+      for (int k = slot; k < kAcc * kB; k += 128) s_acc[k] = 0.0;
+#endif
+    }
+#if GS_BWD_ACC_CLEAR == 1
+    for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
+#elif GS_BWD_ACC_CLEAR == 2
+    if (t < 128)  // waves 0, 1 have nothing else to do here
+      for (int k = t; k < kAcc * kB; k += 128) s_acc[k] = 0.0;
+#endif
+#else
     if (t < count) {  // count <= kB
       const int g = sorted[start + base + t];
       SplatRec s = load_record<kPacked>(g, recs, raw);
@@ -490,6 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       s_id[t] = g;
     }
     for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
+#endif
     GS_LAP(st_stage);
     __syncthreads();
     GS_LAP(st_bar1);
@@ -649,6 +698,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
     GS_LAP(st_bar2);
+#if GS_BWD_SPLIT_STAGING
+    prefetch(base - kB, t);  // waves 2, 3: the next batch's loads are in flight while waves 0, 1 run the flush's first step
+#endif
     // flush, step 1: one thread per gaussian turns its nine raw sums into the nine gradient values (uniform control
     // flow, the double arithmetic once per gaussian instead of once per lane of a 16-lane group)
     if (t < count) {
