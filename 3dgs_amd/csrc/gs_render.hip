@@ -483,6 +483,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       pre_g = sorted[start + next_base + slot];
       pre = load_record<kPacked>(pre_g, recs, raw);
       if constexpr (kPacked) pre.r2.w = __uint_as_float((unsigned int)masks_in[start + next_base + slot]);
+      // (nothing here may WAIT for these loads: converting the record or computing the raw-array operator's block mask
+      // in this place holds waves 2 and 3 back from the barrier in front of the flush's second step -- measured +8 us,
+      // profiles/r05_ab_split_staging.txt; the values are first touched at staging time, a whole flush later)
     }
   };
   prefetch(((top - 1) / kB) * kB, tid);
