@@ -473,23 +473,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
   const unsigned int acc_lane = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)accb + (unsigned int)(red_idx * 8);
 
-#if GS_BWD_SPLIT_STAGING
+  // Split staging is for the fused path (packed 48-byte records: three loads that nothing touches until staging time).
+  // The raw-array operator builds its record from nine scattered values with arithmetic on them (make_record) and
+  // computes the block mask: requested early, that work would make waves 2 and 3 WAIT for the loads in front of the
+  // flush's second step (measured: gsplat_render_image_backward 0.38 -> 0.45 ms), so it keeps the r04 staging.
+  constexpr bool kSplit = GS_BWD_SPLIT_STAGING != 0 && kPacked;
   // what waves 2 and 3 hold for the NEXT batch: slot (thread - 128)'s list entry, record and block mask
   SplatRec pre = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   int pre_g = 0;
   auto prefetch = [&](int next_base, int tt) {
-    const int slot = tt - 128;
-    if (tt >= 128 && next_base >= 0 && slot < min(kB, top - next_base)) {
-      pre_g = sorted[start + next_base + slot];
-      pre = load_record<kPacked>(pre_g, recs, raw);
-      if constexpr (kPacked) pre.r2.w = __uint_as_float((unsigned int)masks_in[start + next_base + slot]);
-      // (nothing here may WAIT for these loads: converting the record or computing the raw-array operator's block mask
-      // in this place holds waves 2 and 3 back from the barrier in front of the flush's second step -- measured +8 us,
-      // profiles/r05_ab_split_staging.txt; the values are first touched at staging time, a whole flush later)
+    if constexpr (kSplit) {
+      const int slot = tt - 128;
+      if (tt >= 128 && next_base >= 0 && slot < min(kB, top - next_base)) {
+        pre_g = sorted[start + next_base + slot];
+        pre = load_record<kPacked>(pre_g, recs, raw);
+        pre.r2.w = __uint_as_float((unsigned int)masks_in[start + next_base + slot]);
+        // (nothing here may WAIT for these loads: converting the record in this place holds waves 2 and 3 back from the
+        // barrier in front of the flush's second step -- measured +8 us, profiles/r05_ab_split_staging.txt; the values are
+        // first touched at staging time, a whole flush later)
+      }
     }
   };
   prefetch(((top - 1) / kB) * kB, tid);
-#endif
   for (int base = ((top - 1) / kB) * kB; base >= 0; base -= kB) {
     const int count = min(kB, top - base);
     // an opaque per-batch copy of the thread index: the LDS addresses of staging and flush derive from it and are
@@ -503,45 +508,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
     __syncthreads();
     GS_LAP(st_bar);
-#if GS_BWD_SPLIT_STAGING
-    if (t >= 128) {  // waves 2, 3: the records requested during the previous flush go to LDS; they also clear the sums
-      const int slot = t - 128;
-      if (slot < count) {
-        SplatRec s = pre;
-        if constexpr (!kPacked) s.r2.w = __uint_as_float(block_hits(s, tx0, ty0));
-        stage_record(s);
-        s_r0[slot] = s.r0; s_r1[slot] = s.r1; s_r2[slot] = s.r2;
-        s_id[slot] = pre_g;
-      }
+    if constexpr (kSplit) {
+      if (t >= 128) {  // waves 2, 3: the records requested during the previous flush go to LDS; they also clear the sums
+        const int slot = t - 128;
+        if (slot < count) {
+          SplatRec s = pre;
+          stage_record(s);
+          s_r0[slot] = s.r0; s_r1[slot] = s.r1; s_r2[slot] = s.r2;
+          s_id[slot] = pre_g;
+        }
 #if GS_BWD_ACC_CLEAR == 0
-      for (int k = slot; k < kAcc * kB; k += 128) s_acc[k] = 0.0;
+        for (int k = slot; k < kAcc * kB; k += 128) s_acc[k] = 0.0;
 #endif
-    }
-#if GS_BWD_ACC_CLEAR == 1
-    for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
-#elif GS_BWD_ACC_CLEAR == 2
-    if (t < 128)  // waves 0, 1 have nothing else to do here
-      for (int k = t; k < kAcc * kB; k += 128) s_acc[k] = 0.0;
-#endif
-#else
-    if (t < count) {  // count <= kB
-      const int g = sorted[start + base + t];
-      SplatRec s = load_record<kPacked>(g, recs, raw);
-#if GS_ABLATE == 9
-      if constexpr (kPacked) {  // one more dependent global round trip: sensitivity to the staging latency
-        const float4 extra = recs[3 * (g ^ (int)(s.r0.x == 12345.678f)) + 1];
-        if (extra.x == 98765.4f) s.r0.x += 1.0f;
       }
+#if GS_BWD_ACC_CLEAR == 1
+      for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
+#elif GS_BWD_ACC_CLEAR == 2
+      if (t < 128)  // waves 0, 1 have nothing else to do here
+        for (int k = t; k < kAcc * kB; k += 128) s_acc[k] = 0.0;
 #endif
-      // the fused path hands over the forward's block masks; the raw-array operator computes them here
-      if constexpr (kPacked) s.r2.w = __uint_as_float((unsigned int)masks_in[start + base + t]);
-      else s.r2.w = __uint_as_float(block_hits(s, tx0, ty0));
-      stage_record(s);
-      s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
-      s_id[t] = g;
+    } else {
+      if (t < count) {  // count <= kB
+        const int g = sorted[start + base + t];
+        SplatRec s = load_record<kPacked>(g, recs, raw);
+#if GS_ABLATE == 9
+        if constexpr (kPacked) {  // one more dependent global round trip: sensitivity to the staging latency
+          const float4 extra = recs[3 * (g ^ (int)(s.r0.x == 12345.678f)) + 1];
+          if (extra.x == 98765.4f) s.r0.x += 1.0f;
+        }
+#endif
+        // the fused path hands over the forward's block masks; the raw-array operator computes them here
+        if constexpr (kPacked) s.r2.w = __uint_as_float((unsigned int)masks_in[start + base + t]);
+        else s.r2.w = __uint_as_float(block_hits(s, tx0, ty0));
+        stage_record(s);
+        s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
+        s_id[t] = g;
+      }
+      for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
     }
-    for (int k = t; k < kAcc * kB; k += 256) s_acc[k] = 0.0;
-#endif
     GS_LAP(st_stage);
     __syncthreads();
     GS_LAP(st_bar1);
@@ -701,9 +705,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
     GS_LAP(st_bar2);
-#if GS_BWD_SPLIT_STAGING
     prefetch(base - kB, t);  // waves 2, 3: the next batch's loads are in flight while waves 0, 1 run the flush's first step
-#endif
     // flush, step 1: one thread per gaussian turns its nine raw sums into the nine gradient values (uniform control
     // flow, the double arithmetic once per gaussian instead of once per lane of a 16-lane group)
     if (t < count) {
