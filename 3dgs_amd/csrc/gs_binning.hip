@@ -488,49 +488,62 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const unsigne
 // whole network runs in LDS on the integer keys.  Longer lists: in place in global memory.
 // kWaves = 2: the lists of up to 2 kWaveSortMax entries (128 threads, 16 KB of LDS: ten workgroups per CU -- the
 // register sorts are latency bound, so residency is what counts); kWaves = 4: everything longer.
-template <int kWaves>
+// kRun: entries per register-sorted run (one wave each).  r05: the hand-over class (lists up to 2 kWaveSortMax entries)
+// runs FOUR waves over runs of kWaveSortMax / 2 entries instead of two waves over runs of kWaveSortMax: the register
+// network of a 512-entry run is 45 stages over 8 entries per lane where the 1024-entry one is 55 over 16 -- less than half
+// the dependent chain the workgroup waits for, for one more merge level (GS_SORT_HALF_RUNS=0: the r04 shape).
+#ifndef GS_SORT_HALF_RUNS
+#define GS_SORT_HALF_RUNS 1
+#endif
+template <int kWaves, int kRun = kWaveSortMax>
 __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned long long *__restrict__ payload,
                                                                       const int *__restrict__ ranges, int num_tiles,
                                                                       int *__restrict__ sorted,
                                                                       const int *__restrict__ long_tiles) {
-  constexpr int kThreads = kWaves * 64, kLds = kWaves * kWaveSortMax;
-  static_assert(kLds <= kLdsSort, "LDS buffer");
+  constexpr int kThreads = kWaves * 64, kLds = kWaves * kRun;
+  constexpr int kClass = kLds / kWaveSortMax;  // 2: the hand-over class; 4, 8, 16: the larger ones
+  static_assert(kLds <= kLdsSort && kRun <= kWaveSortMax && kClass * kWaveSortMax == kLds, "LDS buffer");
   __shared__ unsigned long long buf[kLds];
   __shared__ int s_runs_ok;
-  // kWaves = 2 works through the wave kernel's hand-over list (long lists AND short ones whose keys have no double
+  // Class 2 works through the wave kernel's hand-over list (long lists AND short ones whose keys have no double
   // form).  The larger instantiations pick their tiles by length from `ranges` alone -- every list above kWaveSortMax
   // entries is handed over anyway -- so they do not depend on the wave kernel and run beside it on streams of their own
   // (SortFork): on a capture with thousands of entries per tile the four kernels used to run one after the other, the
   // last two for a handful of lists each (r03 garden-shaped workload: 43 + 28 + 41 + 64 + 66 us in a row).
-  const int count = kWaves == 2 ? long_tiles[0] : num_tiles;
+  const int count = kClass == 2 ? long_tiles[0] : num_tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
-    const int tile = kWaves == 2 ? long_tiles[1 + t] : t;
+    const int tile = kClass == 2 ? long_tiles[1 + t] : t;
     const int start = ranges[tile], len = ranges[tile + 1] - start;
-    // instantiation kWaves takes the handed-over lists of (kWaves / 2, kWaves] runs of kWaveSortMax entries; 2: every
-    // list up to two runs (short lists arrive here when a key has no double form); 16: also everything longer, in place
-    // in global memory
-    if ((kWaves > 2 && len <= kWaves / 2 * kWaveSortMax) || (kWaves < 16 && len > kWaves * kWaveSortMax)) continue;
+    // class K takes the handed-over lists of (K / 2, K] runs of kWaveSortMax entries; 2: every list up to two runs
+    // (short lists arrive here when a key has no double form); 16: also everything longer, in place in global memory
+    if ((kClass > 2 && len <= kClass / 2 * kWaveSortMax) || (kClass < 16 && len > kLds)) continue;
     int n2 = 1;
     while (n2 < len) n2 <<= 1;
     __syncthreads();  // buf is reused across iterations
     if (len <= kLds) {
       if (tid == 0) s_runs_ok = 1;
       __syncthreads();
-      const int run_len = min(kWaveSortMax, len - wave * kWaveSortMax);
-      if (len > kWaveSortMax && run_len > 0) {
+      const int run_len = min(kRun, len - wave * kRun);
+      if (len > kRun && run_len > 0) {
         // the last run of a list is shorter than the others: the smallest network that holds it
-        const unsigned long long *src = payload + start + wave * kWaveSortMax;
-        unsigned long long *dst = buf + wave * kWaveSortMax;
-        const bool ok = run_len <= 128   ? sort_run_to_lds<2>(src, run_len, lane, dst)
-                        : run_len <= 256 ? sort_run_to_lds<4>(src, run_len, lane, dst)
-                        : run_len <= 512 ? sort_run_to_lds<8>(src, run_len, lane, dst)
-                                         : sort_run_to_lds<kWaveSortMax / 64>(src, run_len, lane, dst);
+        const unsigned long long *src = payload + start + wave * kRun;
+        unsigned long long *dst = buf + wave * kRun;
+        bool ok;
+        if constexpr (kRun > 512)
+          ok = run_len <= 128   ? sort_run_to_lds<2>(src, run_len, lane, dst)
+               : run_len <= 256 ? sort_run_to_lds<4>(src, run_len, lane, dst)
+               : run_len <= 512 ? sort_run_to_lds<8>(src, run_len, lane, dst)
+                                : sort_run_to_lds<kWaveSortMax / 64>(src, run_len, lane, dst);
+        else
+          ok = run_len <= 128   ? sort_run_to_lds<2>(src, run_len, lane, dst)
+               : run_len <= 256 ? sort_run_to_lds<4>(src, run_len, lane, dst)
+                                : sort_run_to_lds<8>(src, run_len, lane, dst);
         if (!ok && lane == 0) s_runs_ok = 0;
       }
       __syncthreads();
-      if (len > kWaveSortMax && s_runs_ok) {
-        merge_sorted_runs<kThreads, kLds / kThreads>(buf, len, kWaveSortMax, tid);
+      if (len > kRun && s_runs_ok) {
+        merge_sorted_runs<kThreads, kLds / kThreads>(buf, len, kRun, tid);
       } else {
         __syncthreads();
         for (int i = tid; i < len; i += kThreads) buf[i] = payload[start + i];
@@ -606,8 +619,13 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
   GS_LAUNCH_CHECK();
   if (max_long > 0) {
     // workgroups beyond the list's length leave at once; ten (16 KB of LDS) resp. five (32 KB) fit on a CU
+#if GS_SORT_HALF_RUNS
+    tile_depth_sort_kernel<4, kWaveSortMax / 2><<<std::min(max_long, 8 * 256), 256, 0, st>>>(payload, ranges, num_tiles,
+                                                                                             sorted_out, long_tiles);
+#else
     tile_depth_sort_kernel<2><<<std::min(max_long, 10 * 256), 128, 0, st>>>(payload, ranges, num_tiles, sorted_out,
                                                                             long_tiles);
+#endif
     GS_LAUNCH_CHECK();
     for (int k = 0; k < 3; ++k)
       if (!forked[k] && wanted(k)) {
@@ -740,6 +758,10 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int T, int *__restric
   for (int k = 0; k < kRows; ++k) { table[(size_t)row_of(kRows * w + k) * T + t] = run; run += v[k]; }
 }
 
+#ifndef GS_SCATTER_PREFETCH
+#define GS_SCATTER_PREFETCH 1
+#endif
+
 // what bin_scatter_kernel needs to publish the forward's host record (pub == nullptr: nothing to publish)
 struct RecordSource {
   volatile unsigned long long *pub;
@@ -864,6 +886,52 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
   // one lane walking thousands of tiles alone decided this kernel's duration on scenes with large splats, so the wave
   // takes those one at a time, every lane testing every 64th tile of the rectangle's clipped span (the same functions
   // on the same broadcast inputs as the count in preprocess_kernel: the same instances).
+#if GS_SCATTER_PREFETCH
+  // r05: the chunk loop as a two-stage pipeline.  A chunk costs two DEPENDENT global round trips before any placement
+  // can start (rank[] -> the chunk's slots, then radius / uv / depth / hit mask of those slots), and the kernel runs one
+  // workgroup per CU (four waves per SIMD) -- little else hides them.  While chunk k is placed, the five loads of chunk
+  // k + 1 and the two rank reads of chunk k + 2 are in flight (94 -> ~106 VGPRs of the 128 this launch shape allows).
+  constexpr int kStep = kBinBlocks * (kBinThreads / 64);
+  const int c_first = (int)blockIdx.x + kBinBlocks * (int)(threadIdx.x >> 6);
+  auto slots_of = [&](int c, int &j, int &hi) {  // chunk c's compacted slots [j - lane, hi)
+    if (c >= walk_chunks) { j = 0; hi = 0; return; }
+    if (compact_walk) {
+      j = c * kBinChunk + lane;
+      hi = M;
+    } else {
+      j = rank[c * kBinChunk] + lane;
+      hi = rank[min(c * kBinChunk + kBinChunk, N)];
+    }
+  };
+  struct ChunkData { float4 rd; float u, v, z; unsigned long long hm; };
+  auto fetch = [&](int j, int hi, ChunkData &d) {
+    d.rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f); d.u = d.v = d.z = 0.0f; d.hm = 0ull;
+    if (j < hi) {
+      d.rd = reinterpret_cast<const float4 *>(radius)[j];
+      d.u = uv[2 * j]; d.v = uv[2 * j + 1];
+      d.z = xyz_c[3 * j + 2];
+      d.hm = hitmask[j];  // (read for every slot: rectangles above 64 tiles ignore it)
+    }
+  };
+  int j_cur, hi_cur, j_nxt, hi_nxt;
+  ChunkData cur, nxt;
+  slots_of(c_first, j_cur, hi_cur);
+  fetch(j_cur, hi_cur, cur);
+  slots_of(c_first + kStep, j_nxt, hi_nxt);
+  for (int c = c_first; c < walk_chunks; c += kStep) {
+    int j_nn, hi_nn;
+    slots_of(c + 2 * kStep, j_nn, hi_nn);  // two chunks ahead: the rank reads
+    fetch(j_nxt, hi_nxt, nxt);             // one chunk ahead: the data
+    const int j = j_cur, hi = hi_cur;
+    const float4 rd = cur.rd;
+    const float u = cur.u, v = cur.v;
+    unsigned long long pay = 0ull;
+    bool big = false;
+    Obb bob = {};          // of a lane whose rectangle goes to the cooperative loop: its OBB ...
+    TileRect bsp = {0, 0, 0, 0};  // ... and the span of tiles to test
+    if (j < hi) {
+      pay = ((unsigned long long)float_sort_bits(cur.z) << 32) | (unsigned int)j;
+#else
   for (int c = (int)blockIdx.x + kBinBlocks * (int)(threadIdx.x >> 6); c < walk_chunks; c += kBinBlocks * (kBinThreads / 64)) {
     int j, hi;
     if (compact_walk) {
@@ -883,11 +951,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
       rd = reinterpret_cast<const float4 *>(radius)[j];
       u = uv[2 * j]; v = uv[2 * j + 1];
       pay = ((unsigned long long)float_sort_bits(xyz_c[3 * j + 2]) << 32) | (unsigned int)j;
+#endif
       const TileRect r = coarse_rect(u, v, rd.x, ntx, nty);
       const int rh = r.y1 - r.y0;
       if (r.x1 > r.x0 && rh > 0) {
         if ((r.x1 - r.x0) * rh <= 64) {
+#if GS_SCATTER_PREFETCH
+          unsigned long long m = cur.hm;
+#else
           unsigned long long m = hitmask[j];
+#endif
           const float inv_rh = 1.0f / (float)rh;  // b / rh for b < 64, rh <= 64: exact through the float reciprocal
           while (m != 0ull) {
             const int b = __builtin_ctzll(m);
@@ -927,6 +1000,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(const float *_
         span_step(wk);
       }
     }
+#if GS_SCATTER_PREFETCH
+    j_cur = j_nxt; hi_cur = hi_nxt; cur = nxt;
+    j_nxt = j_nn; hi_nxt = hi_nn;
+#endif
   }
 }
 
