@@ -202,6 +202,24 @@ def main(argv=None, log=print):
             + ", ".join(f"{k} {v[0]:.3f}" for k, v in st.items() if v[1])
             + f"; view 0: M {f['num_culled']}, candidate pairs {f['num_pairs']}, instances {f['num_splats']}, tile lists "
               f"mean {lens.mean().item():.0f} / max {lens.max().item():.0f}", flush=True)
+        # r05: the compositing kernels' HBM roofline on THIS capture (40 / 76 bytes per list entry some pixel of
+        # its tile needs + 20 bytes per pixel), S_eff averaged over 16 of the training views
+        s_eff, inst = [], []
+        for cam, _ in views[:: max(1, len(views) // 16)][:16]:
+            fv = ctx.rasterize_image(dict(trainer.params), cam, trainer.cfg, 0.0, trainer.l_max)
+            H, W = fv["n"].shape
+            nty, ntx = (H + 15) // 16, (W + 15) // 16
+            npad = torch.zeros(nty * 16, ntx * 16, dtype=fv["n"].dtype, device=fv["n"].device)
+            npad[:H, :W] = fv["n"]
+            s_eff.append(int(npad.reshape(nty, 16, ntx, 16).amax(dim=(1, 3)).sum().item()))
+            inst.append(int(fv["num_splats"]))
+        se, P = sum(s_eff) / len(s_eff), float(H * W)
+        fw, bw = st["render_forward"][0], st["render_backward"][0]
+        log(f"[roofline] {len(s_eff)} views: instances {sum(inst) / len(inst):.0f}, S_eff {se:.0f} (entries some pixel of "
+            f"their tile needs); render_fwd {fw:.3f} ms = {(40 * se + 20 * P) / (fw * 1e-3) / 8e12 * 100:.1f} % of 8 TB/s on "
+            f"{(40 * se + 20 * P) / 1e6:.0f} MB, {fw * 1e9 / se:.0f} ps per needed entry; render_bwd {bw:.3f} ms = "
+            f"{(76 * se + 20 * P) / (bw * 1e-3) / 8e12 * 100:.1f} % on {(76 * se + 20 * P) / 1e6:.0f} MB, "
+            f"{bw * 1e9 / se:.0f} ps per needed entry", flush=True)
     train_psnr = trainer.evaluate(views[:: max(1, len(views) // 16)])
     test_psnr = trainer.evaluate(test_views) if test_views else float("nan")
     if rank == 0:
