@@ -49,11 +49,13 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero, long long zero_vec,
-                      unsigned short *masks_out, const int *order, int *tops_out);
+                      unsigned short *masks_out, const int *order, int *tops_out, const TileSegments *segments);
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st,
-                      const unsigned short *masks_in, hipEvent_t ev_start, hipEvent_t ev_stop, const int *order);
+                      const unsigned short *masks_in, hipEvent_t ev_start, hipEvent_t ev_stop, const int *order,
+                      const TileSegments *segments);
+int launch_tile_segments(const int *ranges, int num_tiles, const TileSegments &seg, hipStream_t st);
 int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *order, hipStream_t st);
 bool tile_order_supported(int num_tiles);
 }  // namespace gs
@@ -73,6 +75,12 @@ struct gsplat_context {
   // by render_fwd, and the order table made from it right behind the forward (off the backward's critical path)
   gs::DeviceBuffer tile_tops, tile_order;
   bool order_ready = false;  // tile_order belongs to the recorded forward
+  // r05: long lists split into segments for the backward (gs_render.h: TileSegments); allocated by the first forward that
+  // follows one with a list beyond kSegSplitMin
+  gs::DeviceBuffer seg_first, seg_extra, seg_chk;
+  int seg_cap = 0;          // extra segments the recorded forward had room for
+  bool seg_ready = false;   // the recorded forward wrote the table and the checkpoints
+  unsigned long long n_segmented_backwards = 0;
   const unsigned char *last_mask = nullptr;  // the mask array the last COMPLETED forward wrote (gsplat_context_last_compaction)
   int *h_words = nullptr;  // pinned
   bool dense_route = false;  // binning route of the next forward (follows the last one's density)
@@ -130,7 +138,8 @@ struct gsplat_context {
   size_t bytes() const {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
+                                     &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order,
+                                     &seg_first, &seg_extra, &seg_chk};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -140,7 +149,8 @@ struct gsplat_context {
     last_mask = nullptr;
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
-                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order};
+                               &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order,
+                               &seg_first, &seg_extra, &seg_chk};
     for (auto *p : all) p->release();
     fork.destroy();
     if (h_words) (void)hipHostFree(h_words);
@@ -159,6 +169,12 @@ constexpr int kBlock = 256;
 // GSPLAT_NO_TILE_ORDER=1: the backward takes its tiles in the plain XCD-run order (A/B of r04's heaviest-first order)
 bool gs_no_tile_order() {
   static const bool v = [] { const char *e = getenv("GSPLAT_NO_TILE_ORDER"); return e && e[0] == '1'; }();
+  return v;
+}
+
+// GSPLAT_NO_SEGMENTS=1: long lists stay whole in the backward (A/B of r05's segment split)
+bool gs_no_segments() {
+  static const bool v = [] { const char *e = getenv("GSPLAT_NO_SEGMENTS"); return e && e[0] == '1'; }();
   return v;
 }
 
@@ -1282,12 +1298,28 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // (The forward itself keeps the plain XCD-run order: dealt heaviest first by list length it was 10-14 us SLOWER on
     // the garden-shaped workload, profiles/r04_tile_order_ab.txt -- the list length says little about a dense tile's
     // forward, whose pixels saturate early, and neighbouring tiles no longer run side by side on one XCD's L2.)
+    // Lists beyond kSegSplitMin are split for the backward (gs_render.h: TileSegments) -- decided, like the order, by the
+    // previous forward: its longest list says whether there is anything to split, its instance count how many further
+    // segments to make room for (a list that does not fit stays whole).
+    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin && c->S > 0;
+    if (split) {
+      const size_t want = (((size_t)c->S + (size_t)c->S / 4) / gs::kSegEntries + 64 + 7) & ~(size_t)7;
+      if ((r = c->seg_first.reserve(((size_t)num_tiles + 8) * 4))) return r;
+      if ((r = c->seg_extra.reserve((want + 2) * sizeof(int2)))) return r;  // [want]: the count
+      if ((r = c->seg_chk.reserve(want * 256 * sizeof(float4)))) return r;
+      seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + want),
+             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want};
+      if ((r = gs::launch_tile_segments(c->ranges.as<int>(), num_tiles, seg, st))) return r;
+    }
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
                               ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
-                              ordered ? c->tile_tops.as<int>() : nullptr);
+                              ordered ? c->tile_tops.as<int>() : nullptr, split ? &seg : nullptr);
     if (r) return r;
+    c->seg_ready = split;
+    c->seg_cap = seg.extra_cap;
     c->mark(4, true, st);
     // the backward's tile order, behind the forward: nothing waits for it until the loss has produced dL/dimage
     if (ordered && (r = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return r;
@@ -1375,8 +1407,9 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
                                c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                                c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
                                ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
-                               ordered ? c->tile_tops.as<int>() : nullptr);
+                               ordered ? c->tile_tops.as<int>() : nullptr, nullptr);
     if (rc) return rc;
+    c->seg_ready = false;
     c->mark(4, true, st);
     if (ordered && (rc = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return rc;
     c->order_ready = ordered;
@@ -1456,13 +1489,19 @@ int gsplat_backward_render_split(gsplat_context *c, const float *grad_image, flo
   c->rows_zeroed = false;
   // stage 6 is this one launch: when it is timed, the launch itself stamps the two events (see launch_render_bwd)
   const bool timed = (c->timing >> 6) & 1u;
+  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (c->seg_ready)
+    seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + c->seg_cap),
+           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap};
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,
                                  c->blockmasks.as<unsigned short>(), timed ? c->ev[c->slot][12] : nullptr,
                                  timed ? c->ev[c->slot][13] : nullptr,
-                                 (c->order_ready && !gs_no_tile_order()) ? c->tile_order.as<int>() : nullptr);
+                                 (c->order_ready && !gs_no_tile_order()) ? c->tile_order.as<int>() : nullptr,
+                                 c->seg_ready ? &seg : nullptr);
   if (rc) return rc;
+  if (c->seg_ready) c->n_segmented_backwards++;
   if (c->order_ready && !gs_no_tile_order()) c->n_ordered_backwards++;
   if (timed) c->pending[c->slot][6] = 1;
   if (rgb_global) {
@@ -1587,9 +1626,10 @@ int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask)
 
 int gsplat_context_get_counters(gsplat_context *c, long long *out, int n) {
   GS_REQUIRE(c && out && n >= 0, "null argument");
-  const long long v[5] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards};
-  for (int k = 0; k < n && k < 5; ++k) out[k] = v[k];
-  return 5;
+  const long long v[6] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards,
+                          (long long)c->n_segmented_backwards};
+  for (int k = 0; k < n && k < 6; ++k) out[k] = v[k];
+  return 6;
 }
 
 int gsplat_context_set_render_only(gsplat_context *c, int enabled) {

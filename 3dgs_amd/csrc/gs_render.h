@@ -449,4 +449,26 @@ __device__ __forceinline__ int ordered_tile(const int *__restrict__ order, int b
 }
 constexpr int kOrderMaxRun = 2048;  // tiles per XCD run the order kernel handles (16384 tiles: the counting-sort limit)
 
+// r05 -- long tile lists, split for the BACKWARD.  One workgroup walks one tile's list batch after batch: a list of ten
+// thousand entries is eighty batches in a row, and on a trained capture (lists of 1100 entries on average, 9800 at most)
+// that ONE chain was the duration of the whole launch -- render_bwd 0.72 ms with the VALU 19 % busy.  The back-to-front
+// recurrence only needs, at a boundary b of the list, the transmittance in front of entry b and the colour composited
+// behind it; the forward passes both through anyway.  So for tiles whose list exceeds kSegSplitMin entries the forward
+// stores, at every kSegEntries-th entry, a per-pixel checkpoint {T_b, C_b} (C_b: the colour accumulated from the entries
+// in front of b, without the background), and the backward gives every segment [k kSegEntries, (k+1) kSegEntries) of
+// such a list a workgroup of its own: a pixel that stops behind the segment starts it from T_b and the colour
+// (image - C_b) / T_b behind it, a pixel that stops inside or in front of it from its final transmittance as before.
+// The gradient rows are added with atomics either way.  Segment 0 of every tile is the block the tile has always had;
+// the further segments of the split tiles are extra blocks in front of the main grid, listed in `extra`.
+constexpr int kSegEntries = 992;            // 4 forward batches = 8 backward batches
+constexpr int kSegSplitMin = 2 * kSegEntries;  // lists up to here stay whole
+struct TileSegments {
+  int *chk_first;          // [num_tiles]: checkpoint slot of the tile's first boundary, or -1: the tile is not split
+  int2 *extra;             // [extra_cap]: (tile, k) of the segments k >= 1
+  int *extra_count;        // [1]
+  float4 *chk;             // [slots][256]: one checkpoint per boundary, per pixel of the tile (thread order)
+  const float *image;      // the forward's image (the backward's view of the colour behind a boundary)
+  int extra_cap;           // room in `extra` = checkpoint slots (one boundary per further segment); a multiple of 8
+};
+
 }  // namespace gs

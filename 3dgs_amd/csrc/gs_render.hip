@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
                                                               int *__restrict__ n_out, float *__restrict__ T_out,
                                                               float *__restrict__ image, float4 *__restrict__ zero,
                                                               long long zero_vec, unsigned short *__restrict__ masks_out,
-                                                              const int *__restrict__ order, int *__restrict__ tops_out) {
+                                                              const int *__restrict__ order, int *__restrict__ tops_out,
+                                                              TileSegments seg) {
   __shared__ float4 s_r0[kBatch + 1], s_r1[kBatch + 1], s_r2[kBatch + 1];  // [kBatch]: the all-zero sentinel record
   __shared__ int s_tile_top;
   __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride + 2];
@@ -225,12 +226,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   unsigned long long satmask = __ballot(!inside);  // lanes whose pixel is saturated or outside the image
   int live = satmask != ~0ull ? 1 : 0;
 
+  static_assert(kSegEntries % kBatch == 0, "a segment boundary is a batch boundary of the forward");
+  const int chk_first = seg.chk ? seg.chk_first[tile] : -1;  // >= 0: a long list, checkpointed for the backward's segments
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
     // an opaque per-batch copy of the thread index (see render_bwd_kernel): staging and list-building addresses are
     // rebuilt per batch instead of living in registers across the compositing loop
     int t = tid;
     asm volatile("" : "+v"(t));
+    if (chk_first >= 0 && base > 0 && base % kSegEntries == 0)  // (gs_render.h: TileSegments)
+      seg.chk[(size_t)(chk_first + base / kSegEntries - 1) * 256 + t] = make_float4(T, ar, ag, ab);
 #if GS_STAMP
     ++st_batches;
     GS_LAP(st_lists);  // (prologue of the first batch; nothing between the batches)
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                               const float *__restrict__ grad_image, int width,
                                                               int height, int ntx, int num_tiles, float bg,
                                                               GradOut out, const unsigned short *__restrict__ masks_in,
-                                                              const int *__restrict__ order) {
+                                                              const int *__restrict__ order, TileSegments seg) {
   __shared__ float4 s_r0[kB + 1], s_r1[kB + 1];  // [kB]: the all-zero sentinel record
   // [slot][9]: rgb, S0, Sx, Sy, Sxx, Sxy, Syy.  Doubles on purpose: on gfx950 ds_add_f32 retires about one LANE
   // every three cycles while ds_add_f64 runs at LDS rate (profiles/microbench/lds_atomic_rate: 109 vs 16 cycles for
@@ -398,8 +403,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   float *s_res = reinterpret_cast<float *>(s_mix);
   static_assert(kB * 9 * 4 <= 16 * kB * 2 + kB * 16, "the flush values must not reach the sentinel record");
   __shared__ int s_top;
-  const int tile = ordered_tile(order, blockIdx.x, num_tiles);
-  if (tile >= num_tiles) return;
+  // which tile, and which segment of its list (gs_render.h: TileSegments; seg_a = 0, seg_end = -1: the whole list)
+  int tile, seg_a = 0, seg_end = -1, chk_slot = -1;
+  static_assert(kSegEntries % kB == 0, "a segment is a whole number of backward batches");
+  if (seg.chk && (int)blockIdx.x < seg.extra_cap) {  // the further segments come first: each is kSegEntries of work
+    const int e = (int)blockIdx.x;
+    if (e >= *seg.extra_count) return;
+    const int2 ex = seg.extra[e];
+    tile = ex.x;
+    seg_a = ex.y * kSegEntries;
+    seg_end = seg_a + kSegEntries;
+    chk_slot = seg.chk_first[tile] + ex.y;  // the checkpoint at this segment's far boundary (if the list reaches it)
+  } else {
+    // (extra_cap is a multiple of 8: the main blocks keep their XCDs)
+    tile = ordered_tile(order, seg.chk ? (int)blockIdx.x - seg.extra_cap : (int)blockIdx.x, num_tiles);
+    if (tile >= num_tiles) return;
+    if (seg.chk) {
+      const int cf = seg.chk_first[tile];
+      if (cf >= 0) { seg_end = kSegEntries; chk_slot = cf; }
+    }
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
 #if GS_STAMP
   const unsigned long long st_t0 = GS_NOW(), st_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const bool inside = px < width && py < height;
   const float fpx = (float)px, fpy = (float)py;
   const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
-  const int start = ranges[tile];
+  const int start = ranges[tile] + seg_a;
   const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
   const char *r2b = reinterpret_cast<const char *>(s_r2);
   char *accb = reinterpret_cast<char *>(s_acc);
@@ -440,6 +463,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // at bg instead of 0, T (colour - c) . grad already contains the reference's - T_final (bg . grad) / (1 - alpha)
   // term (cuda/render_backward.cu:139-151: c' = c + T_final bg / T_next obeys the same recurrence and starts at bg).
   float T = Tf, s = bg * g0 + bg * g1 + bg * g2;
+  if (seg_end >= 0) {  // a segment of a split list: entries [seg_a, seg_end) of the tile's list
+    if (n > seg_end) {
+      // the pixel stops behind this segment: it enters at the far boundary with the forward's checkpoint -- T in front of
+      // entry seg_end, and behind it the colour (image - C) / T (the image holds everything, the background included)
+      const int pid = py * width + px;
+      const float4 ck = seg.chk[(size_t)chk_slot * 256 + tid];
+      T = ck.x;
+      const float inv = __builtin_amdgcn_rcpf(ck.x);
+      s = (g0 * (seg.image[3 * pid] - ck.y) + g1 * (seg.image[3 * pid + 1] - ck.z) + g2 * (seg.image[3 * pid + 2] - ck.w)) * inv;
+      n = seg_end - seg_a;
+    } else {
+      n = max(n - seg_a, 0);  // it stops inside the segment or in front of it: as an unsplit list from here on
+    }
+  }
   const int row_top_v = row_max_int(n);
   const int rt0 = __builtin_amdgcn_readlane(row_top_v, 0), rt1 = __builtin_amdgcn_readlane(row_top_v, 16);
   const int rt2 = __builtin_amdgcn_readlane(row_top_v, 32), rt3 = __builtin_amdgcn_readlane(row_top_v, 48);
@@ -847,17 +884,48 @@ int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *or
 }
 bool tile_order_supported(int num_tiles) { return ((num_tiles + 7) >> 3) <= kOrderMaxRun; }
 
+// r05: which tiles' lists are split for the backward (gs_render.h: TileSegments).  One thread per tile; the extra segments of
+// all split tiles cannot exceed (instances / kSegEntries), which is what `extra` and the checkpoint pool are sized for.
+__global__ __launch_bounds__(256) void tile_segments_kernel(const int *__restrict__ ranges, int num_tiles, TileSegments seg) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= num_tiles) return;
+  const int len = ranges[t + 1] - ranges[t];
+  int first = -1;
+  if (len > kSegSplitMin) {
+    const int nseg = (len + kSegEntries - 1) / kSegEntries;
+    // (a list that does not fit any more stays whole: the launch's room follows the previous forward's instance count)
+    if (*(volatile int *)seg.extra_count + nseg - 1 <= seg.extra_cap) {
+      const int pos = atomicAdd(seg.extra_count, nseg - 1);
+      if (pos + nseg - 1 <= seg.extra_cap) {
+        first = pos;
+        for (int k = 1; k < nseg; ++k) seg.extra[pos + k - 1] = make_int2(t, k);
+      } else {
+        atomicSub(seg.extra_count, nseg - 1);
+      }
+    }
+  }
+  seg.chk_first[t] = first;
+}
+
+int launch_tile_segments(const int *ranges, int num_tiles, const TileSegments &seg, hipStream_t st) {
+  GS_HIP(hipMemsetAsync(seg.extra_count, 0, sizeof(int), st));
+  tile_segments_kernel<<<div_up(num_tiles, 256), 256, 0, st>>>(ranges, num_tiles, seg);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
 // host-side launchers shared with gs_fused.hip ------------------------------------------
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero,
-                      long long zero_vec, unsigned short *masks_out, const int *order, int *tops_out) {
+                      long long zero_vec, unsigned short *masks_out, const int *order, int *tops_out, const TileSegments *segments) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
+  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (recs) {
-    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out);
+    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out, seg);
   } else {
-    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr, order, tops_out);
+    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr, order, tops_out, seg);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -866,9 +934,11 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in,
-                      hipEvent_t ev_start, hipEvent_t ev_stop, const int *order) {
+                      hipEvent_t ev_start, hipEvent_t ev_stop, const int *order, const TileSegments *segments) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
-  const dim3 grid(tile_grid(num_tiles)), block(256);
+  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  // split lists: their further segments are extra blocks in front of the main grid (blocks beyond the count leave at once)
+  const dim3 grid(tile_grid(num_tiles) + (seg.chk ? seg.extra_cap : 0)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   GradOut out = {rows, g_rgb, g_opacity, g_uv, g_conic};
   if (recs && rows && ev_start && ev_stop) {
@@ -876,15 +946,15 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
     // its completion signal.  Two hipEventRecord calls around the launch are barrier packets of their own and kept the
     // GPU idle for ~11 us before and ~6 us after the kernel in every step they were on.
     hipExtLaunchKernelGGL((render_bwd_kernel<true, true, GS_BWD_BATCH>), grid, block, 0, st, ev_start, ev_stop, 0, recs, none,
-                          sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
+                          sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order, seg);
   } else if (recs && rows) {
-    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
+    render_bwd_kernel<true, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order, seg);
   } else if (recs) {
-    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
+    render_bwd_kernel<true, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(recs, none, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order, seg);
   } else if (rows) {  // the reference operator's input arrays, gradient rows out (gsplat_render_image_backward stages them)
-    render_bwd_kernel<false, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
+    render_bwd_kernel<false, true, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order, seg);
   } else {
-    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order);
+    render_bwd_kernel<false, false, GS_BWD_BATCH><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, out, masks_in, order, seg);
   }
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
@@ -917,7 +987,7 @@ int gsplat_render_image(const float *uv, const float *opacity, const float *coni
   gs::RawSplats raw = {uv, opacity, conic, rgb};
   return gs::launch_render_fwd(nullptr, &raw, sorted_splats, splat_range_by_tile, image_width, image_height,
                                background_opacity, splats_per_pixel, weight_per_pixel, image, (hipStream_t)stream, nullptr,
-                               0, nullptr, nullptr, nullptr);
+                               0, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"
@@ -997,7 +1067,7 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
     GS_HIP(hipMemsetAsync(rows.ptr, 0, (size_t)bound * 64, st));
     rc = gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr, nullptr);
+                               rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
     rows_to_arrays_kernel<<<gs::div_up(bound, 256), 256, 0, st>>>(rows.as<float4>(), bound, grad_rgb, grad_opacity, grad_uv,
                                                                   grad_conic);
@@ -1006,7 +1076,7 @@ int gsplat_render_image_backward(const float *uvs, const float *opacity, const f
   }
   return gs::launch_render_bwd(nullptr, &raw, sorted_splats, splat_range_by_tile, num_splats_per_pixel,
                                final_weight_per_pixel, grad_image, image_width, image_height, background_opacity,
-                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, st, nullptr, nullptr, nullptr, nullptr);
+                               nullptr, grad_rgb, grad_opacity, grad_uv, grad_conic, st, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

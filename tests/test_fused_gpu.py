@@ -564,6 +564,53 @@ def test_very_long_tile_lists(gpu, scene, orc):
     _check_forward(ctx.rasterize_image(raster.device_params(params), raster.device_camera(cam), c, 0.5, L), ref)
 
 
+def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
+    """r05 (gs_render.h: TileSegments): once a forward has seen a list beyond 1984 entries, the next forward stores a
+    per-pixel checkpoint {T, colour so far} at every 992nd entry of such lists and the backward walks each segment with a
+    workgroup of its own.  Lists of 2 100 .. 7 000 entries whose pixels stop in front of, inside and behind the segment
+    boundaries (opacities from faint to opaque); the gradients must be the oracle's, and the first (unsplit) backward's."""
+    torch, raster = gpu, pkg("raster")
+    N, W, H, L = 24000, 160, 96, 1
+    params = scene.make_gaussians(N, W, H, L)
+    cam = scene.make_camera(W, H)
+    rng = np.random.default_rng(11)
+    for lo, hi, (cu, cv), spread in ((2000, 4200, (24.0, 24.0), 5.0), (4200, 9200, (88.0, 40.0), 7.0),
+                                     (9200, 16200, (136.0, 72.0), 4.0), (16200, 18200, (40.0, 72.0), 3.0)):
+        k = hi - lo
+        z = rng.uniform(3.0, 9.0, k)
+        u, v = cu + rng.uniform(-spread, spread, k), cv + rng.uniform(-spread, spread, k)
+        params["xyz"][lo:hi, 0] = (u - W / 2) * z / cam["fx"]
+        params["xyz"][lo:hi, 1] = (v - H / 2) * z / cam["fy"]
+        params["xyz"][lo:hi, 2] = z
+        params["scale"][lo:hi] = np.log(rng.uniform(0.004, 0.012, (k, 3)))
+        params["opacity"][lo:hi] = rng.choice([-5.0, -4.0, -3.0, -1.0, 3.0], size=k, p=[0.45, 0.3, 0.15, 0.08, 0.02])
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    ctx.set_binning_route(1)
+    dp, dc = raster.device_params(params), raster.device_camera(cam)
+    gi = scene.make_grad_image(W, H)
+    gi_d = torch.as_tensor(gi).cuda()
+    ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=8)
+    lens = np.diff(ref["ranges"])
+    assert lens.max() > 5 * 992 and ((lens > 1984) & (lens < 3 * 992)).any() and ((lens > 992) & (lens <= 1984)).any()
+    bref = orc.backward_pass(ref, cam, gi, c["bg"], L, threads=8)
+    whole = None
+    for it in range(3):
+        fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
+        _check_forward(fwd, ref)
+        grads = ctx.alloc_gradients(fwd["num_culled"], L, intermediates=True)
+        ctx.backward_pass(dp, dc, gi_d, c["bg"], L, grads)
+        assert ctx.counters()["segmented_backwards"] == it, "the split follows the forward before"
+        _check_backward(grads, bref)
+        assert_grad_close(_np(grads["precompute_rgb"]), bref["rgb_pre"], "grad_precompute_rgb")
+        got = {k: _np(grads[k]).copy() for k in ("precompute_rgb", "conic", "uv", "opacity")}
+        if whole is None:
+            whole = got
+        else:
+            for k in whole:  # the same sums in another order of the atomics, plus the checkpoint's rounding
+                assert_grad_close(got[k], whole[k], k + " (segments vs whole lists)")
+
+
 def test_factored_exchange_equals_full_rows(gpu, scene):
     """Simulates a 3-rank view-sharded step on one GPU: per-view factored rows, summed like the all-reduce would,
     then unpacked, must equal the sum of the full packed rows of the three views."""
