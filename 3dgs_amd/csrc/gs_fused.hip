@@ -55,7 +55,7 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st,
                       const unsigned short *masks_in, hipEvent_t ev_start, hipEvent_t ev_stop, const int *order,
                       const TileSegments *segments);
-int launch_tile_segments(const int *ranges, int num_tiles, const TileSegments &seg, hipStream_t st);
+int launch_tile_segments(const int *ranges, const int *tops, int num_tiles, const TileSegments &seg, hipStream_t st);
 int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *order, hipStream_t st);
 bool tile_order_supported(int num_tiles);
 }  // namespace gs
@@ -1299,24 +1299,25 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // the garden-shaped workload, profiles/r04_tile_order_ab.txt -- the list length says little about a dense tile's
     // forward, whose pixels saturate early, and neighbouring tiles no longer run side by side on one XCD's L2.)
     // Lists beyond kSegSplitMin are split for the backward (gs_render.h: TileSegments) -- decided, like the order, by the
-    // previous forward: its longest list says whether there is anything to split, its instance count how many further
-    // segments to make room for (a list that does not fit stays whole).
-    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin && c->S > 0;
+    // previous forward: its longest list says whether there is anything to split; the room for extra blocks follows what
+    // the tiles of the previous forward asked for (a list that does not fit stays whole).
+    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin;
     if (split) {
-      const size_t want = (((size_t)c->S + (size_t)c->S / 4) / gs::kSegEntries + 64 + 7) & ~(size_t)7;
+      const size_t slots = cap / gs::kSegEntries + 2;  // (gs_render.h: segment_slot)
+      const size_t asked = (size_t)*reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 6));
+      const size_t want = std::min(slots, (asked + asked / 2 + 256 + 7) & ~(size_t)7);
       if ((r = c->seg_first.reserve(((size_t)num_tiles + 8) * 4))) return r;
       if ((r = c->seg_extra.reserve((want + 2) * sizeof(int2)))) return r;  // [want]: the count
-      if ((r = c->seg_chk.reserve(want * 256 * sizeof(float4)))) return r;
+      if ((r = c->seg_chk.reserve(slots * 256 * sizeof(float4)))) return r;
       seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + want),
-             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want};
-      if ((r = gs::launch_tile_segments(c->ranges.as<int>(), num_tiles, seg, st))) return r;
+             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want, reinterpret_cast<int *>(c->d_pub + 6)};
     }
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
                               ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
-                              ordered ? c->tile_tops.as<int>() : nullptr, split ? &seg : nullptr);
+                              (ordered || split) ? c->tile_tops.as<int>() : nullptr, split ? &seg : nullptr);
     if (r) return r;
     c->seg_ready = split;
     c->seg_cap = seg.extra_cap;
@@ -1324,6 +1325,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // the backward's tile order, behind the forward: nothing waits for it until the loss has produced dL/dimage
     if (ordered && (r = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return r;
     c->order_ready = ordered;
+    // ... and which segments of the long lists get a block of their own
+    if (split && (r = gs::launch_tile_segments(c->ranges.as<int>(), c->tile_tops.as<int>(), num_tiles, seg, st))) return r;
     return GSPLAT_OK;
   };
   // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
@@ -1489,10 +1492,10 @@ int gsplat_backward_render_split(gsplat_context *c, const float *grad_image, flo
   c->rows_zeroed = false;
   // stage 6 is this one launch: when it is timed, the launch itself stamps the two events (see launch_render_bwd)
   const bool timed = (c->timing >> 6) & 1u;
-  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   if (c->seg_ready)
     seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + c->seg_cap),
-           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap};
+           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap, nullptr};
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,

@@ -454,21 +454,34 @@ constexpr int kOrderMaxRun = 2048;  // tiles per XCD run the order kernel handle
 // that ONE chain was the duration of the whole launch -- render_bwd 0.72 ms with the VALU 19 % busy.  The back-to-front
 // recurrence only needs, at a boundary b of the list, the transmittance in front of entry b and the colour composited
 // behind it; the forward passes both through anyway.  So for tiles whose list exceeds kSegSplitMin entries the forward
-// stores, at every kSegEntries-th entry, a per-pixel checkpoint {T_b, C_b} (C_b: the colour accumulated from the entries
-// in front of b, without the background), and the backward gives every segment [k kSegEntries, (k+1) kSegEntries) of
-// such a list a workgroup of its own: a pixel that stops behind the segment starts it from T_b and the colour
-// (image - C_b) / T_b behind it, a pixel that stops inside or in front of it from its final transmittance as before.
-// The gradient rows are added with atomics either way.  Segment 0 of every tile is the block the tile has always had;
-// the further segments of the split tiles are extra blocks in front of the main grid, listed in `extra`.
-constexpr int kSegEntries = 992;            // 4 forward batches = 8 backward batches
-constexpr int kSegSplitMin = 2 * kSegEntries;  // lists up to here stay whole
+// stores, at every kSegEntries-th entry it reaches, a per-pixel checkpoint {T_b, C_b} (C_b: the colour accumulated from
+// the entries in front of b, without the background), and the backward gives every segment [k kSegEntries,
+// (k+1) kSegEntries) that some pixel of the tile reaches a workgroup of its own: a pixel that stops behind the segment
+// starts it from T_b and the colour (image - C_b) / T_b behind it, a pixel that stops inside or in front of it from its
+// final transmittance as before.  The gradient rows are added with atomics either way.
+//   Checkpoint slots need no table: the boundary k >= 1 of the tile whose list starts at instance r has the slot
+// r / kSegEntries + k (boundaries are kSegEntries instances apart inside a list and further apart across lists, so no two
+// share a slot; the pool has room / kSegEntries + 2 slots).  Which segments exist is decided BEHIND the forward, from the
+// tiles' largest stop indices (tile_segments_kernel): segment 0 of every tile is the block the tile has always had, the
+// further segments are extra blocks in front of the main grid, listed in `extra`; granted[t] = how many tile t got
+// (0: its block walks the whole list, also when the launch's room for extra blocks was used up).
+#ifndef GS_SEG_ENTRIES
+#define GS_SEG_ENTRIES 496
+#endif
+constexpr int kSegEntries = GS_SEG_ENTRIES;  // 2 forward batches = 4 backward batches
+#ifndef GS_SEG_SPLIT_MIN
+#define GS_SEG_SPLIT_MIN (3 * GS_SEG_ENTRIES)
+#endif
+constexpr int kSegSplitMin = GS_SEG_SPLIT_MIN;  // lists up to here stay whole
 struct TileSegments {
-  int *chk_first;          // [num_tiles]: checkpoint slot of the tile's first boundary, or -1: the tile is not split
+  int *granted;            // [num_tiles]: further segments of the tile in `extra` (written behind the forward)
   int2 *extra;             // [extra_cap]: (tile, k) of the segments k >= 1
   int *extra_count;        // [1]
   float4 *chk;             // [slots][256]: one checkpoint per boundary, per pixel of the tile (thread order)
   const float *image;      // the forward's image (the backward's view of the colour behind a boundary)
-  int extra_cap;           // room in `extra` = checkpoint slots (one boundary per further segment); a multiple of 8
+  int extra_cap;           // room in `extra`; a multiple of 8 (the main blocks keep their XCDs)
+  int *asked;              // [1], host-visible: the segments the tiles asked for (sizes the next launch's room)
 };
+__host__ __device__ inline int segment_slot(int list_start, int boundary) { return list_start / kSegEntries + boundary; }
 
 }  // namespace gs

@@ -227,15 +227,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
   int live = satmask != ~0ull ? 1 : 0;
 
   static_assert(kSegEntries % kBatch == 0, "a segment boundary is a batch boundary of the forward");
-  const int chk_first = seg.chk ? seg.chk_first[tile] : -1;  // >= 0: a long list, checkpointed for the backward's segments
+  const bool checkpoints = seg.chk != nullptr && total > kSegSplitMin;  // a long list: the backward may walk it in segments
   for (int base = 0; base < total; base += kBatch) {
     const int count = min(kBatch, total - base);
     // an opaque per-batch copy of the thread index (see render_bwd_kernel): staging and list-building addresses are
     // rebuilt per batch instead of living in registers across the compositing loop
     int t = tid;
     asm volatile("" : "+v"(t));
-    if (chk_first >= 0 && base > 0 && base % kSegEntries == 0)  // (gs_render.h: TileSegments)
-      seg.chk[(size_t)(chk_first + base / kSegEntries - 1) * 256 + t] = make_float4(T, ar, ag, ab);
+    if (checkpoints && base > 0 && base % kSegEntries == 0)  // (gs_render.h: TileSegments)
+      seg.chk[(size_t)segment_slot(start, base / kSegEntries) * 256 + t] = make_float4(T, ar, ag, ab);
 #if GS_STAMP
     ++st_batches;
     GS_LAP(st_lists);  // (prologue of the first batch; nothing between the batches)
@@ -413,15 +413,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     tile = ex.x;
     seg_a = ex.y * kSegEntries;
     seg_end = seg_a + kSegEntries;
-    chk_slot = seg.chk_first[tile] + ex.y;  // the checkpoint at this segment's far boundary (if the list reaches it)
+    chk_slot = segment_slot(ranges[tile], ex.y + 1);  // the checkpoint at this segment's far boundary
   } else {
-    // (extra_cap is a multiple of 8: the main blocks keep their XCDs)
     tile = ordered_tile(order, seg.chk ? (int)blockIdx.x - seg.extra_cap : (int)blockIdx.x, num_tiles);
     if (tile >= num_tiles) return;
-    if (seg.chk) {
-      const int cf = seg.chk_first[tile];
-      if (cf >= 0) { seg_end = kSegEntries; chk_slot = cf; }
-    }
+    if (seg.chk && seg.granted[tile] > 0) { seg_end = kSegEntries; chk_slot = segment_slot(ranges[tile], 1); }
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
 #if GS_STAMP
@@ -884,32 +880,53 @@ int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *or
 }
 bool tile_order_supported(int num_tiles) { return ((num_tiles + 7) >> 3) <= kOrderMaxRun; }
 
-// r05: which tiles' lists are split for the backward (gs_render.h: TileSegments).  One thread per tile; the extra segments of
-// all split tiles cannot exceed (instances / kSegEntries), which is what `extra` and the checkpoint pool are sized for.
-__global__ __launch_bounds__(256) void tile_segments_kernel(const int *__restrict__ ranges, int num_tiles, TileSegments seg) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= num_tiles) return;
-  const int len = ranges[t + 1] - ranges[t];
-  int first = -1;
-  if (len > kSegSplitMin) {
-    const int nseg = (len + kSegEntries - 1) / kSegEntries;
-    // (a list that does not fit any more stays whole: the launch's room follows the previous forward's instance count)
-    if (*(volatile int *)seg.extra_count + nseg - 1 <= seg.extra_cap) {
-      const int pos = atomicAdd(seg.extra_count, nseg - 1);
-      if (pos + nseg - 1 <= seg.extra_cap) {
-        first = pos;
-        for (int k = 1; k < nseg; ++k) seg.extra[pos + k - 1] = make_int2(t, k);
-      } else {
-        atomicSub(seg.extra_count, nseg - 1);
-      }
+// r05: which segments the backward walks with a workgroup of their own (gs_render.h: TileSegments), from the forward's
+// largest stop index per tile.  ONE workgroup walks the tiles in index order, 1024 at a time, with an exclusive scan of the
+// further segments each tile asks for: the table is the same in every run (an atomic counter per tile serialised ~1500
+// requests on one L2 line: 13.7 us).  A list whose segments do not fit into the launch's room stays whole, and so does
+// every list behind it; `asked` tells the host what would have been needed.
+__global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restrict__ ranges, const int *__restrict__ tops,
+                                                             int num_tiles, TileSegments seg) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base, s_count;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = s_count = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < num_tiles; t0 += 1024) {
+    const int t = t0 + tid;
+    const int len = t < num_tiles ? ranges[t + 1] - ranges[t] : 0;
+    const int top = len > kSegSplitMin ? min(tops[t], len) : 0;  // (the forward stores checkpoints for exactly these lists)
+    const int want = top > kSegEntries ? (top + kSegEntries - 1) / kSegEntries - 1 : 0;
+    int incl = want;  // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
     }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    const int pos = before + incl - want;
+    int granted = 0;
+    if (want > 0 && pos + want <= seg.extra_cap) {
+      granted = want;
+      for (int k = 1; k <= want; ++k) seg.extra[pos + k - 1] = make_int2(t, k);
+      atomicMax(&s_count, pos + want);  // (the lists that fit are a prefix of the tiles: pos only grows)
+    }
+    if (t < num_tiles) seg.granted[t] = granted;
+    __syncthreads();
+    if (tid == 1023) s_base = before + incl;
+    __syncthreads();
   }
-  seg.chk_first[t] = first;
+  if (tid == 0) {
+    *seg.extra_count = s_count;
+    if (seg.asked) *seg.asked = s_base;
+  }
 }
 
-int launch_tile_segments(const int *ranges, int num_tiles, const TileSegments &seg, hipStream_t st) {
-  GS_HIP(hipMemsetAsync(seg.extra_count, 0, sizeof(int), st));
-  tile_segments_kernel<<<div_up(num_tiles, 256), 256, 0, st>>>(ranges, num_tiles, seg);
+int launch_tile_segments(const int *ranges, const int *tops, int num_tiles, const TileSegments &seg, hipStream_t st) {
+  tile_segments_kernel<<<1, 1024, 0, st>>>(ranges, tops, num_tiles, seg);
   GS_LAUNCH_CHECK();
   return GSPLAT_OK;
 }
@@ -921,7 +938,7 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
-  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   if (recs) {
     render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out, seg);
   } else {
@@ -936,7 +953,7 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in,
                       hipEvent_t ev_start, hipEvent_t ev_stop, const int *order, const TileSegments *segments) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
-  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   // split lists: their further segments are extra blocks in front of the main grid (blocks beyond the count leave at once)
   const dim3 grid(tile_grid(num_tiles) + (seg.chk ? seg.extra_cap : 0)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};

@@ -479,9 +479,9 @@ int gsplat_context_set_lean_forward(gsplat_context *ctx, int enabled);
  * figures) had to be redone because the instances outgrew the buffers or the longest list needed a sort kernel that
  * was not queued, out[2] forwards that walked the compacted slots, out[3] growths of the instance buffers, out[4]
  * compositing backwards that took their tiles heaviest first (scenes whose longest tile list was more than three times
- * the average in the forward before), out[5] compositing backwards that walked lists of more than 1984 entries as
- * segments of 992 with a workgroup each (the forward before had such a list; the forward stores a per-pixel checkpoint
- * at every segment boundary).  Writes min(n, 6) values and returns 6. */
+ * the average in the forward before), out[5] compositing backwards that walked lists of more than 1488 entries as
+ * segments of 496 with a workgroup each (the forward before had such a list; the forward stores a per-pixel checkpoint
+ * at every segment boundary it reaches).  Writes min(n, 6) values and returns 6. */
 int gsplat_context_get_counters(gsplat_context *ctx, long long *out, int n);
 int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
 /* The same for a subset of the stages (bit k of stage_mask = stage k; 0 switches timing off).  Every timed stage

@@ -565,10 +565,11 @@ def test_very_long_tile_lists(gpu, scene, orc):
 
 
 def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
-    """r05 (gs_render.h: TileSegments): once a forward has seen a list beyond 1984 entries, the next forward stores a
-    per-pixel checkpoint {T, colour so far} at every 992nd entry of such lists and the backward walks each segment with a
-    workgroup of its own.  Lists of 2 100 .. 7 000 entries whose pixels stop in front of, inside and behind the segment
-    boundaries (opacities from faint to opaque); the gradients must be the oracle's, and the first (unsplit) backward's."""
+    """r05 (gs_render.h: TileSegments): once a forward has seen a list beyond 1488 entries, the next forward stores a
+    per-pixel checkpoint {T, colour so far} at every 496th entry of such lists and the backward walks each segment some
+    pixel reaches with a workgroup of its own.  Lists of 2 100 .. 7 000 entries whose pixels stop in front of, inside
+    and behind the segment boundaries (opacities from faint to opaque); the gradients must be the oracle's, and the
+    first (unsplit) backward's."""
     torch, raster = gpu, pkg("raster")
     N, W, H, L = 24000, 160, 96, 1
     params = scene.make_gaussians(N, W, H, L)
@@ -592,7 +593,9 @@ def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
     gi_d = torch.as_tensor(gi).cuda()
     ref = orc.rasterize(params, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], c["bg"], L, threads=8)
     lens = np.diff(ref["ranges"])
-    assert lens.max() > 5 * 992 and ((lens > 1984) & (lens < 3 * 992)).any() and ((lens > 992) & (lens <= 1984)).any()
+    assert lens.max() > 10 * 496 and ((lens > 1488) & (lens < 5 * 496)).any() and ((lens > 496) & (lens <= 1488)).any()
+    stops = np.asarray(ref["n"]).reshape(-1)
+    assert (stops > 3 * 496).any() and ((stops > 496) & (stops < 992)).any(), "pixels must stop behind several boundaries"
     bref = orc.backward_pass(ref, cam, gi, c["bg"], L, threads=8)
     whole = None
     for it in range(3):
