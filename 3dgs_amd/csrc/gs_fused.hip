@@ -49,7 +49,9 @@ int launch_tile_emit(const float *uv, const float *xyz_c, const float *radius, i
 struct RawSplats;
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero, long long zero_vec,
-                      unsigned short *masks_out, const int *order, int *tops_out, const TileSegments *segments);
+                      unsigned short *masks_out, const int *order, int *tops_out, const TileSegments *segments,
+                      const FwdSegments *fwd_segments);
+int launch_fwd_segments_table(const int *ranges, int num_tiles, const FwdSegments &fs, hipStream_t st);
 int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, const int *n_px,
                       const float *T_px, const float *grad_image, int width, int height, float bg, float *rows,
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st,
@@ -78,6 +80,12 @@ struct gsplat_context {
   // r05: long lists split into segments for the backward (gs_render.h: TileSegments); allocated by the first forward that
   // follows one with a list beyond kSegSplitMin
   gs::DeviceBuffer seg_first, seg_extra, seg_chk;
+  // ... and for the forward (gs_render.h: FwdSegments)
+  gs::DeviceBuffer fseg_first, fseg_blocks, fseg_gran, fseg_part, fseg_stop;
+  void *fseg_gran_zeroed = nullptr;  // the granule block whose tags have been cleared (a fresh block holds anything)
+  size_t fseg_gran_zeroed_bytes = 0;
+  unsigned int fseg_epoch = 0;
+  unsigned long long n_segmented_forwards = 0;
   int seg_cap = 0;          // extra segments the recorded forward had room for
   bool seg_ready = false;   // the recorded forward wrote the table and the checkpoints
   unsigned long long n_segmented_backwards = 0;
@@ -139,7 +147,7 @@ struct gsplat_context {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                      &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order,
-                                     &seg_first, &seg_extra, &seg_chk};
+                                     &seg_first, &seg_extra, &seg_chk, &fseg_first, &fseg_blocks, &fseg_gran, &fseg_part, &fseg_stop};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -150,8 +158,9 @@ struct gsplat_context {
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order,
-                               &seg_first, &seg_extra, &seg_chk};
+                               &seg_first, &seg_extra, &seg_chk, &fseg_first, &fseg_blocks, &fseg_gran, &fseg_part, &fseg_stop};
     for (auto *p : all) p->release();
+    fseg_gran_zeroed = nullptr;
     fork.destroy();
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
@@ -175,6 +184,18 @@ bool gs_no_tile_order() {
 // GSPLAT_NO_SEGMENTS=1: long lists stay whole in the backward (A/B of r05's segment split)
 bool gs_no_segments() {
   static const bool v = [] { const char *e = getenv("GSPLAT_NO_SEGMENTS"); return e && e[0] == '1'; }();
+  return v;
+}
+
+// GSPLAT_FWD_SEGMENTS_GATE=<x>: the forward splits its long lists when the longest chain exceeds x times the work per
+// resident workgroup (default 3; 0: always)
+double gs_fwd_segments_gate() {
+  static const double v = [] { const char *e = getenv("GSPLAT_FWD_SEGMENTS_GATE"); return e && e[0] ? atof(e) : 3.0; }();
+  return v;
+}
+// GSPLAT_NO_FWD_SEGMENTS=1: one block per tile in the forward, whatever the list lengths (A/B)
+bool gs_no_fwd_segments() {
+  static const bool v = [] { const char *e = getenv("GSPLAT_NO_FWD_SEGMENTS"); return e && e[0] == '1'; }();
   return v;
 }
 
@@ -1301,7 +1322,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // Lists beyond kSegSplitMin are split for the backward (gs_render.h: TileSegments) -- decided, like the order, by the
     // previous forward: its longest list says whether there is anything to split; the room for extra blocks follows what
     // the tiles of the previous forward asked for (a list that does not fit stays whole).
-    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin;
     if (split) {
       const size_t slots = cap / gs::kSegEntries + 2;  // (gs_render.h: segment_slot)
@@ -1311,13 +1332,48 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       if ((r = c->seg_extra.reserve((want + 2) * sizeof(int2)))) return r;  // [want]: the count
       if ((r = c->seg_chk.reserve(slots * 256 * sizeof(float4)))) return r;
       seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + want),
-             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want, reinterpret_cast<int *>(c->d_pub + 6)};
+             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want, reinterpret_cast<int *>(c->d_pub + 6), nullptr};
+    }
+    // the tiles' largest stop indices of this forward, for the next one's decision below
+    const bool figures = !gs_no_fwd_segments() && c->last_longest > gs::kSegSplitMin;
+    if (figures) seg.stats = reinterpret_cast<int *>(c->d_pub + 5);
+    // ... and for the forward itself (gs_render.h: FwdSegments): every segment of a long list a block of its own
+    gs::FwdSegments fs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+    // Only where the tiles' work is uneven enough for ONE list to set the launch's duration: the previous forward's longest
+    // chain (the largest stop index of any tile) against the work per resident workgroup (the sum over the tiles / 2048).
+    // A throughput-bound scene gains nothing from the split and pays for its table, its combine pass and the product passes
+    // (garden-shaped synthetic scene 0.197 -> 0.271 ms, dense4m 0.183 -> 0.26 when split regardless).
+    const volatile int *figs = reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 5));
+    const long long top_max = figs[0], top_sum = figs[1];
+    const bool fsplit = figures && top_sum > 0 && top_max * 2048ll > (long long)(gs_fwd_segments_gate() * (double)top_sum);
+    if (fsplit) {
+      const size_t most = cap / gs::kSegEntries + (size_t)num_tiles + 8;  // sum of ceil(len / kSegEntries) over any lists
+      const size_t asked = (size_t)*reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 7));
+      const size_t want = std::min(most, asked + asked / 4 + 512) + 7 & ~(size_t)7;
+      if ((r = c->fseg_first.reserve(((size_t)num_tiles + 8 + 136) * 4))) return r;  // ranks | layer bases
+      if ((r = c->fseg_blocks.reserve((want + 2) * sizeof(int2)))) return r;  // [want]: the count
+      if ((r = c->fseg_gran.reserve(2 * want * 256 * sizeof(unsigned long long)))) return r;  // t products | final Ts
+      if ((r = c->fseg_part.reserve(want * 256 * sizeof(float4)))) return r;
+      if ((r = c->fseg_stop.reserve(want * 256 * sizeof(int)))) return r;
+      if (c->fseg_gran.ptr != c->fseg_gran_zeroed || c->fseg_gran.bytes != c->fseg_gran_zeroed_bytes) {
+        GS_HIP(hipMemsetAsync(c->fseg_gran.ptr, 0, c->fseg_gran.bytes, st));  // tags of no epoch
+        c->fseg_gran_zeroed = c->fseg_gran.ptr;
+        c->fseg_gran_zeroed_bytes = c->fseg_gran.bytes;
+      }
+      if (++c->fseg_epoch == 0) c->fseg_epoch = 1;
+      fs = {c->fseg_first.as<int>(), c->fseg_first.as<int>() + num_tiles + 8, c->fseg_blocks.as<int2>(),
+            reinterpret_cast<int *>(c->fseg_blocks.as<int2>() + want),
+            c->fseg_gran.as<unsigned long long>(), c->fseg_part.as<float4>(), c->fseg_stop.as<int>(), (int)want,
+            c->fseg_epoch, reinterpret_cast<int *>(c->d_pub + 7)};
+      if ((r = gs::launch_fwd_segments_table(c->ranges.as<int>(), num_tiles, fs, st))) return r;
+      c->n_segmented_forwards++;
     }
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
                               ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
-                              (ordered || split) ? c->tile_tops.as<int>() : nullptr, split ? &seg : nullptr);
+                              (ordered || split || figures) ? c->tile_tops.as<int>() : nullptr, split ? &seg : nullptr,
+                              fsplit ? &fs : nullptr);
     if (r) return r;
     c->seg_ready = split;
     c->seg_cap = seg.extra_cap;
@@ -1326,7 +1382,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (ordered && (r = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return r;
     c->order_ready = ordered;
     // ... and which segments of the long lists get a block of their own
-    if (split && (r = gs::launch_tile_segments(c->ranges.as<int>(), c->tile_tops.as<int>(), num_tiles, seg, st))) return r;
+    if ((split || figures) && (r = gs::launch_tile_segments(c->ranges.as<int>(), c->tile_tops.as<int>(), num_tiles, seg, st))) return r;
     return GSPLAT_OK;
   };
   // once a backward has been seen, the forward clears the gradient rows on the side (see render_fwd_kernel)
@@ -1410,7 +1466,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
                                c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                                c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
                                ro ? nullptr : c->blockmasks.as<unsigned short>(), nullptr,
-                               ordered ? c->tile_tops.as<int>() : nullptr, nullptr);
+                               ordered ? c->tile_tops.as<int>() : nullptr, nullptr, nullptr);
     if (rc) return rc;
     c->seg_ready = false;
     c->mark(4, true, st);
@@ -1492,10 +1548,10 @@ int gsplat_backward_render_split(gsplat_context *c, const float *grad_image, flo
   c->rows_zeroed = false;
   // stage 6 is this one launch: when it is timed, the launch itself stamps the two events (see launch_render_bwd)
   const bool timed = (c->timing >> 6) & 1u;
-  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (c->seg_ready)
     seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + c->seg_cap),
-           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap, nullptr};
+           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap, nullptr, nullptr};
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,
@@ -1629,10 +1685,11 @@ int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask)
 
 int gsplat_context_get_counters(gsplat_context *c, long long *out, int n) {
   GS_REQUIRE(c && out && n >= 0, "null argument");
-  const long long v[6] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards,
-                          (long long)c->n_segmented_backwards};
-  for (int k = 0; k < n && k < 6; ++k) out[k] = v[k];
-  return 6;
+  const volatile int *figs = reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 5));
+  const long long v[9] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards,
+                          (long long)c->n_segmented_backwards, (long long)c->n_segmented_forwards, figs[0], figs[1]};
+  for (int k = 0; k < n && k < 9; ++k) out[k] = v[k];
+  return 9;
 }
 
 int gsplat_context_set_render_only(gsplat_context *c, int enabled) {

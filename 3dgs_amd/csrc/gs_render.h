@@ -481,7 +481,43 @@ struct TileSegments {
   const float *image;      // the forward's image (the backward's view of the colour behind a boundary)
   int extra_cap;           // room in `extra`; a multiple of 8 (the main blocks keep their XCDs)
   int *asked;              // [1], host-visible: the segments the tiles asked for (sizes the next launch's room)
+  int *stats;              // [2], host-visible: the largest stop index of any tile | the sum of the tiles' largest stop indices
 };
 __host__ __device__ inline int segment_slot(int list_start, int boundary) { return list_start / kSegEntries + boundary; }
+
+// r05 -- the same long lists in the FORWARD.  The front-to-back recurrence is serial in the transmittance only: a
+// segment k of a list can composite on its own once it knows P_k, the T in front of its first entry.  Every segment of a
+// long list is a block of its own (fwd_segment_block), and the blocks are dispatched LAYER by layer: all segments 0,
+// then all segments 1, ...
+//  * Where a layer fills the chip, the layer behind it starts when it is through: a block finds the final T of the block
+//    in front of it (F_(k-1) = P_k) already published, composites (phase C), and publishes its own.  A segment no pixel
+//    reaches finds only zeros and leaves at once.  This is the unsplit forward's work, dealt in equal pieces.
+//  * In the thin layers of the few longest lists the blocks run side by side.  A block that does not find F_(k-1) first
+//    multiplies up the transmittance t_k of ITS entries per pixel (phase A: alpha evaluation only, no colour, no stop
+//    logic: ~70 % of a compositing pass) and publishes it, then collects P_k = F_q t_(q+1) ... t_(k-1) from the nearest
+//    finished block q in front of it and the products behind that, and composites.
+// Published values are 8-byte {launch epoch, value} granules per pixel, written and polled with agent-scope atomics: the
+// data is its own flag.  Phase C runs with T = P_k * t, t the running product inside the segment -- bit for bit the
+// sequence phase A multiplied up -- so F_k = P_k t_k = P_(k+1) exactly, whichever way a block obtained it: a pixel that
+// has not stopped in segment k (every T >= 1e-4) is live in segment k + 1, one that has stopped (T < 1e-4 at some entry)
+// is dead there, whatever the rounding -- no pixel is lost or composited twice.  Segment 0 (P = 1) is the unsplit
+// arithmetic.  A block only ever waits for blocks with smaller indices (workgroups are dispatched in index order) and
+// not for ever: when its poll budget is used up it multiplies the product up itself from entry 0 (same values), so
+// every wave reaches its end whatever the dispatch order.  A one-block-per-tile kernel behind the forward
+// (fwd_segments_combine_kernel) adds the segments' colours in order, finds the segment in which the pixel stopped and
+// writes image / T / stop index / the backward's checkpoints: sums in a fixed order, the same image in every run.
+struct FwdSegments {
+  int *rank;                     // [num_tiles]: the tile's rank among the long lists (most segments first), -1: one block
+  int *base;                     // [129]: first block of layer k; segment (t, k) is block (= storage slot) base[k] + rank[t]
+  int2 *blocks;                  // [cap]: (tile, k | thin-layer flag << 30) by block
+  int *count;                    // [1]: blocks in use
+  unsigned long long *granules;  // [2][cap][256]: {epoch, value} per block and pixel: t_k | the T behind segment k
+  float4 *part;                  // [cap][256]: the segment's colour and the T behind it (its final T if the pixel stopped)
+  int *stop;                     // [cap][256]: the stop index if the pixel stopped in the segment, -1 live, -2 dead
+  int cap;                       // room for segment blocks; a multiple of 8 (the main blocks keep their XCDs)
+  unsigned int epoch;            // of this launch; never 0
+  int *asked;                    // [1], host-visible: segment blocks the lists asked for
+};
+constexpr int kFwdPollBudget = 4096;  // polls (~1 us each) before a segment block multiplies the product up itself
 
 }  // namespace gs

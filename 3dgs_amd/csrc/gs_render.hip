@@ -174,6 +174,249 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
   return rc;
 }
 
+// ---- r05: long lists in segments, forward (gs_render.h: FwdSegments) ------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gs_gu64;
+__device__ __forceinline__ void granule_store(unsigned long long *g, unsigned int epoch, float v) {
+  __hip_atomic_store((gs_gu64 *)g, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool granule_load(const unsigned long long *g, unsigned int epoch, float &v) {
+  const unsigned long long x = __hip_atomic_load((gs_gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __uint_as_float((unsigned int)x);
+  return (unsigned int)(x >> 32) == epoch;
+}
+// T in front of segment k's first entry from what the blocks in front have published: the nearest block q < k whose
+// final T is out (F_q = P_(q+1)) and the products t_(q+1) .. t_(k-1) of the blocks behind it, multiplied up from the left
+// -- whichever q a thread finds, the value is the same left fold.  false: the poll budget ran out.
+// (segment j of the tile lives in storage slot base[j] + rank: t at gran[slot], F at gran[cap + slot])
+__device__ __forceinline__ bool resolve_prefix(const FwdSegments &fs, int rank, int tid, int k, int budget, float &prefix) {
+  const unsigned long long *gt = fs.granules + (size_t)rank * 256 + tid, *gf = gt + (size_t)fs.cap * 256;
+  for (int polls = 0;;) {
+    int q = -1;
+    float v = 0.0f;
+    for (int j = k - 1; j >= 0; --j) {
+      const size_t at = (size_t)fs.base[j] * 256;
+      if (granule_load(gf + at, fs.epoch, v)) { q = j; break; }
+      float t;
+      if (!granule_load(gt + at, fs.epoch, t)) break;
+    }
+    if (q >= 0) {
+      for (int j = q + 1; j < k; ++j) {
+        float t;
+        (void)granule_load(gt + (size_t)fs.base[j] * 256, fs.epoch, t);  // (seen on the way down: published values stay)
+        v = v * t;
+      }
+      prefix = v;
+      return true;
+    }
+    if (++polls >= budget) return false;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+// Phase A: the product of (1 - alpha) over the entries [begin, end) of the tile's list, per pixel -- the forward's loop
+// without colour, stop test and saturation bookkeeping, the same alpha values in the same order, so that the running
+// product is bit for bit the one phase C multiplies up.  `fold`: the product segment by segment from the left,
+// ((t_0 t_1) t_2) ..., the order in which collect_prefix takes the published values.
+template <bool kPacked>
+__device__ __forceinline__ float fwd_t_product(const float4 *__restrict__ recs, const RawSplats &raw,
+                                               const int *__restrict__ sorted, int start, int begin, int end, bool fold,
+                                               float tx0, float ty0, float fpx, float fpy, int tid, float4 *s_r0,
+                                               float4 *s_r1, float4 *s_r2, unsigned short *s_list) {
+  const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
+  const char *r2b = reinterpret_cast<const char *>(s_r2);
+  float tl = 1.0f, pref = 1.0f;
+  for (int base = begin; base < end; base += kBatch) {
+    const int count = min(kBatch, end - base);
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    if (fold && base > begin && base % kSegEntries == 0) { pref = pref * tl; tl = 1.0f; }
+    __syncthreads();
+    if (t < count) {
+      const int g = sorted[start + base + t];
+      SplatRec s = load_record<kPacked>(g, recs, raw);
+      const unsigned int hits = block_hits(s, tx0, ty0);
+      stage_record(s);
+      s.r1.w = __uint_as_float(hits);
+      s.r2.w = s.r1.y > kLog2AlphaMax ? kLog2AlphaMax : s.r1.y;
+      s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
+    }
+    __syncthreads();
+    unsigned short *lists = s_list + (t >> 6) * 4 * kListStride;
+    const unsigned int list_lds =
+        (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + ((t >> 4) & 3) * kListStride);
+    const RowCounts rc = build_row_lists<kListStride>(s_r1, lists, count, t >> 6, t & 63, kBatch, kBatch, kBatch, kBatch, 2);
+    const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+    for (int i = 0; i < trips; i += 2) {
+      int off0, off1;
+      asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:2\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(off0), "=&v"(off1) : "v"(list_lds + 2 * i) : "memory");
+      const float4 a0 = *reinterpret_cast<const float4 *>(r0b + off0), a1 = *reinterpret_cast<const float4 *>(r0b + off1);
+      const float2 b0 = *reinterpret_cast<const float2 *>(r1b + off0), b1 = *reinterpret_cast<const float2 *>(r1b + off1);
+      const float l0 = *reinterpret_cast<const float *>(r2b + off0 + 12), l1 = *reinterpret_cast<const float *>(r2b + off1 + 12);
+      float al0 = staged_alpha_capped(a0.z, a0.w, b0.x, b0.y, l0, a0.x - fpx, a0.y - fpy);
+      float al1 = staged_alpha_capped(a1.z, a1.w, b1.x, b1.y, l1, a1.x - fpx, a1.y - fpy);
+      al0 = al0 > kAlphaMin ? al0 : 0.0f;
+      al1 = al1 > kAlphaMin ? al1 : 0.0f;
+      asm volatile("" : "+v"(al0), "+v"(al1));
+      tl = __builtin_fmaf(-al0, tl, tl);
+      tl = __builtin_fmaf(-al1, tl, tl);
+    }
+  }
+  return fold ? pref * tl : tl;
+}
+
+// One segment of a long list (gs_render.h: FwdSegments).
+template <bool kPacked>
+__device__ __forceinline__ void fwd_segment_block(const float4 *__restrict__ recs, const RawSplats &raw,
+                                                  const int *__restrict__ sorted, const int *__restrict__ ranges,
+                                                  int width, int height, int ntx, unsigned short *__restrict__ masks_out,
+                                                  const FwdSegments &fs, int blk, float4 *s_r0, float4 *s_r1,
+                                                  float4 *s_r2, unsigned short *s_list) {
+  const int2 bk = fs.blocks[blk];
+  const int tile = bk.x, k = bk.y & 0xFFFF;
+  const bool side_by_side = (bk.y >> 30) != 0;  // a thin layer (fwd_segments_table_kernel)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
+  if (tid == 0) {
+    s_r0[kBatch] = s_r2[kBatch] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s_r1[kBatch] = sentinel_r1();
+  }
+  const int tile_x = tile % ntx, tile_y = tile / ntx;
+  const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
+  const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
+  const bool inside = px < width && py < height;
+  const float fpx = (float)px, fpy = (float)py;
+  const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
+  const int start = ranges[tile], total = ranges[tile + 1] - start;
+  const int m = (total + kSegEntries - 1) / kSegEntries;
+  const int a = k * kSegEntries, b = min(total, a + kSegEntries);
+  // this block's storage slot is its index; the slot of the segment in front: base[k - 1] + the tile's rank
+  const int rank = fs.rank[tile];
+  unsigned long long *gran_t = fs.granules + (size_t)blk * 256 + tid, *gran_f = gran_t + (size_t)fs.cap * 256;
+  float4 *part = fs.part + (size_t)blk * 256 + tid;
+  int *stop = fs.stop + (size_t)blk * 256 + tid;
+
+  float prefix = 1.0f;
+  if (k > 0) {
+    // Is the block in front done already?  (The blocks are dispatched layer by layer -- all segments 0, then all segments
+    // 1, ...: where a layer fills the chip, the layer behind it starts when it is through.)  Then T is simply what it left
+    // behind, nobody behind this block can be waiting for its product yet either, so phase A is skipped: its final T will
+    // do.  And if no pixel of the tile is left, neither has this segment anything to add.
+    float f = 0.0f;
+    const bool have = granule_load(fs.granules + ((size_t)fs.cap + fs.base[k - 1] + rank) * 256 + tid, fs.epoch, f);
+    const bool all_have = __syncthreads_and(have ? 1 : 0);
+    if (all_have) {
+      prefix = f;
+      if (__syncthreads_and(!inside || f < kTMin ? 1 : 0)) {
+        if (k < m - 1) granule_store(gran_f, fs.epoch, 0.0f);
+        *part = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *stop = -2;
+        return;
+      }
+    } else {
+      // In a thin layer the segments of a list run side by side: the blocks behind need this segment's product before
+      // its compositing.  In a thick one the block in front is about to finish (it was dispatched a layer earlier) and the
+      // other blocks of this CU keep its SIMDs busy meanwhile: waiting costs less than the product pass.
+      if (side_by_side && k < m - 1) {
+        const float tk = fwd_t_product<kPacked>(recs, raw, sorted, start, a, b, false, tx0, ty0, fpx, fpy, tid, s_r0, s_r1, s_r2, s_list);
+        granule_store(gran_t, fs.epoch, tk);
+      }
+      const bool got = resolve_prefix(fs, rank, tid, k, kFwdPollBudget, prefix);
+      if (__syncthreads_or(got ? 0 : 1))  // (rare: the blocks in front have not run yet and may be waiting for this CU)
+        prefix = fwd_t_product<kPacked>(recs, raw, sorted, start, 0, a, true, tx0, ty0, fpx, fpy, tid, s_r0, s_r1, s_r2, s_list);
+    }
+  }
+
+  // Phase C: the forward's loop with T = prefix * (running product of the segment)
+  const char *r0b = reinterpret_cast<const char *>(s_r0), *r1b = reinterpret_cast<const char *>(s_r1);
+  const char *r2b = reinterpret_cast<const char *>(s_r2);
+  const bool alive = inside && prefix >= kTMin;
+  float tl = alive ? 1.0f : 0.0f, T = alive ? prefix : 0.0f, T_fin = -1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  int n = -1;
+  unsigned long long satmask = __ballot(!alive);
+  int live = satmask != ~0ull ? 1 : 0;
+  for (int base = a; base < b; base += kBatch) {
+    const int count = min(kBatch, b - base);
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    __syncthreads();
+    if (t < count) {
+      const int g = sorted[start + base + t];
+      SplatRec s = load_record<kPacked>(g, recs, raw);
+      const unsigned int hits = block_hits(s, tx0, ty0);
+      if (masks_out) masks_out[start + base + t] = (unsigned short)hits;
+      stage_record(s);
+      s.r1.w = __uint_as_float(hits);
+      s.r2.w = s.r1.y > kLog2AlphaMax ? kLog2AlphaMax : s.r1.y;
+      s_r0[t] = s.r0; s_r1[t] = s.r1; s_r2[t] = s.r2;
+    }
+    __syncthreads();
+    if (live > 0) {
+      const int big = kBatch;
+      unsigned short *lists = s_list + (t >> 6) * 4 * kListStride;
+      const unsigned int list_lds =
+          (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + ((t >> 4) & 3) * kListStride);
+      const RowCounts rc = build_row_lists<kListStride>(s_r1, lists, count, t >> 6, t & 63,
+                                           (unsigned int)(satmask & 0xFFFFull) == 0xFFFFu ? 0 : big,
+                                           (unsigned int)((satmask >> 16) & 0xFFFFull) == 0xFFFFu ? 0 : big,
+                                           (unsigned int)((satmask >> 32) & 0xFFFFull) == 0xFFFFu ? 0 : big,
+                                           (unsigned int)((satmask >> 48) & 0xFFFFull) == 0xFFFFu ? 0 : big, 2);
+      const int trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+      for (int i = 0; i < trips; i += 2) {
+        int off0, off1;
+        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(off0), "=&v"(off1) : "v"(list_lds + 2 * i) : "memory");
+        const float4 a0 = *reinterpret_cast<const float4 *>(r0b + off0), c0 = *reinterpret_cast<const float4 *>(r2b + off0);
+        const float2 b0 = *reinterpret_cast<const float2 *>(r1b + off0);
+        const float4 a1 = *reinterpret_cast<const float4 *>(r0b + off1), c1 = *reinterpret_cast<const float4 *>(r2b + off1);
+        const float2 b1 = *reinterpret_cast<const float2 *>(r1b + off1);
+        float al0 = staged_alpha_capped(a0.z, a0.w, b0.x, b0.y, c0.w, a0.x - fpx, a0.y - fpy);
+        float al1 = staged_alpha_capped(a1.z, a1.w, b1.x, b1.y, c1.w, a1.x - fpx, a1.y - fpy);
+        al0 = al0 > kAlphaMin ? al0 : 0.0f;
+        al1 = al1 > kAlphaMin ? al1 : 0.0f;
+        asm volatile("" : "+v"(al0), "+v"(al1));
+        // (as in render_fwd_kernel: a saturated or dead pixel has tl = T = 0 and stays in the mask by itself)
+        const float w0 = al0 * T;
+        const float tl0 = __builtin_fmaf(-al0, tl, tl);
+        const float tT0 = prefix * tl0;
+        ar = __builtin_fmaf(c0.x, w0, ar);
+        ag = __builtin_fmaf(c0.y, w0, ag);
+        ab = __builtin_fmaf(c0.z, w0, ab);
+        const unsigned long long s0 = __ballot(tT0 < kTMin);
+        tl = tl0;
+        T = tT0;
+        if (s0 != satmask) {
+          if (((s0 & ~satmask) >> lane) & 1ull) { T_fin = tT0; n = base + (off0 >> 4) + 1; tl = 0.0f; T = 0.0f; }
+          satmask = s0;
+          if (satmask == ~0ull) { live = 0; i = trips; }
+        }
+        const float w1 = al1 * T;
+        const float tl1 = __builtin_fmaf(-al1, tl, tl);
+        const float tT1 = prefix * tl1;
+        ar = __builtin_fmaf(c1.x, w1, ar);
+        ag = __builtin_fmaf(c1.y, w1, ag);
+        ab = __builtin_fmaf(c1.z, w1, ab);
+        const unsigned long long s1 = __ballot(tT1 < kTMin);
+        tl = tl1;
+        T = tT1;
+        if (s1 != satmask) {
+          if (((s1 & ~satmask) >> lane) & 1ull) { T_fin = tT1; n = base + (off1 >> 4) + 1; tl = 0.0f; T = 0.0f; }
+          satmask = s1;
+          if (satmask == ~0ull) {
+            live = 0;
+            break;
+          }
+        }
+      }
+    }
+    if (__syncthreads_and(live <= 0 ? 1 : 0)) break;
+  }
+  // what the segment leaves behind: T in front of the next one (0 for a pixel that stopped or was dead: dead from here on)
+  if (k < m - 1) granule_store(gran_f, fs.epoch, T);
+  *part = make_float4(ar, ag, ab, T_fin >= 0.0f ? T_fin : T);
+  *stop = T_fin >= 0.0f ? n : (alive ? -1 : -2);
+}
+
 #ifndef GS_FWD_WAVES
 #define GS_FWD_WAVES 8
 #endif
@@ -186,7 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
                                                               float *__restrict__ image, float4 *__restrict__ zero,
                                                               long long zero_vec, unsigned short *__restrict__ masks_out,
                                                               const int *__restrict__ order, int *__restrict__ tops_out,
-                                                              TileSegments seg) {
+                                                              TileSegments seg, FwdSegments fs) {
   __shared__ float4 s_r0[kBatch + 1], s_r1[kBatch + 1], s_r2[kBatch + 1];  // [kBatch]: the all-zero sentinel record
   __shared__ int s_tile_top;
   __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kListStride + 2];
@@ -197,8 +440,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS_FWD_WAVE
     const long long per = (zero_vec + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = min(lo + per, zero_vec);
     for (long long k = lo + threadIdx.x; k < hi; k += 256) zero[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  const int tile = ordered_tile(order, blockIdx.x, num_tiles);
+  // the segments of the long lists come first (gs_render.h: FwdSegments): each is a block of its own, and the tiles they
+  // belong to have no block in the main grid
+  // (the context's forward only: the stand-alone operator on the reference's arrays keeps one block per tile)
+  const bool segmented = kPacked && fs.blocks != nullptr;
+  if constexpr (kPacked) {
+    if (segmented && (int)blockIdx.x < fs.cap) {
+      if ((int)blockIdx.x < *fs.count)
+        fwd_segment_block<kPacked>(recs, raw, sorted, ranges, width, height, ntx, masks_out, fs, (int)blockIdx.x, s_r0, s_r1, s_r2, s_list);
+      return;
+    }
+  }
+  const int tile = ordered_tile(order, segmented ? (int)blockIdx.x - fs.cap : (int)blockIdx.x, num_tiles);
   if (tile >= num_tiles) return;
+  if (segmented && fs.rank[tile] >= 0) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
 #if GS_STAMP
   const unsigned long long st_t0 = GS_NOW(), st_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -888,10 +1143,27 @@ bool tile_order_supported(int num_tiles) { return ((num_tiles + 7) >> 3) <= kOrd
 __global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restrict__ ranges, const int *__restrict__ tops,
                                                              int num_tiles, TileSegments seg) {
   __shared__ int s_wave[16];
-  __shared__ int s_base, s_count;
+  __shared__ int s_base, s_count, s_max, s_sum;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_base = s_count = 0;
+  if (tid == 0) s_base = s_count = s_max = s_sum = 0;
   __syncthreads();
+  if (seg.stats) {  // how uneven the tiles' work is: decides whether the next forward splits its long lists (gs_fused.hip)
+    int mx = 0, sum = 0;
+    for (int t = tid; t < num_tiles; t += 1024) {
+      const int top = min(tops[t], ranges[t + 1] - ranges[t]);
+      mx = max(mx, top);
+      sum += top;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = max(mx, __shfl_xor(mx, off, 64));
+      sum += __shfl_xor(sum, off, 64);
+    }
+    if (lane == 0) { atomicMax(&s_max, mx); atomicAdd(&s_sum, sum); }
+    __syncthreads();
+    if (tid == 0) { seg.stats[0] = s_max; seg.stats[1] = s_sum; }
+  }
+  if (seg.granted == nullptr) return;  // (a render-only context: the figures only)
   for (int t0 = 0; t0 < num_tiles; t0 += 1024) {
     const int t = t0 + tid;
     const int len = t < num_tiles ? ranges[t + 1] - ranges[t] : 0;
@@ -931,20 +1203,146 @@ int launch_tile_segments(const int *ranges, const int *tops, int num_tiles, cons
   return GSPLAT_OK;
 }
 
+// r05: the forward's segment blocks (gs_render.h: FwdSegments), by list length, in front of the forward.  The blocks are
+// listed LAYER by layer -- all segments 0, then all segments 1, ... -- so that a segment starts when the segments in front
+// of it are through wherever the layers fill the chip (no product pass then, and nothing at all for a segment nobody
+// reaches), and side by side with them in the thin layers of the few longest lists.  With the long lists ranked by their
+// number of segments m, longest first, layer k is the tiles of rank < L_k (L_k: lists with more than k segments): segment
+// (t, k) is block base_k + rank_t, base_k = L_0 + ... + L_(k-1) -- one counting sort of the tiles by m in one workgroup's
+// LDS.  A list of more than kFwdMaxLayers segments keeps its one block; if the blocks do not fit into the launch's room
+// nothing is split (the next launch's room follows `asked`).
+constexpr int kFwdMaxLayers = 128;
+#ifndef GS_FWD_THIN_LAYER
+#define GS_FWD_THIN_LAYER 512
+#endif
+constexpr int kFwdThinLayer = GS_FWD_THIN_LAYER;  // layers of fewer blocks run their lists' segments side by side (phase A)
+__global__ __launch_bounds__(1024) void fwd_segments_table_kernel(const int *__restrict__ ranges, int num_tiles, FwdSegments fs) {
+  __shared__ int s_hist[kFwdMaxLayers + 2], s_more[kFwdMaxLayers + 2], s_base[kFwdMaxLayers + 2], s_cursor[kFwdMaxLayers + 2];
+  const int tid = threadIdx.x;
+  if (tid < kFwdMaxLayers + 2) s_hist[tid] = s_cursor[tid] = 0;
+  __syncthreads();
+  auto segments_of = [&](int t) {
+    if (t >= num_tiles) return 0;
+    const int len = ranges[t + 1] - ranges[t];
+    const int m = len > kSegSplitMin ? (len + kSegEntries - 1) / kSegEntries : 0;
+    return m > kFwdMaxLayers ? 0 : m;
+  };
+  for (int t = tid; t < num_tiles; t += 1024) {
+    const int m = segments_of(t);
+    if (m > 0) atomicAdd(&s_hist[m], 1);
+  }
+  __syncthreads();
+  if (tid <= kFwdMaxLayers) {  // L_k = lists with more than k segments
+    int more = 0;
+    for (int q = tid + 1; q <= kFwdMaxLayers; ++q) more += s_hist[q];
+    s_more[tid] = more;
+  }
+  __syncthreads();
+  if (tid <= kFwdMaxLayers) {
+    int base = 0;
+    for (int q = 0; q < tid; ++q) base += s_more[q];
+    s_base[tid] = base;
+    fs.base[tid] = base;
+  }
+  __syncthreads();
+  const int total = s_base[kFwdMaxLayers];
+  const bool fits = total <= fs.cap;
+  for (int t = tid; t < num_tiles; t += 1024) {
+    const int m = fits ? segments_of(t) : 0;
+    int rank = -1;
+    if (m > 0) {
+      rank = s_more[m] + atomicAdd(&s_cursor[m], 1);  // behind the lists of more segments
+      for (int k = 0; k < m; ++k) fs.blocks[s_base[k] + rank] = make_int2(t, k | (s_more[k] < kFwdThinLayer ? 1 << 30 : 0));
+    }
+    fs.rank[t] = rank;
+  }
+  if (tid == 0) {
+    *fs.count = fits ? total : 0;
+    if (fs.asked) *fs.asked = total;
+  }
+}
+
+// ... and behind it: one block per tile adds up what the tile's segment blocks left (fixed order: the same image in every
+// run), finds the segment the pixel stopped in and writes the forward's per-pixel outputs, the tile's largest stop index
+// and the backward's checkpoints {T in front of the boundary, colour in front of it} (gs_render.h: TileSegments).
+__global__ __launch_bounds__(256) void fwd_segments_combine_kernel(const int *__restrict__ ranges, int width, int height,
+                                                                   int ntx, int num_tiles, float bg, int *__restrict__ n_out,
+                                                                   float *__restrict__ T_out, float *__restrict__ image,
+                                                                   int *__restrict__ tops_out, FwdSegments fs, TileSegments seg) {
+  __shared__ int s_top;
+  const int tile = blockIdx.x;
+  const int rank = fs.rank[tile];
+  if (rank < 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
+  if (tid == 0) s_top = 0;
+  __syncthreads();
+  const int tile_x = tile % ntx, tile_y = tile / ntx;
+  const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
+  const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
+  const bool inside = px < width && py < height;
+  const int start = ranges[tile], total = ranges[tile + 1] - start;
+  const int m = (total + kSegEntries - 1) / kSegEntries;
+  float ar = 0.0f, ag = 0.0f, ab = 0.0f, Tout = 1.0f, pref = 1.0f;
+  int n = total;
+  for (int k = 0; k < m; ++k) {
+    if (k > 0) {
+      // T in front of the boundary: what the segment in front left behind (read by the backward only for pixels that
+      // pass the boundary alive, for which it is exactly the T segment k started from)
+      pref = __uint_as_float((unsigned int)fs.granules[((size_t)fs.cap + fs.base[k - 1] + rank) * 256 + tid]);
+      if (seg.chk) seg.chk[(size_t)segment_slot(start, k) * 256 + tid] = make_float4(pref, ar, ag, ab);
+    }
+    const size_t slot = (size_t)(fs.base[k] + rank);
+    const int st = fs.stop[slot * 256 + tid];
+    if (st == -2) break;  // (a pixel outside the image; inside it a pixel is dead only behind the segment it stopped in)
+    const float4 p = fs.part[slot * 256 + tid];
+    ar += p.x; ag += p.y; ab += p.z;
+    Tout = p.w;
+    if (st >= 0) { n = st; break; }
+  }
+  if (tops_out) {
+    int top = inside ? n : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if (lane == 0) atomicMax(&s_top, top);
+    __syncthreads();
+    if (tid == 0) tops_out[tile] = s_top;
+  }
+  if (inside) {
+    const int pid = py * width + px;
+    n_out[pid] = n;
+    T_out[pid] = Tout;
+    image[3 * pid + 0] = ar + Tout * bg;
+    image[3 * pid + 1] = ag + Tout * bg;
+    image[3 * pid + 2] = ab + Tout * bg;
+  }
+}
+
+int launch_fwd_segments_table(const int *ranges, int num_tiles, const FwdSegments &fs, hipStream_t st) {
+  fwd_segments_table_kernel<<<1, 1024, 0, st>>>(ranges, num_tiles, fs);
+  GS_LAUNCH_CHECK();
+  return GSPLAT_OK;
+}
+
 // host-side launchers shared with gs_fused.hip ------------------------------------------
 int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorted, const int *ranges, int width,
                       int height, float bg, int *n_out, float *T_out, float *image, hipStream_t st, float4 *zero,
-                      long long zero_vec, unsigned short *masks_out, const int *order, int *tops_out, const TileSegments *segments) {
+                      long long zero_vec, unsigned short *masks_out, const int *order, int *tops_out, const TileSegments *segments,
+                      const FwdSegments *fwd_segments) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
-  const dim3 grid(tile_grid(num_tiles)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
-  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  const FwdSegments fs = fwd_segments ? *fwd_segments : FwdSegments{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+  const dim3 grid(tile_grid(num_tiles) + (fs.blocks ? fs.cap : 0)), block(256);
   if (recs) {
-    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out, seg);
+    render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out, seg, fs);
   } else {
-    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr, order, tops_out, seg);
+    render_fwd_kernel<false><<<grid, block, 0, st>>>(nullptr, *raw, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, nullptr, order, tops_out, seg, fs);
   }
   GS_LAUNCH_CHECK();
+  if (fs.blocks) {
+    fwd_segments_combine_kernel<<<num_tiles, 256, 0, st>>>(ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, tops_out, fs, seg);
+    GS_LAUNCH_CHECK();
+  }
   return GSPLAT_OK;
 }
 
@@ -953,7 +1351,7 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
                       float *g_rgb, float *g_opacity, float *g_uv, float *g_conic, hipStream_t st, const unsigned short *masks_in,
                       hipEvent_t ev_start, hipEvent_t ev_stop, const int *order, const TileSegments *segments) {
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
-  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+  const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   // split lists: their further segments are extra blocks in front of the main grid (blocks beyond the count leave at once)
   const dim3 grid(tile_grid(num_tiles) + (seg.chk ? seg.extra_cap : 0)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
@@ -1004,7 +1402,7 @@ int gsplat_render_image(const float *uv, const float *opacity, const float *coni
   gs::RawSplats raw = {uv, opacity, conic, rgb};
   return gs::launch_render_fwd(nullptr, &raw, sorted_splats, splat_range_by_tile, image_width, image_height,
                                background_opacity, splats_per_pixel, weight_per_pixel, image, (hipStream_t)stream, nullptr,
-                               0, nullptr, nullptr, nullptr, nullptr);
+                               0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -569,7 +569,8 @@ def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
     per-pixel checkpoint {T, colour so far} at every 496th entry of such lists and the backward walks each segment some
     pixel reaches with a workgroup of its own.  Lists of 2 100 .. 7 000 entries whose pixels stop in front of, inside
     and behind the segment boundaries (opacities from faint to opaque); the gradients must be the oracle's, and the
-    first (unsplit) backward's."""
+    first (unsplit) backward's.  The forward of such a context runs every segment of those lists as a workgroup of its
+    own (gs_render.h: FwdSegments): image, transmittance and stop indices must be the oracle's as before."""
     torch, raster = gpu, pkg("raster")
     N, W, H, L = 24000, 160, 96, 1
     params = scene.make_gaussians(N, W, H, L)
@@ -598,12 +599,21 @@ def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
     assert (stops > 3 * 496).any() and ((stops > 496) & (stops < 992)).any(), "pixels must stop behind several boundaries"
     bref = orc.backward_pass(ref, cam, gi, c["bg"], L, threads=8)
     whole = None
-    for it in range(3):
+    for it in range(4):
         fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
         _check_forward(fwd, ref)
         grads = ctx.alloc_gradients(fwd["num_culled"], L, intermediates=True)
         ctx.backward_pass(dp, dc, gi_d, c["bg"], L, grads)
         assert ctx.counters()["segmented_backwards"] == it, "the split follows the forward before"
+        # (the forward's own split also waits for the previous forward's figures: how uneven the tiles' work is)
+        assert ctx.counters()["segmented_forwards"] == max(0, it - 1)
+        image = _np(fwd["image"]).copy()
+        if it == 2:
+            segmented_image = image
+            assert ctx.counters()["longest_chain"] == int(stops.max())
+        elif it == 3:  # the segments' colours are added in a fixed order: the same bits in every run
+            assert (image == segmented_image).all() and (_np(fwd["n"]) == stops_gpu).all()
+        stops_gpu = _np(fwd["n"]).copy()
         _check_backward(grads, bref)
         assert_grad_close(_np(grads["precompute_rgb"]), bref["rgb_pre"], "grad_precompute_rgb")
         got = {k: _np(grads[k]).copy() for k in ("precompute_rgb", "conic", "uv", "opacity")}
