@@ -1323,7 +1323,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // previous forward: its longest list says whether there is anything to split; the room for extra blocks follows what
     // the tiles of the previous forward asked for (a list that does not fit stays whole).
     gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-    const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin;
+    const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin && num_tiles <= 16384;  // (the table kernels' reach)
     if (split) {
       const size_t slots = cap / gs::kSegEntries + 2;  // (gs_render.h: segment_slot)
       const size_t asked = (size_t)*reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 6));
@@ -1335,7 +1335,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
              c->seg_chk.as<float4>(), c->image.as<float>(), (int)want, reinterpret_cast<int *>(c->d_pub + 6), nullptr};
     }
     // the tiles' largest stop indices of this forward, for the next one's decision below
-    const bool figures = !gs_no_fwd_segments() && c->last_longest > gs::kSegSplitMin;
+    const bool figures = !gs_no_fwd_segments() && c->last_longest > gs::kSegSplitMin && num_tiles <= 16384;
     if (figures) seg.stats = reinterpret_cast<int *>(c->d_pub + 5);
     // ... and for the forward itself (gs_render.h: FwdSegments): every segment of a long list a block of its own
     gs::FwdSegments fs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};

@@ -1139,20 +1139,43 @@ bool tile_order_supported(int num_tiles) { return ((num_tiles + 7) >> 3) <= kOrd
 // largest stop index per tile.  ONE workgroup walks the tiles in index order, 1024 at a time, with an exclusive scan of the
 // further segments each tile asks for: the table is the same in every run (an atomic counter per tile serialised ~1500
 // requests on one L2 line: 13.7 us).  A list whose segments do not fit into the launch's room stays whole, and so does
-// every list behind it; `asked` tells the host what would have been needed.
+// every list behind it; `asked` tells the host what would have been needed.  All of a thread's tiles are loaded up front
+// (at most kTableChunks = 16 of them: the counting-sort route ends at 16 384 tiles): chunk by chunk the kernel was five
+// global round trips long, 12 us behind every forward.
+constexpr int kTableChunks = 16;
+__device__ __forceinline__ int sum_below(const int *s_wave, int wave) {  // of the 16 per-wave totals, those of the waves in front
+  const int4 *v = reinterpret_cast<const int4 *>(s_wave);
+  const int4 a = v[0], b = v[1], c = v[2], d = v[3];
+  const int w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sum += k < wave ? w[k] : 0;
+  return sum;
+}
 __global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restrict__ ranges, const int *__restrict__ tops,
                                                              int num_tiles, TileSegments seg) {
-  __shared__ int s_wave[16];
+  __shared__ __attribute__((aligned(16))) int s_wave[16];
   __shared__ int s_base, s_count, s_max, s_sum;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_base = s_count = s_max = s_sum = 0;
+  int len[kTableChunks], top[kTableChunks];
+#pragma unroll
+  for (int c = 0; c < kTableChunks; ++c) {
+    const int t = c * 1024 + tid;
+    len[c] = top[c] = 0;
+    if (t < num_tiles) {
+      len[c] = ranges[t + 1] - ranges[t];
+      top[c] = tops[t];
+    }
+  }
   __syncthreads();
   if (seg.stats) {  // how uneven the tiles' work is: decides whether the next forward splits its long lists (gs_fused.hip)
     int mx = 0, sum = 0;
-    for (int t = tid; t < num_tiles; t += 1024) {
-      const int top = min(tops[t], ranges[t + 1] - ranges[t]);
-      mx = max(mx, top);
-      sum += top;
+#pragma unroll
+    for (int c = 0; c < kTableChunks; ++c) {
+      const int reach = min(top[c], len[c]);
+      mx = max(mx, reach);
+      sum += reach;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1164,11 +1187,12 @@ __global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restri
     if (tid == 0) { seg.stats[0] = s_max; seg.stats[1] = s_sum; }
   }
   if (seg.granted == nullptr) return;  // (a render-only context: the figures only)
-  for (int t0 = 0; t0 < num_tiles; t0 += 1024) {
-    const int t = t0 + tid;
-    const int len = t < num_tiles ? ranges[t + 1] - ranges[t] : 0;
-    const int top = len > kSegSplitMin ? min(tops[t], len) : 0;  // (the forward stores checkpoints for exactly these lists)
-    const int want = top > kSegEntries ? (top + kSegEntries - 1) / kSegEntries - 1 : 0;
+#pragma unroll
+  for (int c = 0; c < kTableChunks; ++c) {
+    if (c * 1024 >= num_tiles) break;
+    const int t = c * 1024 + tid;
+    const int reach = len[c] > kSegSplitMin ? min(top[c], len[c]) : 0;  // (the forward stores checkpoints for exactly these lists)
+    const int want = reach > kSegEntries ? (reach + kSegEntries - 1) / kSegEntries - 1 : 0;
     int incl = want;  // inclusive scan over the wave, then over the 16 waves
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1177,8 +1201,7 @@ __global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restri
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    int before = s_base;
-    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    const int before = s_base + sum_below(s_wave, wave);
     const int pos = before + incl - want;
     int granted = 0;
     if (want > 0 && pos + want <= seg.extra_cap) {
@@ -1217,42 +1240,62 @@ constexpr int kFwdMaxLayers = 128;
 #endif
 constexpr int kFwdThinLayer = GS_FWD_THIN_LAYER;  // layers of fewer blocks run their lists' segments side by side (phase A)
 __global__ __launch_bounds__(1024) void fwd_segments_table_kernel(const int *__restrict__ ranges, int num_tiles, FwdSegments fs) {
-  __shared__ int s_hist[kFwdMaxLayers + 2], s_more[kFwdMaxLayers + 2], s_base[kFwdMaxLayers + 2], s_cursor[kFwdMaxLayers + 2];
+  // [k]: lists of exactly k segments -> lists of more than k segments (suffix sums) | first block of layer k (prefix sums)
+  __shared__ int s_more[kFwdMaxLayers + 2], s_base[kFwdMaxLayers + 2], s_cursor[kFwdMaxLayers + 2], s_tmp[kFwdMaxLayers + 2];
   const int tid = threadIdx.x;
-  if (tid < kFwdMaxLayers + 2) s_hist[tid] = s_cursor[tid] = 0;
-  __syncthreads();
-  auto segments_of = [&](int t) {
-    if (t >= num_tiles) return 0;
-    const int len = ranges[t + 1] - ranges[t];
-    const int m = len > kSegSplitMin ? (len + kSegEntries - 1) / kSegEntries : 0;
-    return m > kFwdMaxLayers ? 0 : m;
-  };
-  for (int t = tid; t < num_tiles; t += 1024) {
-    const int m = segments_of(t);
-    if (m > 0) atomicAdd(&s_hist[m], 1);
+  if (tid < kFwdMaxLayers + 2) s_more[tid] = s_cursor[tid] = 0;
+  int m[kTableChunks];  // all of the thread's tiles up front (see tile_segments_kernel)
+#pragma unroll
+  for (int c = 0; c < kTableChunks; ++c) {
+    const int t = c * 1024 + tid;
+    m[c] = 0;
+    if (t < num_tiles) {
+      const int len = ranges[t + 1] - ranges[t];
+      const int segs = len > kSegSplitMin ? (len + kSegEntries - 1) / kSegEntries : 0;
+      m[c] = segs > kFwdMaxLayers ? 0 : segs;
+    }
   }
   __syncthreads();
-  if (tid <= kFwdMaxLayers) {  // L_k = lists with more than k segments
-    int more = 0;
-    for (int q = tid + 1; q <= kFwdMaxLayers; ++q) more += s_hist[q];
-    s_more[tid] = more;
-  }
+#pragma unroll
+  for (int c = 0; c < kTableChunks; ++c)
+    if (m[c] > 0) atomicAdd(&s_more[m[c]], 1);
   __syncthreads();
-  if (tid <= kFwdMaxLayers) {
-    int base = 0;
-    for (int q = 0; q < tid; ++q) base += s_more[q];
-    s_base[tid] = base;
-    fs.base[tid] = base;
+  // L_k = lists with more than k segments: exclusive suffix sums, then base_k = L_0 + .. + L_(k-1): exclusive prefix sums
+  // (Hillis-Steele over 129 threads: a thread adding up its 128 predecessors one LDS read after the other took 7 us)
+  const bool mine = tid <= kFwdMaxLayers;
+  int v = mine ? s_more[tid] : 0;
+  const int own = v;
+  for (int off = 1; off <= kFwdMaxLayers; off <<= 1) {
+    if (mine) s_tmp[tid] = v;
+    __syncthreads();
+    if (mine && tid + off <= kFwdMaxLayers) v += s_tmp[tid + off];
+    __syncthreads();
+  }
+  const int more = v - own;
+  if (mine) s_more[tid] = more;
+  v = more;
+  for (int off = 1; off <= kFwdMaxLayers; off <<= 1) {
+    if (mine) s_tmp[tid] = v;
+    __syncthreads();
+    if (mine && tid >= off) v += s_tmp[tid - off];
+    __syncthreads();
+  }
+  if (mine) {
+    s_base[tid] = v - more;
+    fs.base[tid] = v - more;
   }
   __syncthreads();
   const int total = s_base[kFwdMaxLayers];
   const bool fits = total <= fs.cap;
-  for (int t = tid; t < num_tiles; t += 1024) {
-    const int m = fits ? segments_of(t) : 0;
+#pragma unroll
+  for (int c = 0; c < kTableChunks; ++c) {
+    const int t = c * 1024 + tid;
+    if (t >= num_tiles) break;
+    const int segs = fits ? m[c] : 0;
     int rank = -1;
-    if (m > 0) {
-      rank = s_more[m] + atomicAdd(&s_cursor[m], 1);  // behind the lists of more segments
-      for (int k = 0; k < m; ++k) fs.blocks[s_base[k] + rank] = make_int2(t, k | (s_more[k] < kFwdThinLayer ? 1 << 30 : 0));
+    if (segs > 0) {
+      rank = s_more[segs] + atomicAdd(&s_cursor[segs], 1);  // behind the lists of more segments
+      for (int k = 0; k < segs; ++k) fs.blocks[s_base[k] + rank] = make_int2(t, k | (s_more[k] < kFwdThinLayer ? 1 << 30 : 0));
     }
     fs.rank[t] = rank;
   }
@@ -1282,22 +1325,36 @@ __global__ __launch_bounds__(256) void fwd_segments_combine_kernel(const int *__
   const bool inside = px < width && py < height;
   const int start = ranges[tile], total = ranges[tile + 1] - start;
   const int m = (total + kSegEntries - 1) / kSegEntries;
-  float ar = 0.0f, ag = 0.0f, ab = 0.0f, Tout = 1.0f, pref = 1.0f;
+  float ar = 0.0f, ag = 0.0f, ab = 0.0f, Tout = 1.0f;
   int n = total;
-  for (int k = 0; k < m; ++k) {
-    if (k > 0) {
-      // T in front of the boundary: what the segment in front left behind (read by the backward only for pixels that
-      // pass the boundary alive, for which it is exactly the T segment k started from)
-      pref = __uint_as_float((unsigned int)fs.granules[((size_t)fs.cap + fs.base[k - 1] + rank) * 256 + tid]);
-      if (seg.chk) seg.chk[(size_t)segment_slot(start, k) * 256 + tid] = make_float4(pref, ar, ag, ab);
+  // kAhead segments' values are requested before the first is looked at: one at a time the longest list's twenty
+  // segments were twenty dependent round trips (28 us behind the forward)
+  constexpr int kAhead = 8;
+  bool done = false;
+  for (int k0 = 0; k0 < m && !done; k0 += kAhead) {
+    int st[kAhead];
+    float4 p[kAhead];
+    float pref[kAhead];
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) {
+      const int k = min(k0 + q, m - 1);
+      const size_t slot = (size_t)(fs.base[k] + rank);
+      st[q] = fs.stop[slot * 256 + tid];
+      p[q] = fs.part[slot * 256 + tid];
+      // T in front of boundary k: what the segment in front left behind (read by the backward only for pixels that pass
+      // the boundary alive, for which it is exactly the T segment k started from)
+      pref[q] = k > 0 ? __uint_as_float((unsigned int)fs.granules[((size_t)fs.cap + fs.base[k - 1] + rank) * 256 + tid]) : 1.0f;
     }
-    const size_t slot = (size_t)(fs.base[k] + rank);
-    const int st = fs.stop[slot * 256 + tid];
-    if (st == -2) break;  // (a pixel outside the image; inside it a pixel is dead only behind the segment it stopped in)
-    const float4 p = fs.part[slot * 256 + tid];
-    ar += p.x; ag += p.y; ab += p.z;
-    Tout = p.w;
-    if (st >= 0) { n = st; break; }
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) {
+      const int k = k0 + q;
+      if (k >= m || done) break;
+      if (k > 0 && seg.chk) seg.chk[(size_t)segment_slot(start, k) * 256 + tid] = make_float4(pref[q], ar, ag, ab);
+      if (st[q] == -2) { done = true; break; }  // (a pixel outside the image; inside it a pixel is dead only behind the segment it stopped in)
+      ar += p[q].x; ag += p[q].y; ab += p[q].z;
+      Tout = p[q].w;
+      if (st[q] >= 0) { n = st[q]; done = true; }
+    }
   }
   if (tops_out) {
     int top = inside ? n : 0;
