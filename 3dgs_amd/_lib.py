@@ -150,6 +150,7 @@ SIGNATURES = {
     "gsplat_precompute_spherical_harmonics_backward": (_I, [_P, _P, _P, _F, _F, _F, _P, _I, _I, _P, _P, _P, _P]),
     "gsplat_render_image_backward": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gsplat_context_set_binning_route": (_I, [_P, _I]),
+    "gsplat_context_set_segment_options": (_I, [_P, _I, _I, ctypes.c_float]),
     "gsplat_backward_render": (_I, [_P, _P, _F, _P, _P]),
     "gsplat_context_detach_forward_outputs": (_I, [_P]),
     "gsplat_context_last_compaction": (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I)]),

@@ -85,6 +85,8 @@ struct gsplat_context {
   void *fseg_gran_zeroed = nullptr;  // the granule block whose tags have been cleared (a fresh block holds anything)
   size_t fseg_gran_zeroed_bytes = 0;
   unsigned int fseg_epoch = 0;
+  int fseg_poll_budget = gs::kFwdPollBudget, fseg_thin_layer = gs::kFwdThinLayerDefault;
+  double fseg_gate = -1.0;  // < 0: GSPLAT_FWD_SEGMENTS_GATE / its default
   unsigned long long n_segmented_forwards = 0;
   int seg_cap = 0;          // extra segments the recorded forward had room for
   bool seg_ready = false;   // the recorded forward wrote the table and the checkpoints
@@ -1338,14 +1340,15 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     const bool figures = !gs_no_fwd_segments() && c->last_longest > gs::kSegSplitMin && num_tiles <= 16384;
     if (figures) seg.stats = reinterpret_cast<int *>(c->d_pub + 5);
     // ... and for the forward itself (gs_render.h: FwdSegments): every segment of a long list a block of its own
-    gs::FwdSegments fs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+    gs::FwdSegments fs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
     // Only where the tiles' work is uneven enough for ONE list to set the launch's duration: the previous forward's longest
     // chain (the largest stop index of any tile) against the work per resident workgroup (the sum over the tiles / 2048).
     // A throughput-bound scene gains nothing from the split and pays for its table, its combine pass and the product passes
     // (garden-shaped synthetic scene 0.197 -> 0.271 ms, dense4m 0.183 -> 0.26 when split regardless).
     const volatile int *figs = reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 5));
     const long long top_max = figs[0], top_sum = figs[1];
-    const bool fsplit = figures && top_sum > 0 && top_max * 2048ll > (long long)(gs_fwd_segments_gate() * (double)top_sum);
+    const double gate = c->fseg_gate >= 0.0 ? c->fseg_gate : gs_fwd_segments_gate();
+    const bool fsplit = figures && top_sum > 0 && top_max * 2048ll > (long long)(gate * (double)top_sum);
     if (fsplit) {
       const size_t most = cap / gs::kSegEntries + (size_t)num_tiles + 8;  // sum of ceil(len / kSegEntries) over any lists
       const size_t asked = (size_t)*reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 7));
@@ -1364,7 +1367,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       fs = {c->fseg_first.as<int>(), c->fseg_first.as<int>() + num_tiles + 8, c->fseg_blocks.as<int2>(),
             reinterpret_cast<int *>(c->fseg_blocks.as<int2>() + want),
             c->fseg_gran.as<unsigned long long>(), c->fseg_part.as<float4>(), c->fseg_stop.as<int>(), (int)want,
-            c->fseg_epoch, reinterpret_cast<int *>(c->d_pub + 7)};
+            c->fseg_epoch, reinterpret_cast<int *>(c->d_pub + 7), c->fseg_poll_budget, c->fseg_thin_layer};
       if ((r = gs::launch_fwd_segments_table(c->ranges.as<int>(), num_tiles, fs, st))) return r;
       c->n_segmented_forwards++;
     }
@@ -1667,6 +1670,14 @@ int gsplat_context_set_binning_route(gsplat_context *c, int route) {
   GS_REQUIRE(c != nullptr, "null context");
   GS_REQUIRE(route >= 0 && route <= 2, "route: 0 auto, 1 counting sort, 2 radix sorts");
   c->forced_route = route;
+  return GSPLAT_OK;
+}
+
+int gsplat_context_set_segment_options(gsplat_context *c, int poll_budget, int thin_layer_blocks, float gate) {
+  GS_REQUIRE(c != nullptr, "null context");
+  if (poll_budget >= 0) c->fseg_poll_budget = poll_budget > 0 ? poll_budget : 1;
+  if (thin_layer_blocks >= 0) c->fseg_thin_layer = thin_layer_blocks;
+  if (gate >= 0.0f) c->fseg_gate = gate;
   return GSPLAT_OK;
 }
 

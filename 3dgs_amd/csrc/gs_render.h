@@ -517,7 +517,9 @@ struct FwdSegments {
   int cap;                       // room for segment blocks; a multiple of 8 (the main blocks keep their XCDs)
   unsigned int epoch;            // of this launch; never 0
   int *asked;                    // [1], host-visible: segment blocks the lists asked for
+  int poll_budget;               // polls (~1 us each) before a segment block multiplies the product up itself
+  int thin_layer;                // layers of fewer blocks run their lists' segments side by side (phase A)
 };
-constexpr int kFwdPollBudget = 4096;  // polls (~1 us each) before a segment block multiplies the product up itself
+constexpr int kFwdPollBudget = 4096, kFwdThinLayerDefault = 512;  // (gsplat_context_set_segment_options changes them)
 
 }  // namespace gs

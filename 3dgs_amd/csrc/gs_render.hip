@@ -321,7 +321,7 @@ __device__ __forceinline__ void fwd_segment_block(const float4 *__restrict__ rec
         const float tk = fwd_t_product<kPacked>(recs, raw, sorted, start, a, b, false, tx0, ty0, fpx, fpy, tid, s_r0, s_r1, s_r2, s_list);
         granule_store(gran_t, fs.epoch, tk);
       }
-      const bool got = resolve_prefix(fs, rank, tid, k, kFwdPollBudget, prefix);
+      const bool got = resolve_prefix(fs, rank, tid, k, fs.poll_budget, prefix);
       if (__syncthreads_or(got ? 0 : 1))  // (rare: the blocks in front have not run yet and may be waiting for this CU)
         prefix = fwd_t_product<kPacked>(recs, raw, sorted, start, 0, a, true, tx0, ty0, fpx, fpy, tid, s_r0, s_r1, s_r2, s_list);
     }
@@ -1235,10 +1235,6 @@ int launch_tile_segments(const int *ranges, const int *tops, int num_tiles, cons
 // LDS.  A list of more than kFwdMaxLayers segments keeps its one block; if the blocks do not fit into the launch's room
 // nothing is split (the next launch's room follows `asked`).
 constexpr int kFwdMaxLayers = 128;
-#ifndef GS_FWD_THIN_LAYER
-#define GS_FWD_THIN_LAYER 512
-#endif
-constexpr int kFwdThinLayer = GS_FWD_THIN_LAYER;  // layers of fewer blocks run their lists' segments side by side (phase A)
 __global__ __launch_bounds__(1024) void fwd_segments_table_kernel(const int *__restrict__ ranges, int num_tiles, FwdSegments fs) {
   // [k]: lists of exactly k segments -> lists of more than k segments (suffix sums) | first block of layer k (prefix sums)
   __shared__ int s_more[kFwdMaxLayers + 2], s_base[kFwdMaxLayers + 2], s_cursor[kFwdMaxLayers + 2], s_tmp[kFwdMaxLayers + 2];
@@ -1295,7 +1291,7 @@ __global__ __launch_bounds__(1024) void fwd_segments_table_kernel(const int *__r
     int rank = -1;
     if (segs > 0) {
       rank = s_more[segs] + atomicAdd(&s_cursor[segs], 1);  // behind the lists of more segments
-      for (int k = 0; k < segs; ++k) fs.blocks[s_base[k] + rank] = make_int2(t, k | (s_more[k] < kFwdThinLayer ? 1 << 30 : 0));
+      for (int k = 0; k < segs; ++k) fs.blocks[s_base[k] + rank] = make_int2(t, k | (s_more[k] < fs.thin_layer ? 1 << 30 : 0));
     }
     fs.rank[t] = rank;
   }
@@ -1388,7 +1384,7 @@ int launch_render_fwd(const float4 *recs, const RawSplats *raw, const int *sorte
   const int ntx = (width + 15) / 16, nty = (height + 15) / 16, num_tiles = ntx * nty;
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   const TileSegments seg = segments ? *segments : TileSegments{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-  const FwdSegments fs = fwd_segments ? *fwd_segments : FwdSegments{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+  const FwdSegments fs = fwd_segments ? *fwd_segments : FwdSegments{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
   const dim3 grid(tile_grid(num_tiles) + (fs.blocks ? fs.cap : 0)), block(256);
   if (recs) {
     render_fwd_kernel<true><<<grid, block, 0, st>>>(recs, none, sorted, ranges, width, height, ntx, num_tiles, bg, n_out, T_out, image, zero, zero_vec, masks_out, order, tops_out, seg, fs);

@@ -131,6 +131,11 @@ class RasterContext:
         """0 automatic, 1 LDS counting sort + per-tile depth sort, 2 stable radix sorts (identical results)."""
         check(self._lib.gsplat_context_set_binning_route(self._h, int(route)))
 
+    def set_segment_options(self, poll_budget=-1, thin_layer_blocks=-1, gate=-1.0):
+        """Testing / tuning hook of the forward's long-list segments (gsplat_context_set_segment_options); results do not
+        depend on it."""
+        check(self._lib.gsplat_context_set_segment_options(self._h, int(poll_budget), int(thin_layer_blocks), float(gate)))
+
     def set_render_only(self, enabled):
         """Serving mode: forwards skip the outputs only a backward reads (see gsplat_context_set_render_only)."""
         check(self._lib.gsplat_context_set_render_only(self._h, int(bool(enabled))))

@@ -426,6 +426,16 @@ int gsplat_backward_gaussians_split(gsplat_context *ctx, const gsplat_gaussians 
  * tiles, stable radix sorts on (depth bits, tile).  1 / 2 force one route.  Both produce identical lists. */
 int gsplat_context_set_binning_route(gsplat_context *ctx, int route);
 
+/* Testing / tuning hook for the forward's long-list segments (every value < 0 keeps what is set).
+ * poll_budget: how often a segment's workgroup polls for the transmittance published by the workgroups in front of it
+ * before it multiplies that product up itself (default 4096; 1 makes every workgroup that is not handed its value at once
+ * take that path -- same values, more work).  thin_layer_blocks: layers of fewer segment workgroups run their lists'
+ * segments side by side, each publishing its own transmittance product first (default 512; 0: none do, every workgroup
+ * waits for the one in front).  gate: the forward splits its long lists when the previous forward's longest chain exceeded
+ * gate x the work per resident workgroup (default 3, or GSPLAT_FWD_SEGMENTS_GATE; 0: always).  Results do not depend on
+ * any of the three. */
+int gsplat_context_set_segment_options(gsplat_context *ctx, int poll_budget, int thin_layer_blocks, float gate);
+
 /* Measurement hook: when enabled, every stage of the two fused passes is bracketed by HIP events on the
  * caller's stream.  Stage ids: 0 project+cull+scan, 1 preprocess+scan, 2 emit + tile sort + ranges + per-tile depth sort, 3 reserved,
  * 4 compositing forward, 5 gradient-row memset, 6 compositing backward, 7 per-gaussian backward.

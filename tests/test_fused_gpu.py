@@ -622,6 +622,27 @@ def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
         else:
             for k in whole:  # the same sums in another order of the atomics, plus the checkpoint's rounding
                 assert_grad_close(got[k], whole[k], k + " (segments vs whole lists)")
+    # However a segment's workgroup obtains the transmittance in front of it -- handed over by the workgroup in front (no
+    # layer runs side by side), folded from the products the workgroups in front published (every layer does), or
+    # multiplied up by itself because its polls ran out (a budget of one poll) -- the value is the same left fold, so the
+    # forward's outputs must be the SAME BITS, and the render-only context's too.
+    T_gpu = _np(fwd["T"]).copy()
+    for what, opts in (("every workgroup waits for the one in front", dict(thin_layer_blocks=0)),
+                       ("all layers side by side", dict(thin_layer_blocks=1 << 20)),
+                       ("one poll, then the product from entry 0", dict(poll_budget=1, thin_layer_blocks=1 << 20)),
+                       ("one poll, nobody publishes products", dict(poll_budget=1, thin_layer_blocks=0)),
+                       ("render only", dict(render_only=True))):
+        other = raster.RasterContext(N, W, H)
+        other.set_binning_route(1)
+        if opts.pop("render_only", False):
+            other.set_render_only(True)
+        other.set_segment_options(**opts)
+        for it in range(3):
+            out = other.rasterize_image(dp, dc, c, c["bg"], L)
+            torch.cuda.synchronize()  # (the next forward decides by the figures the kernels behind this one publish)
+        assert other.counters()["segmented_forwards"] == 1, what
+        assert (_np(out["image"]) == segmented_image).all(), what
+        assert (_np(out["n"]) == stops_gpu).all() and (_np(out["T"]) == T_gpu).all(), what
 
 
 def test_factored_exchange_equals_full_rows(gpu, scene):
