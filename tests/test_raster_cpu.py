@@ -52,3 +52,44 @@ def test_chunk_ownership_arithmetic():
         for w in range(16):
             seen[b + K * w::K * 16] += 1
     assert (seen == 1).all()
+
+
+def test_segment_slot_arithmetic():
+    """gs_render.h (r05): the checkpoint of boundary k >= 1 of a tile whose list starts at instance r lives in slot
+    r // S + k, S = 496 -- no table.  Restated here: over random tile lists no two boundaries of lists beyond the split
+    threshold share a slot and every slot is below instances // S + 2, the pool's size.  And the forward's block table:
+    with the long lists ranked by their number of segments (most first), segment (t, k) is block base[k] + rank[t] with
+    base[k] = L_0 + .. + L_(k-1), L_k = lists of more than k segments -- a bijection onto [0, sum of the segments), every
+    block of a list behind the list's earlier ones."""
+    import numpy as np
+    S, split_min = 496, 1488
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        T = int(rng.integers(1, 400))
+        lens = rng.choice([0, 1, 37, 495, 496, 497, 1487, 1488, 1489, 1984, 1985, 5000, 9800, 20000], size=T) + \
+            rng.integers(0, 3, size=T)
+        starts = np.concatenate([[0], np.cumsum(lens)])
+        total = int(starts[-1])
+        slots = []
+        for t in range(T):
+            if lens[t] > split_min:
+                m = -(-int(lens[t]) // S)
+                slots += [int(starts[t]) // S + k for k in range(1, m)]   # boundaries 1 .. m - 1
+        assert len(slots) == len(set(slots))
+        assert not slots or max(slots) < total // S + 2
+        # the forward's table
+        m = np.where(lens > split_min, -(-lens // S), 0)
+        order = np.argsort(-m, kind="stable")
+        rank = np.empty(T, int)
+        rank[order] = np.arange(T)
+        L = np.array([(m > k).sum() for k in range(int(m.max()) + 1)])
+        base = np.concatenate([[0], np.cumsum(L)])
+        blocks = {}
+        for t in range(T):
+            for k in range(int(m[t])):
+                assert rank[t] < L[k]
+                b = int(base[k] + rank[t])
+                assert b not in blocks
+                blocks[b] = (t, k)
+                assert k == 0 or base[k - 1] + rank[t] < b      # the segment in front has the smaller block index
+        assert sorted(blocks) == list(range(int(m.sum())))
