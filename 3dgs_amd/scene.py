@@ -168,6 +168,9 @@ WORKLOADS = {
     # points, DESIGN section 9: 1.26 M gaussians at 1297x840, tile lists of ~1100 entries on average and ~10 000 in the
     # tiles of the object in the middle), in Morton order as a training run keeps them
     "garden1200k": (1_260_000, 1297, 840, 3, True),
+    # not a BASELINE config: a TRAINED view's shape (make_veiled): lists of ~10 000 entries whose pixels never saturate --
+    # the scene on which one tile's list used to be the duration of both compositing launches (r05: lists in segments)
+    "veiled1200k": (1_260_000, 1297, 840, 3, True),
 }
 
 
@@ -181,11 +184,26 @@ def make_garden_like(N, W, H, L, seed=SEED, splat_scale=1.8, cluster_fraction=0.
     return morton_order(cull_half(p, seed, cull))
 
 
+def make_veiled(N, W, H, L, seed=SEED, faint_fraction=0.35, faint_scale=0.4, faint_sigma=0.05, faint_opacity=(-5.5, -3.5)):
+    """The shape of a TRAINED view of the generated garden capture ("on a trained capture"): the
+    garden-like scene without its opaque object, plus a veil of small, faint splats over the middle of the image -- tile
+    lists of ~10 000 entries there whose pixels never saturate (each splat reaches a few pixels with alpha of a few
+    hundredths), so the longest list IS the longest chain of the compositing kernels.  That is what training produces and
+    what neither the uniform benchmark scene nor the garden-like one (whose long lists saturate early) has."""
+    n_faint = int(N * faint_fraction)
+    base = cull_half(make_gaussians(N - n_faint, W, H, L, seed, splat_scale=1.8, opacity_range=(-5.0, 0.5)), seed, 0.40)
+    faint = make_gaussians(n_faint, W, H, L, seed + 17, splat_scale=faint_scale, cluster=(1.0, 0.5, 0.55, faint_sigma),
+                           opacity_range=faint_opacity)
+    return morton_order({k: np.concatenate([base[k], faint[k]], 0) for k in base})
+
+
 def make_workload_gaussians(name, seed=SEED):
     """The gaussians of a named workload, with its variant applied (half culled, Morton order, large splats)."""
     N, W, H, L, _ = WORKLOADS[name]
     if name == "garden1200k":
         return make_garden_like(N, W, H, L, seed)
+    if name == "veiled1200k":
+        return make_veiled(N, W, H, L, seed)
     params = make_gaussians(N, W, H, L, seed, splat_scale=5.0 if name == "bigsplats" else 1.0)
     if name == "config3_halfculled":
         params = cull_half(params, seed)

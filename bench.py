@@ -379,6 +379,26 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
     out["roofline"] = compositing_rooflines(S_eff, W * H, st["render_forward"][0], st["render_backward"][0], counters)
     if note:
         out["roofline"]["note"] = note
+    if name == "veiled1200k":
+        # the scene of the long-list segments: what the context did, and the forward of a second context
+        # whose gate keeps one workgroup per tile (the backward's split has no per-context switch: GSPLAT_NO_SEGMENTS=1)
+        c = ctx.counters()
+        ctx.close()
+        ctx = raster.RasterContext(N, W, H)
+        ctx.set_lean_forward(True)
+        ctx.set_segment_options(gate=1e9)
+        for _ in range(5):
+            ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+            ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
+        whole = stage_pass(ctx, dp, dc, dgi, cfg, L, grads, reps)
+        out["segments"] = {"segmented_forwards": c["segmented_forwards"], "segmented_backwards": c["segmented_backwards"],
+                           "forwards": c["forwards"], "longest_chain": c["longest_chain"], "chain_sum": c["chain_sum"],
+                           "longest_chain_over_work_per_resident_workgroup": round(c["longest_chain"] * 2048 / max(1, c["chain_sum"]), 2),
+                           "render_forward_ms": round(st["render_forward"][0], 4),
+                           "render_forward_ms_one_workgroup_per_tile": round(whole["render_forward"][0], 4),
+                           "what": "lists beyond 1488 entries are walked in segments of 496 by workgroups of their own, in both "
+                                   "compositing kernels (gs_render.h: TileSegments, FwdSegments); the second forward figure is a "
+                                   "context whose gate (gsplat_context_set_segment_options) keeps the forward whole"}
     if train_it_s is not None:
         out["train_it_s"] = round(train_it_s, 1)
         out["roofline_in_training_iteration"] = compositing_rooflines(S_eff, W * H, train_stage["render_forward"][0],
@@ -844,11 +864,20 @@ def run_rank(args, comm, device_index):
         except Exception as e:  # never lose the headline line to a side measurement
             alternating = {"error": repr(e)[:300]}
 
+    # ---- the reference host's own sequence on the headline workload (a child process), before the side workloads run
+    ref_host = None
+    legs_default = "1" if spawning_legs_allowed() else "0"
+    if world == 1 and do_bwd and os.environ.get("GSPLAT_BENCH_REFERENCE_HOST", legs_default) != "0":
+        try:
+            ref_host = reference_host_path(params, cam, gi, cfg, L)
+        except Exception as e:  # never lose the headline line to a side measurement
+            ref_host = {"error": repr(e)[:300]}
+
     # ---- non-headline workloads (extra keys): what real training views do to the per-gaussian kernels and the binning
     extra = None
     if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
         extra = {}
-        for name in ("config3_halfculled", "config3_morton", "dense4m", "bigsplats", "garden1200k"):
+        for name in ("config3_halfculled", "config3_morton", "dense4m", "bigsplats", "garden1200k", "veiled1200k"):
             try:
                 extra[name] = extra_workload(torch, scene, raster, name, dev)
             except Exception as e:  # never lose the headline line to a side measurement
@@ -867,13 +896,7 @@ def run_rank(args, comm, device_index):
     step_stats = ({"median": iv[len(iv) // 2], "min": iv[0], "max": iv[-1], "p90": iv[int(0.9 * (len(iv) - 1))],
                    "what": "host-clock intervals between consecutive steps of the timed region (each forward waits for "
                            "its count record, so an interval is one step of GPU time)"} if iv else None)
-    ref_host = None
     legs_default = "1" if spawning_legs_allowed() else "0"
-    if world == 1 and do_bwd and os.environ.get("GSPLAT_BENCH_REFERENCE_HOST", legs_default) != "0":
-        try:
-            ref_host = reference_host_path(params, cam, gi, cfg, L)
-        except Exception as e:  # never lose the headline line to a side measurement
-            ref_host = {"error": repr(e)[:300]}
     # the exchange's HOST cost through the real backend, one rank (a child: it needs a process group of its own)
     host_cost = None
     if world == 1 and do_bwd and args.workload == "config3" and os.environ.get("GSPLAT_BENCH_EXCHANGE_HOST_COST", legs_default) != "0":

@@ -11,6 +11,9 @@ cfg = scene.CONFIG
 if name == "garden1200k" and len(sys.argv) > 3:  # tuning: scale cluster_fraction cull op_lo op_hi
     a = [float(x) for x in sys.argv[3:8]]
     params = scene.make_garden_like(N, W, H, L, splat_scale=a[0], cluster_fraction=a[1], cull=a[2], opacity_range=(a[3], a[4]))
+elif name == "veiled1200k" and len(sys.argv) > 3:  # tuning: faint_fraction faint_scale faint_sigma op_lo op_hi
+    a = [float(x) for x in sys.argv[3:8]]
+    params = scene.make_veiled(N, W, H, L, faint_fraction=a[0], faint_scale=a[1], faint_sigma=a[2], faint_opacity=(a[3], a[4]))
 else:
     params = scene.make_workload_gaussians(name)
 dp = raster.device_params(params); dc = raster.device_camera(scene.make_camera(W, H, 0))
@@ -46,3 +49,8 @@ for _ in range(reps):
     ctx.backward_pass(dp, dc, dgi, cfg["bg"], L, grads)
 torch.cuda.synchronize()
 print(f"  {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per fwd+bwd; stages (ms): " + ", ".join(f"{k} {v[0]:.3f}" for k, v in st.items() if v[1]))
+c = ctx.counters()
+n = fwd["n"].view(-1).float()
+print(f"  stop indices: mean {n.mean().item():.0f} max {n.max().item():.0f}; longest chain {c['longest_chain']}, chain sum "
+      f"{c['chain_sum']} (x 2048 / sum = {c['longest_chain'] * 2048 / max(1, c['chain_sum']):.2f}: the forward splits above 3); "
+      f"segmented forwards {c['segmented_forwards']}, backwards {c['segmented_backwards']} of {c['forwards']} forwards")
