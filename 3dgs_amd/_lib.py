@@ -120,7 +120,7 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
-ABI_VERSION = 6  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
+ABI_VERSION = 7  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -132,6 +132,10 @@ SIGNATURES = {
     "gsplat_release_scratch": (_I, []),
     "gsplat_pool_alloc": (_I, [ctypes.POINTER(ctypes.c_void_p), _S]),
     "gsplat_pool_free": (_I, [_P]),
+    "gsplat_pool_alloc_on": (_I, [ctypes.POINTER(ctypes.c_void_p), _S, _P]),
+    "gsplat_pool_free_on": (_I, [_P, _P]),
+    "gsplat_pool_cross_stream_reuses": (ctypes.c_ulonglong, []),
+    "gsplat_pool_trim": (_I, [_S]),
     "gsplat_pool_release": (_I, []),
     "gsplat_pool_bytes": (_S, [_I]),
     "gsplat_compute_camera_space_points": (_I, [_P, _P, _I, _P, _P]),
@@ -192,6 +196,7 @@ SIGNATURES = {
                                   ctypes.POINTER(Gradients), _P]),
     "gsplat_context_set_render_only": (_I, [_P, _I]),
     "gsplat_context_set_lean_forward": (_I, [_P, _I]),
+    "gsplat_context_set_preprocess_split": (_I, [_P, _I]),
     "gsplat_context_get_counters": (_I, [_P, ctypes.POINTER(ctypes.c_longlong), _I]),
     "gsplat_context_set_timing": (_I, [_P, _I]),
     "gsplat_context_set_timing_stages": (_I, [_P, ctypes.c_uint]),

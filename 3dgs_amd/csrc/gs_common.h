@@ -104,9 +104,17 @@ struct DeviceBuffer {
   // the next reserve() finds a block of the same size class in the pool without touching the allocator -- how the
   // rasterize_image shim gives ForwardPassData the forward's own output arrays instead of copies (raster.cuh).
   bool pooled = false;
-  size_t wanted = 0;  // the largest size ever asked for: what reserve_again() restores after a detach
-  int reserve(size_t want);
-  int reserve_again() { return reserve(wanted); }
+  size_t wanted = 0;  // the largest size ever asked for
+  size_t detached_bytes = 0;  // size of the block detach() gave away: what reserve_again() restores (headroom included)
+  // `user`: the stream whose work will touch the storage next -- a pooled block that another stream returned is ordered
+  // behind that stream first (gsplat_pool_alloc_on); the hipMalloc path synchronises the device when it grows anyway
+  int reserve(size_t want, hipStream_t user = nullptr);
+  int reserve_again(hipStream_t user = nullptr) {
+    const size_t w = wanted;
+    const int rc = reserve(detached_bytes > wanted ? detached_bytes : wanted, user);
+    wanted = w;
+    return rc;
+  }
   void *detach();
   void release();
   template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
@@ -117,6 +125,7 @@ struct DeviceBuffer {
 // and once the caller has freed that block the pointer may name somebody else's data.  One watch per slot: watching
 // again replaces the previous block; pool_unwatch(slot) before the slot's owner dies.
 void pool_watch(const void *block, const unsigned char **slot);
+int pool_free_quiet(void *ptr);  // gsplat_pool_free for a block nothing queued on the device can still touch
 void pool_unwatch(const unsigned char **slot);
 
 // Scratch slots of the stand-alone operators (the reference allocates thrust::device_vector

@@ -36,7 +36,7 @@ int check_device_ptr(const void *p, const char *name, const char *fn) {
   return GSPLAT_OK;
 }
 
-int DeviceBuffer::reserve(size_t want) {
+int DeviceBuffer::reserve(size_t want, hipStream_t user) {
   if (want > wanted) wanted = want;
   if (want <= bytes) return GSPLAT_OK;
   size_t grow = want + want / 4 + 256;
@@ -49,7 +49,7 @@ int DeviceBuffer::reserve(size_t want) {
     if (ptr) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) { set_error("scratch: hipDeviceSynchronize: %s", hipGetErrorString(e)); return GSPLAT_ERR_HIP; }
-      (void)gsplat_pool_free(ptr);
+      (void)pool_free_quiet(ptr);  // (the device has just been synchronised)
       ptr = nullptr;
       bytes = 0;
     } else {
@@ -57,7 +57,7 @@ int DeviceBuffer::reserve(size_t want) {
     }
     ++generation;
     void *fresh = nullptr;
-    const int rc = gsplat_pool_alloc(&fresh, grow);
+    const int rc = gsplat_pool_alloc_on(&fresh, grow, user);  // r06: ordered behind whoever returned the block
     if (rc != GSPLAT_OK) return rc;
     ptr = fresh;
     bytes = grow;  // (the block may be larger -- its size class -- but only this much is promised)
@@ -82,6 +82,7 @@ int DeviceBuffer::reserve(size_t want) {
 }
 
 void *DeviceBuffer::detach() {
+  detached_bytes = bytes;  // what reserve_again() asks for: the same headroom, hence the same pool class
   void *p = ptr;
   ptr = nullptr;
   bytes = 0;
@@ -91,7 +92,7 @@ void *DeviceBuffer::detach() {
 
 void DeviceBuffer::release() {
   if (ptr) {
-    if (pooled) (void)gsplat_pool_free(ptr);
+    if (pooled) (void)pool_free_quiet(ptr);  // (release() runs behind a device synchronisation: context destruction)
     else (void)hipFree(ptr);
   }
   ptr = nullptr;
@@ -144,7 +145,14 @@ HostWords &host_words() { return g_words; }
 // ---- device block pool (gsplat_pool_alloc / gsplat_pool_free): see include/gsplat_hip.h
 namespace gs {
 namespace {
-struct PoolBlock { size_t cls; int device; };
+// `freed_on`: the stream whose queued work may still touch the block when it was returned (gsplat_pool_free_on), or
+// kQuiet when nothing can (the returner had synchronised the device).  r06: a request from ANOTHER stream first orders
+// itself behind that stream (pool_order_behind) -- until r05 a freed block was reusable at once by anybody, correct only
+// because every caller sat on the NULL stream (the reference host owns a second stream: cuda/trainer.cu:1257-1259).
+struct PoolBlock { size_t cls; int device; hipStream_t freed_on; };
+const hipStream_t kQuiet = reinterpret_cast<hipStream_t>(~(uintptr_t)0);
+hipEvent_t g_pool_event = nullptr;  // scratch event of pool_order_behind (used under the pool mutex)
+unsigned long long g_pool_cross_stream = 0;  // reuses that needed the ordering (gsplat_pool_cross_stream_reuses)
 std::mutex g_pool_mutex;
 std::unordered_map<void *, PoolBlock> g_pool_live, g_pool_idle_info;
 std::map<std::pair<int, size_t>, std::vector<void *>> g_pool_idle;  // (device, class size) -> cached blocks
@@ -206,22 +214,88 @@ void pool_watch(const void *block, const unsigned char **slot) {
 }
 }  // namespace gs
 
+namespace gs {
+namespace {
+// Work queued on `taker` from now on runs behind everything queued on `giver` so far (which includes whatever was queued
+// when the block was returned: the record happens later).  Same stream: stream order already says so.  The legacy NULL
+// stream orders itself with every BLOCKING stream by definition, but not with hipStreamNonBlocking ones (torch's side
+// streams, the context's sort streams), so it gets the event like any other pair.  A giver that has been destroyed
+// meanwhile cannot be recorded on: the device is synchronised instead (its queued work may still be running).
+int pool_order_behind(hipStream_t giver, hipStream_t taker) {
+  if (giver == kQuiet || giver == taker) return GSPLAT_OK;
+  ++g_pool_cross_stream;
+  if (!g_pool_event && hipEventCreateWithFlags(&g_pool_event, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    g_pool_event = nullptr;
+  }
+  if (g_pool_event && hipEventRecord(g_pool_event, giver) == hipSuccess &&
+      hipStreamWaitEvent(taker, g_pool_event, 0) == hipSuccess)
+    return GSPLAT_OK;
+  (void)hipGetLastError();
+  if (hipDeviceSynchronize() != hipSuccess) {
+    set_error("gsplat_pool_alloc: could not order the new owner of a block behind the stream that returned it");
+    return GSPLAT_ERR_HIP;
+  }
+  return GSPLAT_OK;
+}
+
+int pool_free_impl(void *ptr, hipStream_t freed_on) {
+  if (!ptr) return GSPLAT_OK;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  auto it = g_pool_live.find(ptr);
+  if (it == g_pool_live.end()) {
+    set_error("gsplat_pool_free: %p was not allocated by gsplat_pool_alloc (or was freed twice)", ptr);
+    return GSPLAT_ERR_INVALID_ARG;
+  }
+  PoolBlock b = it->second;
+  b.freed_on = freed_on;
+  g_pool_live.erase(it);
+  {
+    auto w = g_pool_watch.find(ptr);
+    if (w != g_pool_watch.end()) {  // somebody remembered this block by pointer: it stops meaning what it meant
+      *w->second = nullptr;
+      g_pool_watch_of.erase(w->second);
+      g_pool_watch.erase(w);
+    }
+  }
+  g_pool_live_bytes -= b.cls;
+  g_pool_idle[{b.device, b.cls}].push_back(ptr);
+  g_pool_idle_info[ptr] = b;
+  g_pool_idle_bytes += b.cls;
+  return GSPLAT_OK;
+}
+}  // namespace
+// a block nothing on the device can still be touching (the caller has synchronised): reusable by any stream at once
+int pool_free_quiet(void *ptr) { return pool_free_impl(ptr, kQuiet); }
+}  // namespace gs
+
 extern "C" {
-int gsplat_pool_alloc(void **ptr, size_t bytes) {
+int gsplat_pool_alloc_on(void **ptr, size_t bytes, void *stream) {
   GS_REQUIRE(ptr != nullptr, "ptr is null");
   *ptr = nullptr;
   if (bytes == 0) return GSPLAT_OK;
   int dev = 0;
   GS_HIP(hipGetDevice(&dev));
   const size_t cls = gs::pool_class(bytes);
+  const hipStream_t taker = (hipStream_t)stream;
   std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
   auto it = gs::g_pool_idle.find({dev, cls});
   if (it != gs::g_pool_idle.end() && !it->second.empty()) {
-    void *p = it->second.back();
-    it->second.pop_back();
+    // a block this stream returned itself (or a quiet one) needs no ordering: look for one among the most recent returns
+    std::vector<void *> &v = it->second;
+    size_t pick = v.size() - 1;
+    for (size_t k = v.size(), seen = 0; k-- > 0 && seen < 8; ++seen) {
+      const hipStream_t f = gs::g_pool_idle_info[v[k]].freed_on;
+      if (f == taker || f == gs::kQuiet) { pick = k; break; }
+    }
+    void *p = v[pick];
+    const gs::PoolBlock b = gs::g_pool_idle_info[p];
+    const int rc = gs::pool_order_behind(b.freed_on, taker);
+    if (rc != GSPLAT_OK) return rc;
+    v.erase(v.begin() + (long)pick);
     gs::g_pool_idle_info.erase(p);
     gs::g_pool_idle_bytes -= cls;
-    gs::g_pool_live[p] = {cls, dev};
+    gs::g_pool_live[p] = {cls, dev, gs::kQuiet};
     gs::g_pool_live_bytes += cls;
     *ptr = p;
     return GSPLAT_OK;
@@ -238,34 +312,52 @@ int gsplat_pool_alloc(void **ptr, size_t bytes) {
     gs::set_error("gsplat_pool_alloc: hipMalloc(%zu) failed: %s", cls, hipGetErrorString(e));
     return GSPLAT_ERR_HIP;
   }
-  gs::g_pool_live[p] = {cls, dev};
+  gs::g_pool_live[p] = {cls, dev, gs::kQuiet};
   gs::g_pool_live_bytes += cls;
   *ptr = p;
   return GSPLAT_OK;
 }
 
-int gsplat_pool_free(void *ptr) {
-  if (!ptr) return GSPLAT_OK;
+int gsplat_pool_alloc(void **ptr, size_t bytes) { return gsplat_pool_alloc_on(ptr, bytes, nullptr); }
+
+int gsplat_pool_free_on(void *ptr, void *stream) { return gs::pool_free_impl(ptr, (hipStream_t)stream); }
+int gsplat_pool_free(void *ptr) { return gs::pool_free_impl(ptr, (hipStream_t)nullptr); }
+
+unsigned long long gsplat_pool_cross_stream_reuses(void) {
   std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
-  auto it = gs::g_pool_live.find(ptr);
-  if (it == gs::g_pool_live.end()) {
-    gs::set_error("gsplat_pool_free: %p was not allocated by gsplat_pool_alloc (or was freed twice)", ptr);
-    return GSPLAT_ERR_INVALID_ARG;
-  }
-  const gs::PoolBlock b = it->second;
-  gs::g_pool_live.erase(it);
-  {
-    auto w = gs::g_pool_watch.find(ptr);
-    if (w != gs::g_pool_watch.end()) {  // somebody remembered this block by pointer: it stops meaning what it meant
-      *w->second = nullptr;
-      gs::g_pool_watch_of.erase(w->second);
-      gs::g_pool_watch.erase(w);
+  return gs::g_pool_cross_stream;
+}
+
+// r06: what a context's destruction calls instead of gsplat_pool_release -- that one synchronises EVERY
+// device owning an idle block and frees the blocks cached for other live contexts, the shim's vectors and other rank
+// threads' devices.  This one looks at the CURRENT device only, which the caller has just synchronised (so its idle
+// blocks are quiet), and frees idle blocks -- largest classes first -- only while more than `keep_bytes` of them are
+// cached: a process that creates and destroys contexts of different sizes hoards at most that much.
+int gsplat_pool_trim(size_t keep_bytes) {
+  int dev = 0;
+  GS_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(gs::g_pool_mutex);
+  size_t idle_here = 0;
+  for (auto &kv : gs::g_pool_idle)
+    if (kv.first.first == dev) idle_here += kv.first.second * kv.second.size();
+  if (idle_here <= keep_bytes) return GSPLAT_OK;
+  bool synced = false;
+  for (auto it = gs::g_pool_idle.rbegin(); it != gs::g_pool_idle.rend() && idle_here > keep_bytes; ++it) {
+    if (it->first.first != dev) continue;
+    std::vector<void *> &v = it->second;
+    while (!v.empty() && idle_here > keep_bytes) {
+      void *p = v.back();
+      if (gs::g_pool_idle_info[p].freed_on != gs::kQuiet && !synced) {  // returned behind the caller's synchronisation
+        (void)hipDeviceSynchronize();
+        synced = true;
+      }
+      v.pop_back();
+      gs::g_pool_idle_info.erase(p);
+      (void)hipFree(p);
+      gs::g_pool_idle_bytes -= it->first.second;
+      idle_here -= it->first.second;
     }
   }
-  gs::g_pool_live_bytes -= b.cls;
-  gs::g_pool_idle[{b.device, b.cls}].push_back(ptr);
-  gs::g_pool_idle_info[ptr] = b;
-  gs::g_pool_idle_bytes += b.cls;
   return GSPLAT_OK;
 }
 

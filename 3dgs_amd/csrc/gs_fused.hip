@@ -62,6 +62,20 @@ int launch_tile_order(const int *work, const int *ranges, int num_tiles, int *or
 bool tile_order_supported(int num_tiles);
 }  // namespace gs
 
+// GSPLAT_PRE_SPLIT=0|1|2: the per-gaussian forward as one kernel (the default), as sh_colour_kernel + preprocess_geom_kernel
+// one behind the other, or side by side on two streams (r06: built, bit-identical, measured slower -- see sh_colour_kernel);
+// per context: gsplat_context_set_preprocess_split
+static int gs_pre_split_default() {
+  static const int v = [] { const char *e = getenv("GSPLAT_PRE_SPLIT"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 0; }();
+  return v;
+}
+// GSPLAT_PRE_JOIN=late: the caller's stream waits for the colour kernel only in front of render_fwd (the first reader of
+// the records' colour), not in front of the binning kernels
+static bool gs_pre_join_late() {
+  static const bool v = [] { const char *e = getenv("GSPLAT_PRE_JOIN"); return e && e[0] == 'l'; }();
+  return v;
+}
+
 struct gsplat_context {
   int max_gaussians = 0, max_width = 0, max_height = 0;
   // per-gaussian, global order
@@ -99,6 +113,13 @@ struct gsplat_context {
   bool backward_seen = false, rows_zeroed = false;  // training use: the forward clears grad_rows for the backward
   bool render_only = false;  // gsplat_context_set_render_only: forwards skip what only a backward would read
   bool lean = false;         // gsplat_context_set_lean_forward: Sigma / J / conic / colour are not materialised
+  // r06: the per-gaussian forward: 0 one fused kernel (r01-r05), 1 sh_colour_kernel then preprocess_geom_kernel on the
+  // caller's stream, 2 sh_colour_kernel BESIDE preprocess_geom_kernel on a stream of the context (pre_side) -- a stream
+  // of memory requests next to a kernel bound by its arithmetic (gsplat_context_set_preprocess_split)
+  int pre_split = gs_pre_split_default();
+  hipStream_t pre_side = nullptr;
+  hipEvent_t ev_pre_fork = nullptr, ev_pre_join = nullptr;
+  gs::DeviceBuffer chunk_first;  // [chunks of the index space]: slice-local rank of each chunk's first index (mode 2)
   gs::DeviceBuffer kept;     // slice-local lists of the kept gaussians (project_cull -> preprocess' compacted walk)
   gs::SortFork fork;         // side streams for the per-tile sorts of long lists (created when a forward first needs them)
   // the forward's record (gs_common.h: publish_record): pinned host memory the GPU writes and the host polls
@@ -164,6 +185,10 @@ struct gsplat_context {
     for (auto *p : all) p->release();
     fseg_gran_zeroed = nullptr;
     fork.destroy();
+    chunk_first.release();
+    if (pre_side) { (void)hipStreamDestroy(pre_side); pre_side = nullptr; }
+    if (ev_pre_fork) { (void)hipEventDestroy(ev_pre_fork); ev_pre_fork = nullptr; }
+    if (ev_pre_join) { (void)hipEventDestroy(ev_pre_join); ev_pre_join = nullptr; }
     if (h_words) (void)hipHostFree(h_words);
     h_words = nullptr;
     if (h_pub) { (void)hipHostFree((void *)h_pub); h_pub = nullptr; d_pub = nullptr; }
@@ -218,7 +243,8 @@ __global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const flo
                                                                        int *__restrict__ rank,
                                                                        int *__restrict__ slice_counts,
                                                                        unsigned long long *__restrict__ pair_counters,
-                                                                       int *__restrict__ kept) {
+                                                                       int *__restrict__ kept,
+                                                                       int *__restrict__ chunk_first) {
   extern __shared__ unsigned long long s_ballot[];  // [trips * 16] ballots, then [trips * 16] exclusive counts (int)
   constexpr int kWaves = gs::kBinThreads / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -269,6 +295,9 @@ __global__ __launch_bounds__(gs::kBinThreads) void project_cull_kernel(const flo
       const unsigned long long bal = s_ballot[t * kWaves + w];
       const int r = s_before[t * kWaves + w] + __popcll(bal & ((1ull << lane) - 1ull));
       rank[i] = r;
+      // r06: the slice-local rank of every 64-entry chunk's first index (a slice starts on a chunk boundary and a trip is
+      // sixteen chunks), for sh_colour_kernel when it runs BESIDE preprocess_geom_kernel, which rewrites rank[] in place
+      if (chunk_first && lane == 0) chunk_first[(lo >> 6) + t * kWaves + w] = s_before[t * kWaves + w];
       // the slice's kept gaussians as a list (preprocess_kernel's compacted walk; null when the next kernel walks all)
       if (kept && ((bal >> lane) & 1ull)) kept[lo + r] = i;
     }
@@ -510,6 +539,392 @@ __global__ __launch_bounds__(gs::kBinThreads) void preprocess_kernel(gsplat_gaus
   }
   // candidate-pair count (what call 1 of get_sorted_gaussian_list reports): one atomic per wave, spread over 64
   // counters so that no single address serialises the chip
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) coarse += __shfl_down(coarse, off, 64);
+  if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(&o.pairs[(blockIdx.x * 16 + (threadIdx.x >> 6)) & 63], coarse);
+  if (table) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += gs::kBinThreads) table[(size_t)blockIdx.x * T + t] = s_hist[t];
+  }
+}
+
+// ---- r06: the per-gaussian forward as TWO kernels (gsplat_context_set_preprocess_split / GSPLAT_PRE_SPLIT) ------------
+// VERDICT r05 asked for the split that r04 had only priced: preprocess_kernel<3> needs 99-128 VGPRs (four waves per SIMD in
+// the 1024-thread shape of the LDS histogram) and reaches 36 % of HBM on its algorithmic bytes.  Built here, bit-identical
+// (tests/test_fused_gpu.py: test_preprocess_split_is_bit_identical), switchable -- and NOT the default, because it loses
+// (profiles/r06_ab_preprocess_split.txt, same box, alternating):
+//   sh_colour_kernel        SH -> colour as a plain stream: every wave moves its 64 rows (180 B each at degree 3) through
+//                           LDS as one linear span of 16-byte loads (gs_rows.h), writes 12 bytes per gaussian.
+//                           47 us for 228 MB = 4.8 TB/s.
+//   preprocess_geom_kernel  everything else in the persistent 256 x 1024 shape; a gaussian's inputs are 14 dwords, so the
+//                           chunk loop requests the next chunk's inputs a whole trip early, in front of the tile loop,
+//                           and defers the tile count / hit mask stores to the next trip (one wait per trip, on loads
+//                           and stores that are a tile loop old).  64 us lean / 69 us full.
+//   mode 1 (one behind the other) 112 / 121 us against the fused kernel's 86 / 103; mode 2 (side by side on two streams,
+//   the colour written straight into the records) 124 / 140: the geometry kernel slows down beside a stream of loads.
+// Where the geometry kernel's 64 us go (diagnostic builds, profiles/r06_ab_preprocess_split.txt): without its tile loop
+// 42 us, without tile loop and conic / radius arithmetic 40 us -- the floor is 150 MB, two thirds of it WRITTEN, at
+// 3.7 TB/s, and the order of loads and stores inside a trip does not move it (three orders measured).  The fused kernel
+// moves 350 MB (lean) in 86 us = 4.1 TB/s and 420 MB (every array stored) in 103 us: it already runs at the rate this
+// mix of strided 4..16-byte stores reaches, with the SH loads riding in the shadow of the arithmetic; the figure the
+// verdict compares it with, preprocess_bwd's 72 %, is a kernel whose traffic is linear spans read and written in equal
+// parts.  What is left in the fused kernel is its tile loop (9 us) and bytes (the tile count array, 4 B, is dead weight
+// on the sparse route).  cuda/raster.cu:78-100 runs the colour and the covariance chain as separate kernels too.
+// `rank`: the cull's slice-local ranks (sequential form, in front of preprocess_geom_kernel) or, when the kernel runs
+// beside that one -- which rewrites rank[] in place --, null: the rank then comes from `chunk_first` and the chunk's mask
+// ballot.  `recs`: the colour goes into the 48-byte records (r2.xyz; the geometry kernel writes the rest of the record,
+// r2.w included: disjoint bytes), `rgb_out`: and / or into ForwardPassData's colour array.
+template <int L, bool kCompact>
+__global__ __launch_bounds__(kBlock) void sh_colour_kernel(gsplat_gaussians g, const unsigned char *__restrict__ mask,
+                                                           const int *__restrict__ rank,
+                                                           const int *__restrict__ chunk_first,
+                                                           const int *__restrict__ slice_counts,
+                                                           const int *__restrict__ kept, float cx, float cy, float cz,
+                                                           float *__restrict__ rgb_out, float4 *__restrict__ recs) {
+  constexpr int n = (L + 1) * (L + 1), kRest = (n - 1) * 3;
+  static_assert(kRest > 0, "degree 0 has no rest coefficients: preprocess_geom_kernel forms the colour itself");
+  static_assert(gs::kBinBlocks == kBlock, "one thread per slice of the cull in the scan below");
+  __shared__ __attribute__((aligned(16))) float s_sh[kBlock * kRest];
+  __shared__ int s_base[gs::kBinBlocks + 1];
+  __shared__ int s_wsum[4];
+  const int N = g.num_gaussians;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  {  // kept gaussians before each of the cull's slices (as preprocess_kernel)
+    const int cnt = slice_counts[threadIdx.x];
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < w; ++q) before += s_wsum[q];
+    s_base[threadIdx.x] = before + incl - cnt;
+    if (threadIdx.x == gs::kBinBlocks - 1) s_base[gs::kBinBlocks] = before + incl;
+    __syncthreads();
+  }
+  const int M = s_base[gs::kBinBlocks];
+  const int C = gs::bin_chunks(N);
+  const int c = (int)blockIdx.x * (kBlock / 64) + w;  // this wave's chunk of the walked space
+  if (c >= gs::bin_chunks(kCompact ? M : N)) return;
+  const int e = c * gs::kBinChunk + lane;
+  int i = e, j = e;
+  bool act;
+  if constexpr (kCompact) {
+    act = e < M;
+    int sl = 0;
+#pragma unroll
+    for (int step = gs::kBinBlocks / 2; step > 0; step >>= 1) sl += (s_base[sl + step] <= e) ? step : 0;
+    i = act ? kept[gs::kBinChunk * gs::bin_slice_first_chunk(C, sl) + (e - s_base[sl])] : 0;
+  } else {
+    act = i < N && mask[i];
+  }
+  const unsigned long long actm = __ballot(act);
+  if (actm == 0ull) return;
+  if constexpr (!kCompact) {
+    if (rank) {
+      if (i < N) j = s_base[gs::bin_slice_of_chunk(C, c)] + rank[i];  // rank[]: still the cull's slice-local counts
+    } else {
+      j = s_base[gs::bin_slice_of_chunk(C, c)] + chunk_first[c] + __popcll(actm & ((1ull << lane) - 1ull));
+    }
+  }
+  float *wsh = s_sh + (threadIdx.x - lane) * kRest;
+  // position and band 0 of the lane's own gaussian: requested before the rows, used behind them
+  float px = 0.0f, py = 0.0f, pz = 0.0f, b0[3] = {0.0f, 0.0f, 0.0f};
+  if (act) {
+    px = g.xyz[3 * i]; py = g.xyz[3 * i + 1]; pz = g.xyz[3 * i + 2];
+    b0[0] = g.rgb[3 * i]; b0[1] = g.rgb[3 * i + 1]; b0[2] = g.rgb[3 * i + 2];
+  }
+  if (!kCompact && __popcll(actm) * 2 >= min(64, N - c * gs::kBinChunk)) {
+    // a chunk of consecutive indices of which most are kept: one linear span, culled rows included
+    gs::rows_to_lds<kRest>(g.sh + (size_t)c * gs::kBinChunk * kRest, wsh, min(64, N - c * gs::kBinChunk), lane);
+  } else {
+    // scattered rows (the compacted walk, or a chunk most of which is culled): twelve lanes fetch one row in 16-byte
+    // pieces, all of a wave's loads issued before the first LDS store (as preprocess_bwd_kernel)
+    constexpr int kPieces = (kRest + 3) / 4, kPer = 64 / kPieces, kIter = (64 + kPer - 1) / kPer;
+    const int grp = lane / kPieces, piece = lane - grp * kPieces;
+    const bool in_grp = grp < kPer;
+    float4 v[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int r = it * kPer + grp;
+      const int ir = __shfl(i, r < 64 ? r : 0, 64);
+      const bool want = in_grp && r < 64 && ((actm >> r) & 1ull);
+      v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (want) {
+        const float *src = g.sh + (size_t)ir * kRest + 4 * piece;
+        if (4 * piece + 3 < kRest) {
+          v[it] = __builtin_bit_cast(float4, *reinterpret_cast<const gs::f4u *>(src));
+        } else {
+          v[it].x = src[0];
+          if (4 * piece + 1 < kRest) v[it].y = src[1];
+          if (4 * piece + 2 < kRest) v[it].z = src[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int r = it * kPer + grp;
+      if (in_grp && r < 64 && ((actm >> r) & 1ull)) {
+        float *dst = wsh + r * kRest + 4 * piece;
+        dst[0] = v[it].x;
+        if (4 * piece + 1 < kRest) dst[1] = v[it].y;
+        if (4 * piece + 2 < kRest) dst[2] = v[it].z;
+        if (4 * piece + 3 < kRest) dst[3] = v[it].w;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (act) {
+    float dx, dy, dz, len, rgb[3];
+    gs::view_dir(px, py, pz, cx, cy, cz, dx, dy, dz, len);
+    gs::sh_to_rgb<L>(wsh + lane * kRest, b0, dx, dy, dz, rgb);
+    if (rgb_out) { rgb_out[3 * j] = rgb[0]; rgb_out[3 * j + 1] = rgb[1]; rgb_out[3 * j + 2] = rgb[2]; }
+    if (recs) {
+      float *r2 = reinterpret_cast<float *>(recs + 3 * (size_t)j + 2);
+      r2[0] = rgb[0]; r2[1] = rgb[1]; r2[2] = rgb[2];
+    }
+  }
+}
+
+// what a lane of preprocess_geom_kernel holds for a chunk it has not started yet
+struct GeomData { float x, y, z, sx, sy, sz, op; float4 q; };
+
+// kColour 0: degree 0 -- the colour is band 0 alone, formed here (no sh_colour_kernel); 1: read from o.rgb, where
+// sh_colour_kernel has left it (the two kernels one behind the other); 2: none -- sh_colour_kernel runs BESIDE this kernel
+// on a stream of its own and writes the colour into the records itself; this kernel stores r0, r1 and r2.w only
+template <int kColour, bool kStoreMid, bool kCompact>
+__global__ __launch_bounds__(gs::kBinThreads) void preprocess_geom_kernel(gsplat_gaussians g, const float *__restrict__ view,
+                                                                  const unsigned char *__restrict__ mask,
+                                                                  int *__restrict__ rank,
+                                                                  const int *__restrict__ slice_counts,
+                                                                  const int *__restrict__ kept,
+                                                                  const float *__restrict__ proj, int width, int height,
+                                                                  float fx, float fy, float tan_fovx, float tan_fovy,
+                                                                  float mh_dist, float cx, float cy, float cz, int ntx,
+                                                                  int nty, PreOut o, int *__restrict__ table) {
+  extern __shared__ int s_hist[];
+  __shared__ int s_base[gs::kBinBlocks + 1];
+  __shared__ int s_wsum[4];
+  __shared__ __attribute__((aligned(16))) float s_stage[kStoreMid ? gs::kBinThreads / 64 : 1][kStoreMid ? 64 * 12 : 4];
+  const int N = g.num_gaussians, T = ntx * nty;
+  static_assert(gs::kBinBlocks == 256, "the scan below is written for four waves of slice counts");
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int cnt = 0, incl = 0;
+    if (threadIdx.x < gs::kBinBlocks) {
+      cnt = slice_counts[threadIdx.x];
+      incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+      }
+      if (lane == 63) s_wsum[w] = incl;
+    }
+    if (table)
+      for (int t = threadIdx.x; t < T; t += gs::kBinThreads) s_hist[t] = 0;
+    __syncthreads();
+    if (threadIdx.x < gs::kBinBlocks) {
+      int before = 0;
+      for (int q = 0; q < w; ++q) before += s_wsum[q];
+      s_base[threadIdx.x] = before + incl - cnt;
+      if (threadIdx.x == gs::kBinBlocks - 1) s_base[gs::kBinBlocks] = before + incl;
+    }
+    __syncthreads();
+  }
+  const int M = s_base[gs::kBinBlocks];
+  const int C = gs::bin_chunks(N);
+  unsigned long long coarse = 0;
+  const int lane = threadIdx.x & 63;
+  for (long long i = (long long)M + (long long)blockIdx.x * gs::kBinThreads + threadIdx.x; i <= N;
+       i += (long long)gs::kBinBlocks * gs::kBinThreads)
+    o.counts[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) rank[N] = M;
+  const int walk_chunks = gs::bin_chunks(kCompact ? M : N);
+  constexpr int kStep = gs::kBinBlocks * (gs::kBinThreads / 64);
+  const int c_first = (int)blockIdx.x + gs::kBinBlocks * (int)(threadIdx.x >> 6);
+  // The pipeline.  s_waitcnt vmcnt counts a wave's loads AND stores in issue order on gfx950: waiting for a load that was
+  // issued behind stores waits for those stores' acknowledgements too, and a value's first use is where the compiler puts
+  // the wait.  So everything a chunk needs from memory is REQUESTED one trip early, at the top of the trip, in front of
+  // that trip's thirteen stores, and left untouched until the chunk's own trip begins: by then the loads are a whole
+  // trip old and the wait lets the younger stores stay in flight (r05's kernel waited three times per trip with all of
+  // its earlier stores still queued in front of the loads).
+  auto load_data = [&](int i) {
+    GeomData d;
+    d.x = g.xyz[3 * i]; d.y = g.xyz[3 * i + 1]; d.z = g.xyz[3 * i + 2];
+    d.q = reinterpret_cast<const float4 *>(g.quaternion)[i];
+    d.sx = g.scale[3 * i]; d.sy = g.scale[3 * i + 1]; d.sz = g.scale[3 * i + 2];
+    d.op = g.opacity[i];
+    return d;
+  };
+  const GeomData kNoData = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+  // all indices in order: a chunk's data are at its own indices (requested whether kept or not: this walk runs when at
+  // most a fifth is culled), rank[] and mask[] are requested with them.  compacted walk: the chunk's global indices come
+  // from `kept`, requested TWO trips early (the data loads of the trip in between take them as addresses).
+  int rk_n = 0, mk_n = 0, ix_n = 0, ix_nn = 0;  // raw: rank / mask of the next chunk | kept index of the next, next-next
+  GeomData d_n = kNoData;
+  auto kept_index = [&](int c) {  // global index of this lane's slot in chunk c of the compacted slots (0 past the end)
+    const int e = c * gs::kBinChunk + lane;
+    if (c >= walk_chunks || e >= M) return 0;
+    int sl = 0;
+#pragma unroll
+    for (int step = gs::kBinBlocks / 2; step > 0; step >>= 1) sl += (s_base[sl + step] <= e) ? step : 0;
+    return kept[gs::kBinChunk * gs::bin_slice_first_chunk(C, sl) + (e - s_base[sl])];
+  };
+  auto request = [&](int c) {  // the loads of chunk c (the chunk after the one being worked on)
+    rk_n = 0; mk_n = 0; d_n = kNoData;
+    const int e = c * gs::kBinChunk + lane;
+    if constexpr (kCompact) {
+      if (c < walk_chunks && e < M) d_n = load_data(ix_n);
+    } else {
+      if (c < walk_chunks && e < N) { rk_n = rank[e]; mk_n = mask[e]; d_n = load_data(e); }
+    }
+  };
+  if constexpr (kCompact) { ix_n = kept_index(c_first); }
+  request(c_first);
+  if constexpr (kCompact) { ix_nn = kept_index(c_first + kStep); }
+  bool late_act = false;  // the previous chunk's tile count and hit mask, stored with this trip's stores
+  int late_j = 0, late_hits = 0;
+  unsigned long long late_hm = 0ull;
+  for (int c = c_first; c < walk_chunks; c += kStep) {
+  // this chunk's values (requested a trip ago, in front of the previous tile loop)
+  const int e0 = c * gs::kBinChunk + lane;
+  const int rk = rk_n, mk = mk_n, i = kCompact ? ix_n : e0;
+  const GeomData cur = d_n;
+  bool act;
+  int j = e0;
+  if constexpr (kCompact) {
+    act = e0 < M;
+  } else {
+    act = e0 < N && mk != 0;
+    if (e0 < N) j = s_base[gs::bin_slice_of_chunk(C, c)] + rk;  // local -> global rank, for every index (see preprocess_kernel)
+  }
+  int hits = 0, span_n = 0;
+  unsigned long long hm = 0ull;
+  float bu = 0.0f, bv = 0.0f, br0 = 0.0f, br1 = 0.0f, br2 = 0.0f, br3 = 0.0f;
+  if (act) {
+    const gs::Mat34 vw = gs::load_view(view);
+    // the colour: requested here, used when the record is made
+    float rgb[3] = {0.0f, 0.0f, 0.0f};
+    if constexpr (kColour == 0) {
+      float dx, dy, dz, len;
+      gs::view_dir(cur.x, cur.y, cur.z, cx, cy, cz, dx, dy, dz, len);
+      gs::sh_to_rgb<0>(nullptr, g.rgb + 3 * i, dx, dy, dz, rgb);
+    } else if constexpr (kColour == 1) {
+      rgb[0] = o.rgb[3 * j]; rgb[1] = o.rgb[3 * j + 1]; rgb[2] = o.rgb[3 * j + 2];
+    }
+    const gs::RotScale rs = gs::rot_scale(cur.q.x, cur.q.y, cur.q.z, cur.q.w, cur.sx, cur.sy, cur.sz);
+    float sg[6], J[6], con[3], rad[4];
+    gs::sigma_from(rs, sg);
+    int pp = 0, nact = 0, j0 = 0;
+    float *wsh = s_stage[0];
+    if constexpr (kStoreMid) {
+      const unsigned long long actm = __ballot(true);
+      nact = __popcll(actm);
+      pp = __popcll(actm & ((1ull << lane) - 1ull));
+      j0 = __builtin_amdgcn_readfirstlane(j - pp);
+      wsh = s_stage[threadIdx.x >> 6];
+      wave_rows_store<6>(o.sigma, j0, pp, nact, sg, wsh);
+    }
+    float x, y, z, u, v;
+    gs::camera_space(vw, cur.x, cur.y, cur.z, x, y, z);
+    gs::to_screen(gs::load_proj(proj), x, y, z, width, height, u, v);
+    gs::jacobian(x, y, z, fx, fy, tan_fovx, tan_fovy, J);
+    gs::conic_radius(J, sg, vw, mh_dist, con, rad);
+    o.c2g[j] = i;
+    o.uv[2 * j] = u; o.uv[2 * j + 1] = v;
+    reinterpret_cast<float4 *>(o.radius)[j] = make_float4(rad[0], rad[1], rad[2], rad[3]);
+    const gs::SplatRec rec = gs::make_record(u, v, con[0], con[1], con[2], cur.op, rgb[0], rgb[1], rgb[2]);
+    if constexpr (kStoreMid) {
+      const float xyzc[3] = {x, y, z};
+      wave_rows_store<3>(o.xyz_c, j0, pp, nact, xyzc, wsh);
+      wave_rows_store<6>(o.J, j0, pp, nact, J, wsh);
+      wave_rows_store<3>(o.conic, j0, pp, nact, con, wsh);
+      if constexpr (kColour == 0) wave_rows_store<3>(o.rgb, j0, pp, nact, rgb, wsh);
+      if constexpr (kColour == 2) {  // (the colour's twelve bytes of the record belong to sh_colour_kernel)
+        o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1;
+        reinterpret_cast<float *>(o.recs + 3 * (size_t)j + 2)[3] = rec.r2.w;
+      } else {
+        const float rr[12] = {rec.r0.x, rec.r0.y, rec.r0.z, rec.r0.w, rec.r1.x, rec.r1.y, rec.r1.z, rec.r1.w,
+                              rec.r2.x, rec.r2.y, rec.r2.z, rec.r2.w};
+        wave_rows_store<12>(reinterpret_cast<float *>(o.recs), j0, pp, nact, rr, wsh);
+      }
+    } else {
+      o.xyz_c[3 * j] = x; o.xyz_c[3 * j + 1] = y; o.xyz_c[3 * j + 2] = z;
+      o.recs[3 * j] = rec.r0; o.recs[3 * j + 1] = rec.r1;
+      if constexpr (kColour == 2) reinterpret_cast<float *>(o.recs + 3 * (size_t)j + 2)[3] = rec.r2.w;
+      else o.recs[3 * j + 2] = rec.r2;
+    }
+    bu = u; bv = v; br0 = rad[0]; br1 = rad[1]; br2 = rad[2]; br3 = rad[3];
+  }
+  // the rest of the trip's stores -- the global rank (every index: the pack kernels read it through the mask) and the
+  // PREVIOUS chunk's tile count and hit mask, which its tile loop produced behind that trip's stores --, then the next
+  // chunk's requests, then the tile loop: no memory instruction in it, so when the loop top waits for the requests,
+  // everything this wave has in flight is a tile loop old
+  if constexpr (kCompact) {
+    if (act) rank[i] = j;
+  } else {
+    if (e0 < N) rank[e0] = j;
+  }
+  if (late_act) {
+    o.counts[late_j] = late_hits;
+    o.hitmask[late_j] = late_hm;
+  }
+  asm volatile("" ::: "memory");
+  if constexpr (kCompact) { ix_n = ix_nn; }
+  request(c + kStep);
+  if constexpr (kCompact) { ix_nn = kept_index(c + 2 * kStep); }
+  asm volatile("" ::: "memory");
+  if (act) {
+    const gs::TileRect r = gs::coarse_rect(bu, bv, br0, ntx, nty);
+    if (r.x1 > r.x0 && r.y1 > r.y0) {
+      coarse += (unsigned long long)(r.x1 - r.x0) * (unsigned long long)(r.y1 - r.y0);
+      const gs::Obb ob = gs::make_obb(bu, bv, br0, br1, br2, br3);
+      const gs::TileRect sp = gs::obb_span(ob, r);
+      const int rh = r.y1 - r.y0;
+      span_n = max(0, sp.x1 - sp.x0) * max(0, sp.y1 - sp.y0);
+      if (span_n <= kCoopTiles) {
+        for (int tx = sp.x0; tx < sp.x1; ++tx)
+          for (int ty = sp.y0; ty < sp.y1; ++ty) {
+            const bool h = gs::obb_hits_tile(ob, tx, ty);
+            const int bit = (tx - r.x0) * rh + (ty - r.y0);
+            hits += h ? 1 : 0;
+            hm |= (h && bit < 64) ? (1ull << bit) : 0ull;
+            if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
+          }
+      }
+    }
+  }
+  for (unsigned long long big = __ballot(span_n > kCoopTiles); big != 0ull; big &= big - 1ull) {  // (as preprocess_kernel)
+    const int owner = __builtin_ctzll(big);
+    const float ou = __shfl(bu, owner, 64), ov = __shfl(bv, owner, 64);
+    const float o0 = __shfl(br0, owner, 64), o1 = __shfl(br1, owner, 64), o2 = __shfl(br2, owner, 64), o3 = __shfl(br3, owner, 64);
+    const gs::TileRect r = gs::coarse_rect(ou, ov, o0, ntx, nty);
+    const gs::Obb ob = gs::make_obb(ou, ov, o0, o1, o2, o3);
+    const gs::TileRect sp = gs::obb_span(ob, r);
+    const int sh = sp.y1 - sp.y0, total = (sp.x1 - sp.x0) * sh;
+    int found = 0;
+    for (int p = lane; p < total + lane; p += 64) {
+      bool h = false;
+      if (p < total) {
+        const int tx = sp.x0 + p / sh, ty = sp.y0 + p % sh;
+        h = gs::obb_hits_tile(ob, tx, ty);
+        if (h && table) atomicAdd(&s_hist[ty * ntx + tx], 1);
+      }
+      found += __popcll(__ballot(h));
+    }
+    if (lane == owner) hits = found;
+  }
+  late_act = act; late_j = j; late_hits = hits; late_hm = hm;
+  }
+  if (late_act) {
+    o.counts[late_j] = late_hits;
+    o.hitmask[late_j] = late_hm;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) coarse += __shfl_down(coarse, off, 64);
   if ((threadIdx.x & 63) == 0 && coarse) atomicAdd(&o.pairs[(blockIdx.x * 16 + (threadIdx.x >> 6)) & 63], coarse);
@@ -1147,9 +1562,10 @@ int gsplat_context_destroy(gsplat_context *ctx) {
   (void)hipDeviceSynchronize();
   ctx->release();
   delete ctx;
-  // the context's pooled output arrays went back to the pool's idle lists: hand them to the runtime, or a process that
-  // creates and destroys contexts of different sizes would hoard one set of blocks per size
-  (void)gsplat_pool_release();
+  // the context's pooled output arrays went back to the pool's idle lists.  r06: they stay there for the next context /
+  // the shim's vectors of this device unless more than a gigabyte is idle on it (gsplat_pool_trim) -- r05 called the
+  // process-wide gsplat_pool_release here, which synchronised every device and emptied the caches of live peers
+  (void)gsplat_pool_trim((size_t)1 << 30);
   return GSPLAT_OK;
 }
 
@@ -1182,7 +1598,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     c->forward_outputs(outs);
     for (gs::DeviceBuffer *b : outs)
       if (b->ptr == nullptr) {
-        const int r = b->reserve_again();
+        const int r = b->reserve_again(st);  // (ordered behind the stream that returned the block, if another)
         if (r) return r;
         // a fresh `sorted` must hold valid gaussian ids wherever the speculative tail may read it (reserve_instances)
         if (b == &c->sorted) GS_HIP(hipMemsetAsync(b->ptr, 0, b->bytes, st));
@@ -1204,6 +1620,18 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   const bool compact = c->N == N && c->M > 0 && (long long)c->M * 5 < (long long)N * 4;
   int rc = GSPLAT_OK;
   if (compact && (rc = c->kept.reserve((size_t)c->max_gaussians * sizeof(int)))) return rc;
+  // the colour kernel beside the geometry kernel (pre_split 2): its stream and the two events, made on first use
+  const bool beside = c->pre_split == 2 && l_max > 0;
+  if (beside) {
+    if ((rc = c->chunk_first.reserve(((size_t)gs::bin_chunks(c->max_gaussians) + gs::kBinThreads / 64 + 1) * sizeof(int)))) return rc;
+    if (!c->pre_side) {
+      int lo_prio = 0, hi_prio = 0;
+      GS_HIP(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));  // (numerically largest = lowest priority)
+      GS_HIP(hipStreamCreateWithPriority(&c->pre_side, hipStreamNonBlocking, lo_prio));
+      GS_HIP(hipEventCreateWithFlags(&c->ev_pre_fork, hipEventDisableTiming));
+      GS_HIP(hipEventCreateWithFlags(&c->ev_pre_join, hipEventDisableTiming));
+    }
+  }
   {
     // LDS of the cull: one ballot + one count per (trip, wave) of the largest slice (a run of whole 64-entry chunks)
     const size_t slice_max = ((size_t)gs::bin_chunks(N) / gs::kBinBlocks + 2) * gs::kBinChunk;
@@ -1212,7 +1640,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
         g->xyz, cam->view, cam->proj, N, W, H, cfg->near_thresh, cfg->cull_mask_padding,
         c->lean ? nullptr : c->xyz_c_all.as<float>(), c->lean ? nullptr : c->uv_all.as<float>(),
         c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->pair_counters(),
-        compact ? c->kept.as<int>() : nullptr);
+        compact ? c->kept.as<int>() : nullptr, beside && !compact ? c->chunk_first.as<int>() : nullptr);
     GS_LAUNCH_CHECK();
   }
   c->mark(0, true, st);
@@ -1243,11 +1671,69 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (mid) { if (compact) GS_PRE3(LL, true, true); else GS_PRE3(LL, true, false); }                                  \
     else { if (compact) GS_PRE3(LL, false, true); else GS_PRE3(LL, false, false); }                                    \
   } while (0)
+  bool join_pending = false;
+  if (c->pre_split) {
+    // r06: colour and geometry as two kernels (see sh_colour_kernel)
+    const bool seq = l_max > 0 && c->pre_split == 1;  // one behind the other: the colour travels through c->rgb
+    if (seq) po.rgb = c->rgb.as<float>();
+    hipStream_t cst = st;
+    if (beside) {  // the colour kernel's stream starts where the cull has finished
+      GS_HIP(hipEventRecord(c->ev_pre_fork, st));
+      GS_HIP(hipStreamWaitEvent(c->pre_side, c->ev_pre_fork, 0));
+      cst = c->pre_side;
+    }
+    auto launch_colour = [&]() -> int {
+      if (l_max == 0) return GSPLAT_OK;
+      const dim3 cg(gs::div_up(gs::bin_chunks(N), kBlock / 64)), cb(kBlock);
+      const int *rk = beside ? nullptr : c->rank.as<int>();
+      float *rgb_to = beside ? (mid ? c->rgb.as<float>() : nullptr) : c->rgb.as<float>();
+      float4 *rec_to = beside ? c->recs.as<float4>() : nullptr;
+#define GS_SHC(LL)                                                                                                     \
+  do {                                                                                                                 \
+    if (compact)                                                                                                       \
+      sh_colour_kernel<LL, true><<<cg, cb, 0, cst>>>(*g, c->mask.as<unsigned char>(), rk, nullptr, c->slice_counts(),   \
+                                                     c->kept.as<int>(), cam->campos[0], cam->campos[1], cam->campos[2], rgb_to, rec_to); \
+    else                                                                                                               \
+      sh_colour_kernel<LL, false><<<cg, cb, 0, cst>>>(*g, c->mask.as<unsigned char>(), rk, c->chunk_first.as<int>(),    \
+                                                      c->slice_counts(), nullptr, cam->campos[0], cam->campos[1], cam->campos[2], rgb_to, rec_to); \
+  } while (0)
+      switch (l_max) {
+        case 1: GS_SHC(1); break;
+        case 2: GS_SHC(2); break;
+        default: GS_SHC(3); break;
+      }
+#undef GS_SHC
+      GS_LAUNCH_CHECK();
+      return GSPLAT_OK;
+    };
+    if (seq && (rc = launch_colour())) return rc;
+#define GS_GEOM3(COL, MID, CMP)                                                                                        \
+  preprocess_geom_kernel<COL, MID, CMP><<<gs::kBinBlocks, gs::kBinThreads, hist_bytes, st>>>(                          \
+      *g, cam->view, c->mask.as<unsigned char>(), c->rank.as<int>(), c->slice_counts(), c->kept.as<int>(),              \
+      cam->proj, W, H, fx, fy, tan_fovx, tan_fovy, cfg->mh_dist, cam->campos[0], cam->campos[1], cam->campos[2], ntx, nty, po, bin_table)
+#define GS_GEOM(COL)                                                                                                   \
+  do {                                                                                                                 \
+    if (mid) { if (compact) GS_GEOM3(COL, true, true); else GS_GEOM3(COL, true, false); }                              \
+    else { if (compact) GS_GEOM3(COL, false, true); else GS_GEOM3(COL, false, false); }                                \
+  } while (0)
+    // (the geometry kernel is queued FIRST: its 256 workgroups want a CU each, the colour kernel's take what is left)
+    if (l_max == 0) GS_GEOM(0); else if (beside) GS_GEOM(2); else GS_GEOM(1);
+#undef GS_GEOM
+#undef GS_GEOM3
+    GS_LAUNCH_CHECK();
+    if (beside) {
+      if ((rc = launch_colour())) return rc;
+      GS_HIP(hipEventRecord(c->ev_pre_join, c->pre_side));
+      if (gs_pre_join_late()) join_pending = true;
+      else GS_HIP(hipStreamWaitEvent(st, c->ev_pre_join, 0));
+    }
+  } else {
   switch (l_max) {
     case 0: GS_PRE(0); break;
     case 1: GS_PRE(1); break;
     case 2: GS_PRE(2); break;
     default: GS_PRE(3); break;
+  }
   }
 #undef GS_PRE
 #undef GS_PRE3
@@ -1371,6 +1857,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       if ((r = gs::launch_fwd_segments_table(c->ranges.as<int>(), num_tiles, fs, st))) return r;
       c->n_segmented_forwards++;
     }
+    if (join_pending) GS_HIP(hipStreamWaitEvent(st, c->ev_pre_join, 0));  // (late join: the records' colour is first read here)
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                               c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                               c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)N * 4,  // M <= N is not known here yet
@@ -1465,6 +1952,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     c->mark(2, true, st);
     c->mark(4, false, st);
     const bool ordered = false;  // (radix route: the longest list is not known; see queue_tail)
+    if (join_pending) GS_HIP(hipStreamWaitEvent(st, c->ev_pre_join, 0));
     rc = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
                                c->n_px.as<int>(), c->T_px.as<float>(), c->image.as<float>(), st,
                                c->rows_zeroed ? c->grad_rows.as<float4>() : nullptr, (long long)M * 4,
@@ -1707,6 +2195,13 @@ int gsplat_context_set_render_only(gsplat_context *c, int enabled) {
   GS_REQUIRE(c != nullptr, "null context");
   c->render_only = enabled != 0;
   if (c->render_only) c->have_forward = false;
+  return GSPLAT_OK;
+}
+
+int gsplat_context_set_preprocess_split(gsplat_context *c, int mode) {
+  GS_REQUIRE(c != nullptr, "null context");
+  GS_REQUIRE(mode >= 0 && mode <= 2, "mode: 0 one kernel, 1 two kernels in sequence, 2 two kernels side by side");
+  c->pre_split = mode;
   return GSPLAT_OK;
 }
 

@@ -145,6 +145,12 @@ class RasterContext:
         recomputes what it needs); those four views are then absent from the forward's result."""
         check(self._lib.gsplat_context_set_lean_forward(self._h, int(bool(enabled))))
 
+    def set_preprocess_split(self, mode):
+        """How the per-gaussian forward is launched: 0 (default) the single fused kernel, 1 SH colour then geometry on the
+        caller's stream, 2 the two side by side on two streams (gsplat_context_set_preprocess_split); every output is
+        bit-identical in all modes, 1 and 2 measure slower (profiles/r06_ab_preprocess_split.txt)."""
+        check(self._lib.gsplat_context_set_preprocess_split(self._h, int(mode)))
+
     def counters(self):
         """What the context's forwards did so far (gsplat_context_get_counters)."""
         v = (ctypes.c_longlong * 9)()

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <exception>
 #include <new>
+#include <type_traits>
 #include <utility>
 
 #include "hip_compat.h"
@@ -84,22 +85,38 @@ template <typename T, int STRIDE> struct gather_rows_fn {
   }
 };
 
-#ifndef GSPLAT_SHIM_NO_RAW_THRUST_VECTOR
 // A thrust::device_vector<T> whose n elements are allocated but NOT value-initialised: thrust's own `device_vector v(n)`
 // runs a fill kernel over the new elements and synchronises the stream behind it.  The conversions below fill such a
 // vector with their own (asynchronous) kernel or copy and move it into the thrust::device_vector<T> the host named --
 // the only cost left of `thrust::device_vector<float> d_sh_selected = compact_masked_array<45>(...)`
 // (cuda/trainer.cu:950-960) is then the vector's hipMalloc and, when the host destroys it, its hipFree.
-// Uses vector_base's protected members m_storage / m_size (a derived class may): if a rocThrust release renames them
-// this fails to compile -- -DGSPLAT_SHIM_NO_RAW_THRUST_VECTOR then selects the gather-iterator construction instead.
+// Uses vector_base's protected members m_storage / m_size (a derived class may).  Whether THIS rocThrust has them under
+// those names is probed at compile time (raw_thrust_vector_ok: the expressions below in an unevaluated SFINAE context
+// of the derived class); when it does not -- a release that renames them -- the conversions fall back to the
+// gather-iterator construction by themselves instead of breaking the maintainer's build (r06).
+// -DGSPLAT_SHIM_NO_RAW_THRUST_VECTOR forces the fallback.
 template <typename T> struct uninitialized_device_vector : thrust::device_vector<T> {
-  explicit uninitialized_device_vector(size_t n) {
+  template <typename U = uninitialized_device_vector,
+            typename = decltype(std::declval<U &>().m_storage.allocate(size_t(1))),
+            typename = decltype(std::declval<U &>().m_size = size_t(1))>
+  static std::true_type probe(int);
+  template <typename U = uninitialized_device_vector> static std::false_type probe(...);
+
+  explicit uninitialized_device_vector(size_t n) { reserve_raw<uninitialized_device_vector>(n); }
+
+ private:
+  template <typename U> void reserve_raw(size_t n) {  // (a template: only instantiated where the probe succeeded)
     if (n) {
-      this->m_storage.allocate(n);
-      this->m_size = n;
+      static_cast<U *>(this)->m_storage.allocate(n);
+      static_cast<U *>(this)->m_size = n;
     }
   }
 };
+#ifdef GSPLAT_SHIM_NO_RAW_THRUST_VECTOR
+template <typename T> inline constexpr bool raw_thrust_vector_ok = false;
+#else
+template <typename T>
+inline constexpr bool raw_thrust_vector_ok = decltype(uninitialized_device_vector<T>::template probe<>(0))::value;
 #endif
 
 template <typename T> class device_array {
@@ -174,8 +191,7 @@ template <typename T> class device_array {
   // vector is built from an iterator range: thrust allocates and runs one copy kernel, without the value-initialising
   // fill (and its stream synchronisation) that `device_vector v(n)` would add.
   operator thrust::device_vector<T>() const {
-#ifndef GSPLAT_SHIM_NO_RAW_THRUST_VECTOR
-    {
+    if constexpr (raw_thrust_vector_ok<T>) {
       uninitialized_device_vector<T> v(size_);
       if (size_) {
         T *dst = thrust::raw_pointer_cast(v.data());
@@ -194,7 +210,6 @@ template <typename T> class device_array {
       }
       return thrust::device_vector<T>(std::move(v));
     }
-#endif
     if (pend_.on && size_ > 0 && size_ < 0xFFFFFFFFull) {  // gather straight into the new vector
       device_array<int> rows;
       const int *rp = pend_.known.rows;  // the forward's compact_to_global, when the mask is the forward's own

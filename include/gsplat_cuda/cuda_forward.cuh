@@ -1,9 +1,10 @@
 // cuda_forward.cuh -- drop-in for the reference header of the same name
 // (AndrewBoessen/3DGS include/gsplat_cuda/cuda_forward.cuh:26-131).  Same free functions,
 // same parameter lists and default stream; every body is one call into the MI355X library
-// (include/gsplat_hip.h).  Only the rasterizer operators are provided; fused_loss,
-// compute_psnr, compute_morton_codes and the never-defined accumulate_gradients are outside
-// the rasterizer path and stay with the host.
+// (include/gsplat_hip.h).  All of the reference header's functions are here: the rasterizer
+// operators, and fused_loss / compute_psnr / compute_morton_codes at the
+// end of the file.  Only accumulate_gradients is absent: the reference declares it and never
+// defines it.
 #pragma once
 #include "hip_compat.h"
 

@@ -52,7 +52,7 @@ extern "C" {
 const char *gsplat_last_error(void);
 /* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
  * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
-#define GSPLAT_ABI_VERSION 6
+#define GSPLAT_ABI_VERSION 7
 int gsplat_abi_version(void);
 /* What the loaded binary was built from: sha256 (first 16 hex digits) over the kernel sources (3dgs_amd/csrc: Makefile,
  * *.h, *.hip) at link time, and the extra compiler flags of a diagnostic build ("" for the product build).  A loader
@@ -69,12 +69,25 @@ int gsplat_release_scratch(void);
  * 6.5 ms the unmodified reference-host iteration took at 1e6 gaussians.  The vectors the drop-in headers create
  * (include/gsplat_cuda/cuda_data.cuh: gsplat_shim::device_array) draw from this pool instead: a freed block is kept and
  * handed to the next request of its size class (three mantissa bits: <= 12.5 % slack), so the steady state allocates
- * nothing.  Blocks are reused in STREAM ORDER: a block freed while work of stream s still reads it may only be
- * re-used by work queued on s afterwards (the reference host issues everything on the NULL stream).
+ * nothing.  Blocks are reused in STREAM ORDER: a block freed while work of stream s still reads it is first re-used by
+ * work queued on s afterwards; a request from another stream is ordered behind s (r06: the _on forms below).
  * gsplat_pool_release hipFree()s the idle blocks; gsplat_pool_bytes reports idle (idle_only != 0) or idle + live bytes. */
 int gsplat_pool_alloc(void **ptr, size_t bytes);
 int gsplat_pool_free(void *ptr);
+/* r06: the stream-aware forms.  gsplat_pool_free_on(ptr, s): work queued on stream `s` so far may still touch the block.
+ * gsplat_pool_alloc_on(&ptr, bytes, t): the block will next be touched by work queued on stream `t`; when it takes a
+ * block that another stream returned, `t` is first ordered behind that stream (an event recorded on it now -- later than
+ * the return, hence covering it -- and awaited by `t`; a device synchronisation if that stream no longer exists); blocks
+ * returned by `t` itself are preferred and cost nothing.  The plain forms above are the NULL-stream forms
+ * (cuda/trainer.cu: everything but the image upload runs on the NULL stream; its transfer_stream, :1257-1259, is the
+ * reason the pool needs the ordering).  gsplat_pool_cross_stream_reuses: how often the ordering was needed. */
+int gsplat_pool_alloc_on(void **ptr, size_t bytes, void *stream);
+int gsplat_pool_free_on(void *ptr, void *stream);
+unsigned long long gsplat_pool_cross_stream_reuses(void);
 int gsplat_pool_release(void);
+/* Frees idle blocks of the CURRENT device (largest first) while more than keep_bytes of them are cached; other devices
+ * are neither synchronised nor touched.  What gsplat_context_destroy calls (keep_bytes = 1 GiB). */
+int gsplat_pool_trim(size_t keep_bytes);
 size_t gsplat_pool_bytes(int idle_only);
 
 /* ---------------------------------------------------------------- forward operators --- */
@@ -484,6 +497,15 @@ int gsplat_context_set_render_only(gsplat_context *ctx, int enabled);
  * gradients are unchanged.  Off by default: the reference's own backward_pass (cuda/trainer.cu:941-1012) hands these
  * arrays to the stand-alone backward operators. */
 int gsplat_context_set_lean_forward(gsplat_context *ctx, int enabled);
+/* r06: how the per-gaussian forward is launched (GSPLAT_PRE_SPLIT in the environment sets the default of new contexts).
+ * 0 (default): the single fused kernel.  1: two kernels one behind the other on `stream` -- the SH colour as a stream
+ * of its own (SH rows through LDS as linear spans), then geometry / record / tile count with the colour read back.
+ * 2: the same two kernels side by side -- the colour kernel on a low-priority stream of the context, forked behind the
+ * cull and joined in front of the binning kernels; it writes the colour straight into the 48-byte records.  The reference
+ * launches compute_rgb_from_sh and the covariance chain separately too (cuda/raster.cu:78-100).  Every output is
+ * bit-identical in all modes; on MI355X modes 1 and 2 measure 25 and 40 us SLOWER than mode 0 at 1e6 gaussians
+ * (profiles/r06_ab_preprocess_split.txt) -- they are kept as the measured answer to "split it", not as a recommendation. */
+int gsplat_context_set_preprocess_split(gsplat_context *ctx, int mode);
 /* What the forwards of this context did so far: out[0] forwards completed, out[1] forwards whose speculatively queued
  * tail (placement, per-tile sorts, compositing: queued before the host has seen the counts, from the previous forward's
  * figures) had to be redone because the instances outgrew the buffers or the longest list needed a sort kernel that

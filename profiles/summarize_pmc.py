@@ -2,7 +2,7 @@
 import csv, glob, json, os, sys, collections
 
 def short(name):
-    for k in ("render_bwd_kernel", "render_fwd_kernel", "preprocess_bwd_kernel", "preprocess_kernel", "tile_emit_kernel",
+    for k in ("render_bwd_kernel", "render_fwd_kernel", "preprocess_bwd_kernel", "preprocess_geom_kernel", "sh_colour_kernel", "preprocess_kernel", "tile_emit_kernel",
               "tile_ranges_kernel", "project_cull_kernel", "coarse_pairs_kernel", "pack_global_kernel", "bin_scatter_kernel",
               "bin_offsets_kernel", "loss_forward_kernel", "loss_backward_kernel", "tile_depth_sort_wave_kernel", "tile_depth_sort_kernel", "publish_counts_kernel"):
         if k in name:

@@ -24,6 +24,15 @@ static int failures = 0;
     if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
   } while (0)
 
+// The rocThrust of this image has vector_base::m_storage / m_size: the conversions to thrust::device_vector take the path
+// without the value-initialising fill.  (Under -DGSPLAT_SHIM_NO_RAW_THRUST_VECTOR, or with a rocThrust that renames the
+// members, the probe is false and the gather-iterator construction is used: tests/test_shim_cpp.py compiles both.)
+#ifndef GSPLAT_SHIM_NO_RAW_THRUST_VECTOR
+static_assert(gsplat_shim::raw_thrust_vector_ok<float>, "the probe does not find rocThrust's vector_base members");
+#else
+static_assert(!gsplat_shim::raw_thrust_vector_ok<float>, "the switch must select the fallback");
+#endif
+
 int main() {
   const int N = 3, W = 64, H = 48;
   CudaDataManager cuda(8);

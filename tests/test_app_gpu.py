@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, perf_check
 
 pytestmark = pytest.mark.gpu
 
@@ -117,7 +117,7 @@ def test_config4_full_schedule_from_disk(tmp_path):
     assert [e[0] for e in s["evals"]] == [0, 3000, 6000]          # cuda/trainer.cu:1388: iter % 3000 == 0
     assert s["psnr_test"] >= 25.0 and s["psnr_test"] > s["evals"][0][1] + 5.0, s
     assert s["gaussians"] > 138000 and s["peak_gaussians"] >= s["gaussians"]
-    assert s["it_per_s"] >= 900.0, s  # r02: 1060 it/s with the 70 image dumps, 1150-1190 without
+    perf_check(s["it_per_s"] >= 900.0, f"{s['it_per_s']:.0f} it/s < 900")  # r02: 1060 it/s with the 70 image dumps, 1150-1190 without
     assert "iter 7000/7000" in run.stdout and "training done: 7000 iterations" in run.stdout
     head = (tmp_path / "gaussians.ply").read_bytes().split(b"end_header\n", 1)[0].decode()
     assert f"element vertex {s['gaussians']}" in head and "f_rest_44" in head and "rot_3" in head

@@ -406,6 +406,45 @@ def test_device_block_pool(gpu):
     assert lib.gsplat_pool_release() == 0 and lib.gsplat_pool_bytes(1) == 0
 
 
+def test_device_block_pool_orders_reuse_across_streams(gpu):
+    """r06: a block returned while stream A still has work queued on it and taken by stream B is
+    ordered behind A (gsplat_pool_free_on / gsplat_pool_alloc_on).  Stream A queues a long chain of fills of the block
+    with 1.0 and returns it; stream B takes the block of that class -- the same one -- and fills it with 2.0 at once.
+    Without the ordering B's single fill finishes long before A's chain does and the block ends as 1.0.  A block taken
+    by the stream that returned it needs no ordering and gets none."""
+    import ctypes
+    torch, lib, raster = gpu, pkg("_lib").load(), pkg("raster")
+    lib.gsplat_pool_release()
+    n = 64 << 20  # floats: 256 MB, a fill takes ~0.1 ms
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    a, b = ctypes.c_void_p(sa.cuda_stream), ctypes.c_void_p(sb.cuda_stream)
+    p, q, r = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.gsplat_pool_alloc_on(ctypes.byref(p), 4 * n, a) == 0 and p.value
+    before = lib.gsplat_pool_cross_stream_reuses()
+    for _ in range(40):
+        assert lib.gsplat_fill_f32(p, n, 1.0, a) == 0
+    assert lib.gsplat_pool_free_on(p, a) == 0
+    assert lib.gsplat_pool_alloc_on(ctypes.byref(q), 4 * n, b) == 0
+    assert q.value == p.value, "the cached block of the class is reused"
+    assert lib.gsplat_pool_cross_stream_reuses() == before + 1
+    assert lib.gsplat_fill_f32(q, n, 2.0, b) == 0
+    torch.cuda.synchronize()
+    got = raster._view(q.value, (n,), "<f4", None)
+    assert float(got.min()) == 2.0 and float(got.max()) == 2.0, "stream B's fill ran before stream A's queued fills"
+    del got
+    # the same stream again: stream order, no event
+    assert lib.gsplat_pool_free_on(q, b) == 0
+    assert lib.gsplat_pool_alloc_on(ctypes.byref(r), 4 * n, b) == 0 and r.value == p.value
+    assert lib.gsplat_pool_cross_stream_reuses() == before + 1
+    assert lib.gsplat_pool_free_on(r, b) == 0
+    torch.cuda.synchronize()
+    # trim: nothing above the budget stays cached on this device; a budget above what is cached frees nothing
+    idle = lib.gsplat_pool_bytes(1)
+    assert idle >= 4 * n
+    assert lib.gsplat_pool_trim(idle) == 0 and lib.gsplat_pool_bytes(1) == idle
+    assert lib.gsplat_pool_trim(0) == 0 and lib.gsplat_pool_bytes(1) == 0
+
+
 def test_compact_with_trusted_count_matches_counted(gpu, orc):
     """compact_masked_array with num_culled given (the reference's call sites: no read-back, asynchronous) against the
     counting form, for the strides with a compile-time instantiation and two without."""

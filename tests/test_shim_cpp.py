@@ -44,3 +44,14 @@ def test_raster_shim_on_gpu():
     out = subprocess.run([_build("raster_shim_test")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+def test_raster_header_host_compiles_without_the_raw_thrust_vector():
+    """cuda_data.cuh probes at compile time whether rocThrust's vector_base has m_storage / m_size under those names and
+    otherwise builds thrust vectors from a gather iterator; -DGSPLAT_SHIM_NO_RAW_THRUST_VECTOR forces that fallback: it
+    must compile too (syntax and templates only: no link, no GPU)."""
+    src = os.path.join(ROOT, "tests", "cpp", "raster_shim_test.cpp")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O0", "-std=c++17", "-x", "hip", "-fsyntax-only",
+                          "-DGSPLAT_SHIM_NO_RAW_THRUST_VECTOR", "-I", os.path.join(ROOT, "include"), src],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]

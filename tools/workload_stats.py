@@ -19,7 +19,7 @@ else:
 dp = raster.device_params(params); dc = raster.device_camera(scene.make_camera(W, H, 0))
 dgi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
 ctx = raster.RasterContext(N, W, H)
-ctx.set_lean_forward(True)
+ctx.set_lean_forward(os.environ.get('GSPLAT_STATS_FULL') != '1')  # GSPLAT_STATS_FULL=1: every ForwardPassData array stored
 grads = ctx.alloc_gradients(N, L)
 for _ in range(5):
     fwd = ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
