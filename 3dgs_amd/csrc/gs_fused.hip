@@ -102,6 +102,9 @@ struct gsplat_context {
   int fseg_poll_budget = gs::kFwdPollBudget, fseg_thin_layer = gs::kFwdThinLayerDefault;
   double fseg_gate = -1.0;  // < 0: GSPLAT_FWD_SEGMENTS_GATE / its default
   unsigned long long n_segmented_forwards = 0;
+  // r06: the figures the segment kernels publish, as the host last took them from a slot whose ticket it could trust
+  // (queue_tail): the largest stop index of any tile, the sum over the tiles, the segments / segment blocks asked for
+  long long fig_max = 0, fig_sum = 0, fig_asked_bwd = 0, fig_asked_fwd = 0;
   int seg_cap = 0;          // extra segments the recorded forward had room for
   bool seg_ready = false;   // the recorded forward wrote the table and the checkpoints
   unsigned long long n_segmented_backwards = 0;
@@ -128,6 +131,7 @@ struct gsplat_context {
   // small device counters: 64 spread counters of candidate pairs, then the kBinBlocks slice counts of the cull
   unsigned long long *pair_counters() const { return counters.as<unsigned long long>(); }
   int *slice_counts() const { return counters.as<int>() + 128; }
+  int *fseg_fallbacks() const { return counters.as<int>() + 128 + gs::kBinBlocks; }  // (zeroed at creation, then only added to)
   // optional per-stage HIP-event timing (gsplat_context_set_timing)
   static constexpr int kStages = 8, kSlots = 32;
   unsigned int timing = 0;  // bit k: stage k is timed
@@ -1519,7 +1523,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
     for (gs::DeviceBuffer *b : outs) b->pooled = true;
   }
   auto R = [&](gs::DeviceBuffer &b, size_t bytes) { if (!rc) rc = b.reserve(bytes); };
-  R(c->mask, N + 16); R(c->counters, 512 + gs::kBinBlocks * 4); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
+  R(c->mask, N + 16); R(c->counters, 512 + gs::kBinBlocks * 4 + 64); R(c->rank, (N + 1) * 4); R(c->xyz_c_all, N * 12); R(c->uv_all, N * 8);
   R(c->c2g, N * 4); R(c->xyz_c, N * 12); R(c->uv, N * 8); R(c->sigma, N * 24); R(c->conic, N * 12); R(c->J, N * 24);
   R(c->rgb, N * 12); R(c->radius, N * 16); R(c->recs, N * 48); R(c->counts, (N + 1) * 4); R(c->offsets, (N + 1) * 4);
   R(c->grad_rows, N * 64); R(c->hitmask, N * 8);
@@ -1531,6 +1535,7 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
     const size_t sb2 = gs::binning_temp_bytes(N, 4 * N, (int)T);
     rc = c->temp.reserve(sb1 > sb2 ? sb1 : sb2);
   }
+  if (!rc && hipMemsetAsync(c->counters.ptr, 0, c->counters.bytes, (hipStream_t)0) != hipSuccess) rc = GSPLAT_ERR_HIP;
   if (!rc) rc = reserve_instances(c, 4 * N, (int)T, (hipStream_t)0);
   if (!rc && hipStreamSynchronize((hipStream_t)0) != hipSuccess) {  // the fills above: done before any stream uses the context
     gs::set_error("gsplat_context_create: hipStreamSynchronize failed");
@@ -1538,12 +1543,12 @@ int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width
   }
   if (!rc) {
     void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
       gs::set_error("gsplat_context_create: could not map the count record");
       rc = GSPLAT_ERR_HIP;
     } else {
-      memset(h, 0, 64);
+      memset(h, 0, 256);  // words 0..4: the forward's record; 8..15: two slots of four tagged figures (queue_tail)
       c->h_pub = (volatile unsigned long long *)h;
       c->d_pub = (unsigned long long *)d;
     }
@@ -1780,6 +1785,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   auto list_class = [](long long longest) {  // which of the workgroup sort kernels a list of that length needs
     return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : 1;
   };
+  bool segmented_this_forward = false;
   auto queue_tail = [&](size_t cap, long long longest_hint, bool publish) -> int {  // the placement publishes the record
     if (cap + 1 > instance_room(c)) {  // every kernel below indexes the instance arrays up to `cap` (inclusive: the spare slot)
       gs::set_error("gsplat_rasterize_image: internal: %zu instances queued into room for %zu", cap, instance_room(c));
@@ -1810,34 +1816,56 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     // Lists beyond kSegSplitMin are split for the backward (gs_render.h: TileSegments) -- decided, like the order, by the
     // previous forward: its longest list says whether there is anything to split; the room for extra blocks follows what
     // the tiles of the previous forward asked for (a list that does not fit stays whole).
-    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    // r06: the figures the segment kernels publish -- how uneven the tiles' work is, how many segments the
+    // lists asked for -- decide whether THIS forward splits and how much room it reserves, and a split forward sums
+    // per-segment partials where an unsplit one runs one fma chain: the decision must not follow host / GPU timing.
+    // The kernels write each figure as {ticket << 32 | value} into the slot of their forward's ticket parity.  This
+    // forward (ticket t) takes the slot of ticket t - 2: the host has seen the record of forward t - 1, which
+    // bin_scatter_kernel published BEHIND everything forward t - 2 queued on the stream, so that slot is complete -- and
+    // nobody writes it again before this forward's own kernels, queued below, run.  (The figures of forward t - 1 may or
+    // may not have landed yet: they are never looked at.)  A slot that does not carry ticket t - 2 -- the forward two back
+    // published nothing -- leaves the figures as they were.
+    {
+      const unsigned int want_tag = (unsigned int)((ticket - 2) & 0xFFFFFFFFull);
+      const volatile unsigned long long *slot = c->h_pub + 8 + 4 * (ticket & 1ull);
+      const unsigned long long w0 = __atomic_load_n(&slot[0], __ATOMIC_RELAXED), w1 = __atomic_load_n(&slot[1], __ATOMIC_RELAXED);
+      const unsigned long long w2 = __atomic_load_n(&slot[2], __ATOMIC_RELAXED), w3 = __atomic_load_n(&slot[3], __ATOMIC_RELAXED);
+      if (ticket >= 3 && (unsigned int)(w0 >> 32) == want_tag && (unsigned int)(w1 >> 32) == want_tag) {
+        c->fig_max = (long long)(int)(unsigned int)w0;
+        c->fig_sum = (long long)(int)(unsigned int)w1;
+      }
+      if (ticket >= 3 && (unsigned int)(w2 >> 32) == want_tag) c->fig_asked_bwd = (long long)(int)(unsigned int)w2;
+      if (ticket >= 3 && (unsigned int)(w3 >> 32) == want_tag) c->fig_asked_fwd = (long long)(int)(unsigned int)w3;
+    }
+    unsigned long long *d_slot = c->d_pub + 8 + 4 * (ticket & 1ull);  // where THIS forward's kernels publish
+    const unsigned int my_tag = (unsigned int)(ticket & 0xFFFFFFFFull);
+    gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, my_tag};
     const bool split = !ro && !gs_no_segments() && c->last_longest > gs::kSegSplitMin && num_tiles <= 16384;  // (the table kernels' reach)
     if (split) {
       const size_t slots = cap / gs::kSegEntries + 2;  // (gs_render.h: segment_slot)
-      const size_t asked = (size_t)*reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 6));
+      const size_t asked = (size_t)c->fig_asked_bwd;
       const size_t want = std::min(slots, (asked + asked / 2 + 256 + 7) & ~(size_t)7);
       if ((r = c->seg_first.reserve(((size_t)num_tiles + 8) * 4))) return r;
       if ((r = c->seg_extra.reserve((want + 2) * sizeof(int2)))) return r;  // [want]: the count
       if ((r = c->seg_chk.reserve(slots * 256 * sizeof(float4)))) return r;
       seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + want),
-             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want, reinterpret_cast<int *>(c->d_pub + 6), nullptr};
+             c->seg_chk.as<float4>(), c->image.as<float>(), (int)want, d_slot + 2, nullptr, my_tag};
     }
     // the tiles' largest stop indices of this forward, for the next one's decision below
     const bool figures = !gs_no_fwd_segments() && c->last_longest > gs::kSegSplitMin && num_tiles <= 16384;
-    if (figures) seg.stats = reinterpret_cast<int *>(c->d_pub + 5);
+    if (figures) seg.stats = d_slot;
     // ... and for the forward itself (gs_render.h: FwdSegments): every segment of a long list a block of its own
-    gs::FwdSegments fs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
+    gs::FwdSegments fs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, my_tag, nullptr, 0, 0};
     // Only where the tiles' work is uneven enough for ONE list to set the launch's duration: the previous forward's longest
     // chain (the largest stop index of any tile) against the work per resident workgroup (the sum over the tiles / 2048).
     // A throughput-bound scene gains nothing from the split and pays for its table, its combine pass and the product passes
     // (garden-shaped synthetic scene 0.197 -> 0.271 ms, dense4m 0.183 -> 0.26 when split regardless).
-    const volatile int *figs = reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 5));
-    const long long top_max = figs[0], top_sum = figs[1];
+    const long long top_max = c->fig_max, top_sum = c->fig_sum;
     const double gate = c->fseg_gate >= 0.0 ? c->fseg_gate : gs_fwd_segments_gate();
     const bool fsplit = figures && top_sum > 0 && top_max * 2048ll > (long long)(gate * (double)top_sum);
     if (fsplit) {
       const size_t most = cap / gs::kSegEntries + (size_t)num_tiles + 8;  // sum of ceil(len / kSegEntries) over any lists
-      const size_t asked = (size_t)*reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 7));
+      const size_t asked = (size_t)c->fig_asked_fwd;
       const size_t want = std::min(most, asked + asked / 4 + 512) + 7 & ~(size_t)7;
       if ((r = c->fseg_first.reserve(((size_t)num_tiles + 8 + 136) * 4))) return r;  // ranks | layer bases
       if ((r = c->fseg_blocks.reserve((want + 2) * sizeof(int2)))) return r;  // [want]: the count
@@ -1853,9 +1881,9 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
       fs = {c->fseg_first.as<int>(), c->fseg_first.as<int>() + num_tiles + 8, c->fseg_blocks.as<int2>(),
             reinterpret_cast<int *>(c->fseg_blocks.as<int2>() + want),
             c->fseg_gran.as<unsigned long long>(), c->fseg_part.as<float4>(), c->fseg_stop.as<int>(), (int)want,
-            c->fseg_epoch, reinterpret_cast<int *>(c->d_pub + 7), c->fseg_poll_budget, c->fseg_thin_layer};
+            c->fseg_epoch, d_slot + 3, my_tag, c->fseg_fallbacks(), c->fseg_poll_budget, c->fseg_thin_layer};
       if ((r = gs::launch_fwd_segments_table(c->ranges.as<int>(), num_tiles, fs, st))) return r;
-      c->n_segmented_forwards++;
+      segmented_this_forward = true;  // (counted once per forward below: a redone tail comes through here twice)
     }
     if (join_pending) GS_HIP(hipStreamWaitEvent(st, c->ev_pre_join, 0));  // (late join: the records' colour is first read here)
     r = gs::launch_render_fwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(), W, H, bg_color,
@@ -1964,6 +1992,7 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
     if (ordered && (rc = gs::launch_tile_order(c->tile_tops.as<int>(), nullptr, num_tiles, c->tile_order.as<int>(), st))) return rc;
     c->order_ready = ordered;
   }
+  if (segmented_this_forward) c->n_segmented_forwards++;
   c->N = N; c->M = M; c->S = S; c->l_max = l_max; c->width = W; c->height = H;
   c->last_mask = c->mask.as<unsigned char>();
   gs::pool_watch(c->last_mask, &c->last_mask);  // cleared when whoever ends up owning the block returns it to the pool
@@ -2039,10 +2068,10 @@ int gsplat_backward_render_split(gsplat_context *c, const float *grad_image, flo
   c->rows_zeroed = false;
   // stage 6 is this one launch: when it is timed, the launch itself stamps the two events (see launch_render_bwd)
   const bool timed = (c->timing >> 6) & 1u;
-  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  gs::TileSegments seg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0u};
   if (c->seg_ready)
     seg = {c->seg_first.as<int>(), c->seg_extra.as<int2>(), reinterpret_cast<int *>(c->seg_extra.as<int2>() + c->seg_cap),
-           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap, nullptr, nullptr};
+           c->seg_chk.as<float4>(), c->image.as<float>(), c->seg_cap, nullptr, nullptr, 0u};
   int rc = gs::launch_render_bwd(c->recs.as<float4>(), nullptr, c->sorted.as<int>(), c->ranges.as<int>(),
                                  c->n_px.as<int>(), c->T_px.as<float>(), grad_image, W, H, bg_color,
                                  c->grad_rows.as<float>(), nullptr, nullptr, nullptr, nullptr, st,
@@ -2184,11 +2213,23 @@ int gsplat_context_set_timing_stages(gsplat_context *c, unsigned int stage_mask)
 
 int gsplat_context_get_counters(gsplat_context *c, long long *out, int n) {
   GS_REQUIRE(c && out && n >= 0, "null argument");
-  const volatile int *figs = reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(c->h_pub + 5));
-  const long long v[9] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards,
-                          (long long)c->n_segmented_backwards, (long long)c->n_segmented_forwards, figs[0], figs[1]};
-  for (int k = 0; k < n && k < 9; ++k) out[k] = v[k];
-  return 9;
+  // (reporting only: the freshest pair of figures either slot holds -- the forward's decisions use queue_tail's rule)
+  long long fmax = c->fig_max, fsum = c->fig_sum;
+  unsigned int best = 0;
+  for (int sl = 0; sl < 2; ++sl) {
+    const unsigned long long w0 = __atomic_load_n(&c->h_pub[8 + 4 * sl], __ATOMIC_RELAXED);
+    const unsigned long long w1 = __atomic_load_n(&c->h_pub[9 + 4 * sl], __ATOMIC_RELAXED);
+    const unsigned int tag = (unsigned int)(w0 >> 32);
+    if (tag != 0 && tag == (unsigned int)(w1 >> 32) && tag >= best && tag <= (unsigned int)(c->ticket & 0xFFFFFFFFull)) {
+      best = tag; fmax = (long long)(int)(unsigned int)w0; fsum = (long long)(int)(unsigned int)w1;
+    }
+  }
+  int fallbacks = 0;  // (a blocking 4-byte copy: this is a diagnostic call)
+  if (n > 9 && c->counters.ptr) GS_HIP(hipMemcpy(&fallbacks, c->fseg_fallbacks(), sizeof(int), hipMemcpyDeviceToHost));
+  const long long v[10] = {c->n_forwards, c->n_tail_redone, c->n_compact_walks, c->n_instance_growths, c->n_ordered_backwards,
+                           (long long)c->n_segmented_backwards, (long long)c->n_segmented_forwards, fmax, fsum, fallbacks};
+  for (int k = 0; k < n && k < 10; ++k) out[k] = v[k];
+  return 10;
 }
 
 int gsplat_context_set_render_only(gsplat_context *c, int enabled) {

@@ -480,9 +480,17 @@ struct TileSegments {
   float4 *chk;             // [slots][256]: one checkpoint per boundary, per pixel of the tile (thread order)
   const float *image;      // the forward's image (the backward's view of the colour behind a boundary)
   int extra_cap;           // room in `extra`; a multiple of 8 (the main blocks keep their XCDs)
-  int *asked;              // [1], host-visible: the segments the tiles asked for (sizes the next launch's room)
-  int *stats;              // [2], host-visible: the largest stop index of any tile | the sum of the tiles' largest stop indices
+  // Host-visible figures of this forward, each ONE 8-byte word {the forward's ticket << 32 | value} (gs_common.h: the
+  // record's form), in the slot of the ticket's parity: the host takes a slot only when it carries the ticket of a forward
+  // whose kernels it knows to have completed (r06, ADVICE r05: the plain ints of r05 were read while the kernels that
+  // write them could still be running, and the forward's split decision followed host / GPU timing).
+  unsigned long long *asked;  // [1]: the segments the tiles asked for (sizes a later launch's room)
+  unsigned long long *stats;  // [2]: the largest stop index of any tile | the sum of the tiles' largest stop indices
+  unsigned int tag;           // low half of the forward's ticket
 };
+__host__ __device__ inline unsigned long long tagged_figure(unsigned int tag, int value) {
+  return ((unsigned long long)tag << 32) | (unsigned int)value;
+}
 __host__ __device__ inline int segment_slot(int list_start, int boundary) { return list_start / kSegEntries + boundary; }
 
 // r05 -- the same long lists in the FORWARD.  The front-to-back recurrence is serial in the transmittance only: a
@@ -516,10 +524,15 @@ struct FwdSegments {
   int *stop;                     // [cap][256]: the stop index if the pixel stopped in the segment, -1 live, -2 dead
   int cap;                       // room for segment blocks; a multiple of 8 (the main blocks keep their XCDs)
   unsigned int epoch;            // of this launch; never 0
-  int *asked;                    // [1], host-visible: segment blocks the lists asked for
+  unsigned long long *asked;     // [1], host-visible, {ticket << 32 | value} (see TileSegments): segment blocks the lists asked for
+  unsigned int tag;              // low half of the forward's ticket
+  int *fallbacks;                // [1], device: segment blocks whose polls ran out and which multiplied the product up themselves
   int poll_budget;               // polls (~1 us each) before a segment block multiplies the product up itself
   int thin_layer;                // layers of fewer blocks run their lists' segments side by side (phase A)
 };
-constexpr int kFwdPollBudget = 4096, kFwdThinLayerDefault = 512;  // (gsplat_context_set_segment_options changes them)
+// r06: 128 polls ~ 0.13 ms, a dozen segments' worth of compositing -- a block whose predecessor is not even
+// resident (the dispatch order it relies on is an assumption) recomputes after that instead of after 4 ms (r05: 4096),
+// and every such block is counted (gsplat_context_get_counters out[9]).
+constexpr int kFwdPollBudget = 128, kFwdThinLayerDefault = 512;  // (gsplat_context_set_segment_options changes them)
 
 }  // namespace gs

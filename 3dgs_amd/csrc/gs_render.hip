@@ -322,8 +322,10 @@ __device__ __forceinline__ void fwd_segment_block(const float4 *__restrict__ rec
         granule_store(gran_t, fs.epoch, tk);
       }
       const bool got = resolve_prefix(fs, rank, tid, k, fs.poll_budget, prefix);
-      if (__syncthreads_or(got ? 0 : 1))  // (rare: the blocks in front have not run yet and may be waiting for this CU)
+      if (__syncthreads_or(got ? 0 : 1)) {  // (rare: the blocks in front have not run yet and may be waiting for this CU)
+        if (tid == 0 && fs.fallbacks) atomicAdd(fs.fallbacks, 1);
         prefix = fwd_t_product<kPacked>(recs, raw, sorted, start, 0, a, true, tx0, ty0, fpx, fpy, tid, s_r0, s_r1, s_r2, s_list);
+      }
     }
   }
 
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restri
     }
     if (lane == 0) { atomicMax(&s_max, mx); atomicAdd(&s_sum, sum); }
     __syncthreads();
-    if (tid == 0) { seg.stats[0] = s_max; seg.stats[1] = s_sum; }
+    if (tid == 0) { seg.stats[0] = tagged_figure(seg.tag, s_max); seg.stats[1] = tagged_figure(seg.tag, s_sum); }
   }
   if (seg.granted == nullptr) return;  // (a render-only context: the figures only)
 #pragma unroll
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(1024) void tile_segments_kernel(const int *__restri
   }
   if (tid == 0) {
     *seg.extra_count = s_count;
-    if (seg.asked) *seg.asked = s_base;
+    if (seg.asked) *seg.asked = tagged_figure(seg.tag, s_base);
   }
 }
 
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(1024) void fwd_segments_table_kernel(const int *__r
   }
   if (tid == 0) {
     *fs.count = fits ? total : 0;
-    if (fs.asked) *fs.asked = total;
+    if (fs.asked) *fs.asked = tagged_figure(fs.tag, total);
   }
 }
 

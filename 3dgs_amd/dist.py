@@ -235,6 +235,59 @@ def all_gather_blocks(out, block, async_op=False):
 XGMI_LINK_GBS = 153.0  # MI355X_MICROARCH.md: 7 xGMI links per GPU, ~153 GB/s each, point to point
 
 
+def collective_environment(comm=None):
+    """What the exchange's collectives run on, for the bench line: the world size AS THE BACKEND'S GROUP SEES IT (not the
+    launcher's WORLD_SIZE), the backend, and the RCCL algorithm / protocol overrides in effect (None: RCCL's own choice) --
+    so that the first multi-GPU record can be read against exchange_model without a second run."""
+    on = dist.is_available() and dist.is_initialized()
+    group = getattr(comm, "group", None)
+    return {"rccl_world": (dist.get_world_size(group) if on else None),
+            "backend": (dist.get_backend(group) if on else None),
+            "nccl_algo": os.environ.get("NCCL_ALGO"), "nccl_proto": os.environ.get("NCCL_PROTO"),
+            "nccl_min_nchannels": os.environ.get("NCCL_MIN_NCHANNELS"), "rccl_msccl_enable": os.environ.get("RCCL_MSCCL_ENABLE")}
+
+
+def time_collectives(comm, num_gaussians, device, reps=10, warmup=3):
+    """ms of the split exchange's two collectives, each ALONE on otherwise idle links: the SUM all-reduce of
+    common[N,12] (48 MB at 1e6 gaussians) and the in-place all-gather of every rank's g_rgb[N+1,3] block (12 MB per
+    rank), bracketed by events on the stream the collective synchronises with; MAX over the ranks.  Collective: every rank
+    of `comm` calls it.  A group of one measures the backend's own overhead (the collectives are copies)."""
+    N, W = int(num_gaussians), comm.world
+    common = torch.zeros(N, 12, device=device)
+    rgb_all = torch.zeros(W, N + 1, 3, device=device)
+    cuda = getattr(device, "type", str(device).split(":")[0]) == "cuda"
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        if cuda:
+            torch.cuda.synchronize()
+        comm.barrier()
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+        else:
+            import time
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            ms = (time.perf_counter() - t) / reps * 1e3
+        t = torch.tensor([ms], dtype=torch.float64, device=device)
+        comm.all_reduce_max(t)
+        return round(float(t.item()), 4)
+
+    out = {"all_reduce_common_ms": timed(lambda: comm.all_reduce(common).wait()),
+           "all_gather_rgb_ms": timed(lambda: comm.all_gather_blocks(rgb_all, rgb_all[comm.rank]).wait()),
+           "all_reduce_bytes": 4 * N * 12, "all_gather_bytes_per_rank": 4 * (N + 1) * 3, "reps": reps}
+    del common, rgb_all
+    return out
+
+
 def exchange_model(world, num_gaussians, l_max, payload, with_uv_norm=False, chunks=1, link_gbs=XGMI_LINK_GBS):
     """What one step's exchange moves per rank and what that costs on xGMI, for checking a measured run against.
     Two bounds per collective: "ring" (RCCL's ring: every byte of a rank leaves through ONE link) and "direct" (every

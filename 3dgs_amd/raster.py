@@ -153,11 +153,11 @@ class RasterContext:
 
     def counters(self):
         """What the context's forwards did so far (gsplat_context_get_counters)."""
-        v = (ctypes.c_longlong * 9)()
-        self._lib.gsplat_context_get_counters(self._h, v, 9)
+        v = (ctypes.c_longlong * 10)()
+        self._lib.gsplat_context_get_counters(self._h, v, 10)
         return dict(forwards=int(v[0]), tail_redone=int(v[1]), compact_walks=int(v[2]), instance_growths=int(v[3]),
                     ordered_backwards=int(v[4]), segmented_backwards=int(v[5]), segmented_forwards=int(v[6]),
-                    longest_chain=int(v[7]), chain_sum=int(v[8]))
+                    longest_chain=int(v[7]), chain_sum=int(v[8]), segment_fallbacks=int(v[9]))
 
     def set_timing(self, enabled, stages=None):
         """Per-stage HIP-event timing on / off; `stages`: names from STAGES to time only those (each timed stage costs

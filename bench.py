@@ -409,6 +409,42 @@ def extra_workload(torch, scene, raster, name, dev, reps=20):
     return out
 
 
+def config2_workload(torch, scene, raster, dev, reps=100):
+    """BASELINE configs[1] -- synthetic 1e5 gaussians, 800x800, SH degree 0, forward render only: the "render fps" half of
+    BASELINE.json's metric on the config it is quoted on (parity of this size: tests/test_fused_gpu.py).  Renders/s in a
+    render-only context (serving: nothing kept for a backward) and in a training context, per-stage times, and the
+    compositing forward's roofline entry on SURVEY 8d's 40 B per needed list entry + 20 B per pixel."""
+    N, W, H, L, _ = scene.WORKLOADS["config2"]
+    cfg = scene.CONFIG
+    dp = raster.device_params(scene.make_workload_gaussians("config2"), dev)
+    dc = raster.device_camera(scene.make_camera(W, H, 0), dev)
+    ctx = raster.RasterContext(N, W, H)
+    out = {"N": N, "width": W, "height": H, "sh_degree": L}
+    for key, render_only in (("render_fps_render_only_context", True), ("render_fps_training_context", False)):
+        ctx.set_render_only(render_only)
+        for _ in range(10):
+            fwd = ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
+        torch.cuda.synchronize()
+        out[key] = reps / (time.perf_counter() - t0)
+    M, S = fwd["num_culled"], fwd["num_splats"]
+    S_eff = tile_max_sum(torch, fwd["n"], W, H)
+    st = stage_pass(ctx, dp, dc, None, cfg, L, None, reps, do_bwd=False)
+    lens = fwd["ranges"][1:] - fwd["ranges"][:-1]
+    out.update({"M": M, "S": S, "S_eff": S_eff, "num_pairs": fwd["num_pairs"],
+                "tile_list_mean": round(float(lens.float().mean().item()), 1), "tile_list_max": int(lens.max().item()),
+                "ms_per_render": 1e3 / out["render_fps_training_context"],
+                "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
+                "roofline": compositing_rooflines(S_eff, W * H, st["render_forward"][0], None, None)})
+    ctx.close()
+    del dp
+    torch.cuda.empty_cache()
+    return out
+
+
 def reference_host_path(params, cam, gi, cfg, L, iterations=20):
     """The path the REFERENCE host drives, timed outside the timed region: tests/cpp/reference_host.cpp is a C++ host
     written against the drop-in headers only (include/gsplat_cuda/raster.cuh, cuda_data.cuh, cuda_backward.cuh) that runs,
@@ -686,7 +722,14 @@ def run_rank(args, comm, device_index):
         """Every payload timed on a fresh communicator; {mode: ms (MAX over ranks) | "failed: ..."}.  Raises SweepAbort /
         whatever a broken backend raises: the caller keeps the headline either way."""
         scomm = comm if backend == "threads" else gdist.TorchComm.own_group()
+        coll = None
+        if backend != "threads":  # the two collectives of the split exchange, each alone on idle links (all ranks)
+            try:
+                coll = gdist.time_collectives(scomm, N, dev)
+            except Exception as e:  # noqa: BLE001 -- reported, the sweep goes on if the ranks still pair up
+                coll = {"error": f"{type(e).__name__}: {e}"[:200]}
         res = sweep_payloads(scomm, SWEEP_MODES, lambda m: time_mode(m, scomm), torch, dev)
+        res["_collectives"] = coll
         if scomm is not comm:
             scomm.close()
         return res
@@ -877,6 +920,10 @@ def run_rank(args, comm, device_index):
     extra = None
     if world == 1 and do_bwd and not args.no_extra_workloads and args.workload == "config3":
         extra = {}
+        try:  # BASELINE configs[1]: the config the metric's "render fps" is quoted on (forward only)
+            extra["config2"] = config2_workload(torch, scene, raster, dev)
+        except Exception as e:  # never lose the headline line to a side measurement
+            extra["config2"] = {"error": repr(e)[:200]}
         for name in ("config3_halfculled", "config3_morton", "dense4m", "bigsplats", "garden1200k", "veiled1200k"):
             try:
                 extra[name] = extra_workload(torch, scene, raster, name, dev)
@@ -936,6 +983,12 @@ def run_rank(args, comm, device_index):
         # (multi-GPU: filled in by the payload sweep BEHIND the timed region -- every payload's ms per step, MAX over the
         # ranks, measured on a communicator of its own; the headline ran config.exchange)
         "exchange_ms_per_step": None,
+        # what the collectives run on -- the world size as the backend's group sees it, the RCCL algorithm / protocol
+        # overrides in effect -- and, for N > 1, the split exchange's two collectives timed each ALONE behind the timed
+        # region (all-reduce of common[N,12], all-gather of g_rgb[N+1,3] per rank; ms, MAX over ranks): to be read against
+        # exchange_model.  null where there is nothing to measure (N = 1).
+        "collectives": dict(gdist.collective_environment(comm if world > 1 else None), all_reduce_common_ms=None,
+                            all_gather_rgb_ms=None),
         # tools/nccl_one_rank.py: every payload through RCCL with ONE rank (collectives = copies): ms per step with the
         # exchange, and the microseconds of it the host spends in the exchange's Python + torch.distributed calls
         "exchange_host_cost_one_rank": host_cost,
@@ -984,7 +1037,11 @@ def run_rank(args, comm, device_index):
     except BaseException as e:  # noqa: BLE001
         sweep = {"status": f"sweep ended: {type(e).__name__}: {e}"[:300]}
         status = "aborted"
-    guard.finish({"exchange_ms_per_step": sweep})
+    coll = sweep.pop("_collectives", None) if isinstance(sweep, dict) else None
+    extra_keys = {"exchange_ms_per_step": sweep}
+    if isinstance(coll, dict):
+        extra_keys["collectives"] = {**line["collectives"], **coll}
+    guard.finish(extra_keys)
     return status
 
 

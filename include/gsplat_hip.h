@@ -513,10 +513,14 @@ int gsplat_context_set_preprocess_split(gsplat_context *ctx, int mode);
  * compositing backwards that took their tiles heaviest first (scenes whose longest tile list was more than three times
  * the average in the forward before), out[5] compositing backwards that walked lists of more than 1488 entries as
  * segments of 496 with a workgroup each (the forward before had such a list; the forward stores a per-pixel checkpoint
- * at every segment boundary it reaches), out[6] forward launches (redone tails included) in which every segment of
- * such a list was a workgroup of its own, out[7] / out[8] the largest stop index of any tile and the sum of the tiles'
- * largest stop indices in the last forward that recorded them (contexts that have seen a list beyond 1488 entries; the
- * forward splits when out[7] * 2048 > 3 * out[8]).  Writes min(n, 9) values and returns 9. */
+ * at every segment boundary it reaches), out[6] forwards in which every segment of such a list was a workgroup of its
+ * own (r06: counted once per forward, a redone tail included), out[7] / out[8] the largest stop index of any tile and the
+ * sum of the tiles' largest stop indices in the last forward that published them (contexts that have seen a list beyond
+ * 1488 entries).  The forward splits when the figures of the forward TWO back say max * 2048 > 3 * sum: those are the
+ * newest ones the host knows to be complete without synchronising, so the decision -- and with it the bits of the image
+ * -- never follows host / GPU timing (r06).  out[9] segment workgroups of split forwards whose polls for the workgroup
+ * in front ran out and which multiplied the transmittance product up themselves (results identical; every one of them
+ * is work done twice).  Writes min(n, 10) values and returns 10. */
 int gsplat_context_get_counters(gsplat_context *ctx, long long *out, int n);
 int gsplat_context_set_timing(gsplat_context *ctx, int enabled);
 /* The same for a subset of the stages (bit k of stage_mask = stage k; 0 switches timing off).  Every timed stage

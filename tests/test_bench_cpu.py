@@ -114,3 +114,17 @@ def test_payload_sweep_reports_failures_and_stops_on_asymmetric_ones():
 def test_launcher_deadline_is_below_the_drivers_timeout():
     src = open(BENCH).read()
     assert 'os.environ.get("GSPLAT_BENCH_DEADLINE_S", "540")' in src  # the driver allows a run 600 s
+
+
+def test_bench_line_describes_the_collectives_without_a_process_group():
+    """r06: the line's `collectives` entry exists at N = 1 too (null where there is nothing to measure), so that the first
+    multi-GPU record and a single-GPU one have the same keys."""
+    sys.path.insert(0, ROOT)
+    from conftest import pkg
+    env = pkg("dist").collective_environment(None)
+    assert env["rccl_world"] is None and env["backend"] is None
+    for k in ("nccl_algo", "nccl_proto", "nccl_min_nchannels", "rccl_msccl_enable"):
+        assert k in env
+    src = open(BENCH).read()
+    assert '"collectives": dict(gdist.collective_environment(' in src and "all_reduce_common_ms=None" in src
+    assert 'extra["config2"] = config2_workload(' in src  # BASELINE configs[1] is in the line

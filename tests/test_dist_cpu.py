@@ -99,6 +99,18 @@ def _worker(rank, world, port, out_dir):
     own.close()
     assert own.group is None
     torch.distributed.all_reduce(torch.ones(2))  # the default group still works
+    # r06: what bench.py reports about the collectives -- the world size as the backend's group sees it, and the split
+    # exchange's two collectives timed each alone (MAX over the ranks: the same figures on every rank)
+    env = gdist.collective_environment(comm)
+    assert env["rccl_world"] == world and env["backend"] == "gloo" and "nccl_algo" in env and "nccl_proto" in env
+    tc = gdist.time_collectives(comm, 2000, torch.device("cpu"), reps=2, warmup=1)
+    assert tc["all_reduce_common_ms"] > 0 and tc["all_gather_rgb_ms"] > 0
+    assert tc["all_reduce_bytes"] == 4 * 2000 * 12 and tc["all_gather_bytes_per_rank"] == 4 * 2001 * 3
+    both = torch.tensor([tc["all_reduce_common_ms"], tc["all_gather_rgb_ms"]], dtype=torch.float64)
+    lo, hi = both.clone(), both.clone()
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    assert torch.equal(lo, hi), "the collective times are the MAX over the ranks: identical everywhere"
     un = gdist.unpack(packed, L)
     assert un["sh"].shape == (N, (L + 1) ** 2 - 1, 3) and un["visible"].shape == (N,)
     assert params_all["xyz"].shape == (N, 3)

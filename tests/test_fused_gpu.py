@@ -652,19 +652,22 @@ def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
     assert (stops > 3 * 496).any() and ((stops > 496) & (stops < 992)).any(), "pixels must stop behind several boundaries"
     bref = orc.backward_pass(ref, cam, gi, c["bg"], L, threads=8)
     whole = None
-    for it in range(4):
+    for it in range(5):
         fwd = ctx.rasterize_image(dp, dc, c, c["bg"], L)
         _check_forward(fwd, ref)
         grads = ctx.alloc_gradients(fwd["num_culled"], L, intermediates=True)
         ctx.backward_pass(dp, dc, gi_d, c["bg"], L, grads)
         assert ctx.counters()["segmented_backwards"] == it, "the split follows the forward before"
-        # (the forward's own split also waits for the previous forward's figures: how uneven the tiles' work is)
-        assert ctx.counters()["segmented_forwards"] == max(0, it - 1)
+        # The forward's own split follows the figures of the forward TWO back (r06): forward 1 is the first to publish them
+        # (forward 0 told it that there are long lists), forward 3 the first that may take them -- the host knows forward
+        # 1's kernels complete once it has seen forward 2's record.  Whatever the host / GPU timing: no synchronisation
+        # anywhere in this loop, and the count is exact.
+        assert ctx.counters()["segmented_forwards"] == max(0, it - 2)
         image = _np(fwd["image"]).copy()
-        if it == 2:
+        if it == 3:
             segmented_image = image
             assert ctx.counters()["longest_chain"] == int(stops.max())
-        elif it == 3:  # the segments' colours are added in a fixed order: the same bits in every run
+        elif it == 4:  # the segments' colours are added in a fixed order: the same bits in every run
             assert (image == segmented_image).all() and (_np(fwd["n"]) == stops_gpu).all()
         stops_gpu = _np(fwd["n"]).copy()
         _check_backward(grads, bref)
@@ -690,9 +693,8 @@ def test_long_lists_split_into_segments_for_the_backward(gpu, scene, orc):
         if opts.pop("render_only", False):
             other.set_render_only(True)
         other.set_segment_options(**opts)
-        for it in range(3):
+        for it in range(4):  # (no synchronisation: the split decision does not depend on what has landed, see above)
             out = other.rasterize_image(dp, dc, c, c["bg"], L)
-            torch.cuda.synchronize()  # (the next forward decides by the figures the kernels behind this one publish)
         assert other.counters()["segmented_forwards"] == 1, what
         assert (_np(out["image"]) == segmented_image).all(), what
         assert (_np(out["n"]) == stops_gpu).all() and (_np(out["T"]) == T_gpu).all(), what
