@@ -113,6 +113,12 @@ class Gradients(ctypes.Structure):  # gsplat_gradients
                  "grad_uv", "grad_J", "grad_sigma", "grad_xyz_c", "grad_precompute_rgb")]
 
 
+class AdamFused(ctypes.Structure):  # gsplat_adam_fused
+    _fields_ = [("exp_avg", ctypes.c_void_p * 6), ("exp_avg_sq", ctypes.c_void_p * 6), ("lr", ctypes.c_float * 6),
+                ("b1", ctypes.c_float), ("b2", ctypes.c_float), ("eps", ctypes.c_float), ("bias1", ctypes.c_float),
+                ("bias2", ctypes.c_float), ("uv_grad_accum", ctypes.c_void_p), ("grad_accum_dur", ctypes.c_void_p)]
+
+
 class AdamGroup(ctypes.Structure):  # gsplat_adam_group
     _fields_ = [("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
                 ("grad", ctypes.c_void_p), ("stride", ctypes.c_int), ("packed_column", ctypes.c_int),
@@ -120,7 +126,7 @@ class AdamGroup(ctypes.Structure):  # gsplat_adam_group
 
 
 MAX_ADAM_GROUPS = 8
-ABI_VERSION = 7  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
+ABI_VERSION = 8  # GSPLAT_ABI_VERSION of include/gsplat_hip.h; bumped with every signature change
 
 # every symbol include/gsplat_hip.h declares, with its argument types
 _P, _I, _F, _S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -194,6 +200,8 @@ SIGNATURES = {
                                     ctypes.POINTER(RasterConfig), _F, _I, ctypes.POINTER(ForwardView), _P]),
     "gsplat_backward_pass": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera), _P, _F, _I,
                                   ctypes.POINTER(Gradients), _P]),
+    "gsplat_backward_gaussians_adam": (_I, [_P, ctypes.POINTER(Gaussians), ctypes.POINTER(Camera), _I,
+                                            ctypes.POINTER(AdamFused), ctypes.POINTER(Gradients), _P]),
     "gsplat_context_set_render_only": (_I, [_P, _I]),
     "gsplat_context_set_lean_forward": (_I, [_P, _I]),
     "gsplat_context_set_preprocess_split": (_I, [_P, _I]),

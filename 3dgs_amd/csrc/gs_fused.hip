@@ -986,9 +986,31 @@ __device__ __forceinline__ int first_slot_not_below(const int *__restrict__ c2g,
   return lo;
 }
 
+// r06: what the per-gaussian backward needs to apply the optimizer step itself (kAdam; gsplat_backward_gaussians_adam):
+// the moments of the six parameter groups in GLOBAL order next to the parameters (`g`, updated in place), the groups'
+// learning rates, Adam's constants and the densification statistics.
+struct AdamFused {
+  float *m_xyz, *v_xyz, *m_rgb, *v_rgb, *m_sh, *v_sh, *m_op, *v_op, *m_sc, *v_sc, *m_q, *v_q;
+  float lr_xyz, lr_rgb, lr_sh, lr_op, lr_sc, lr_q;
+  float b1, b2, eps, bias1, bias2;
+  float *uv_accum;
+  int *accum_dur;
+};
+
 // ---- backward of everything per gaussian, one thread per compacted slot
-template <int L>
-__global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
+// kAdam (r06, single-GPU training): the kernel applies the masked Adam step of TrainerImpl::optimizer_step
+// (cuda/trainer.cu:1027-1158) to the gaussian it has just differentiated instead of storing six gradient arrays for a
+// second and third kernel to read back next to parameters this one has just read.  A gaussian's gradients depend on its
+// own parameters only, so updating in place is safe once the thread -- for the SH rows: the wave -- has read what it
+// needs.  Gradient values and update are the separate kernels' (gs::sh_bwd's product, gs::adam_values): parameters and
+// moments come out bit-identical to gsplat_backward_gaussians + gsplat_optimizer_step_sh_factored + gsplat_optimizer_step
+// (tests/test_optimizer_gpu.py).  The SH group: the coefficient rows stay in the wave's LDS rows (gs::sh_bwd<L, false>),
+// every lane parks its direction and colour gradient next to them, and the wave walks its 64 rows element by element --
+// thread e owns element e of the span, rebuilds gradient = g_rgb[channel] * Y_k(direction) as
+// optimizer_sh_factored_kernel does and streams sh / exp_avg / exp_avg_sq through the update: consecutive lanes,
+// consecutive addresses.
+template <int L, bool kAdam = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
                                                                 const float *__restrict__ proj, int M,
                                                                 const int *__restrict__ c2g,
                                                                 const float *__restrict__ xyz_c_sel,
@@ -996,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
                                                                 float tan_fovx, float tan_fovy, float fwd_tan_fovx,
                                                                 float fwd_tan_fovy, float mh_dist, float cx, float cy,
                                                                 float cz, int width, int height, BwdOut o,
-                                                                int ranged, int i_lo, int i_hi) {
+                                                                int ranged, int i_lo, int i_hi, AdamFused ad) {
   // ranged: only the gaussians with global index in [i_lo, i_hi), i.e. the compacted slots [first slot whose global index
   // is >= i_lo, first slot whose global index is >= i_hi) (chunked backward of a view-sharded step: the exchange of one
   // chunk runs while the next is computed); the grid covers the largest possible chunk, blocks past its end leave at once.
@@ -1014,6 +1036,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   // different cache lines per wave instruction; the wave's 64 rows as one linear span touch 8.  Same for the
   // gradient rows on the way out.  Each wave stages only its own rows (no workgroup barrier).
   __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 ? kBlock * kRest : 4];
+  // kAdam: per row the unit direction and the colour gradient (what the SH gradients are made of) and the global row
+  __shared__ float s_dir[kAdam && kRest > 0 ? kBlock * 7 : 1];
   const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
   const int jw = j_first + blockIdx.x * kBlock + wave_first;  // first compacted slot of this wave
   if (jw >= M) return;
@@ -1067,6 +1091,82 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  // (kAdam: the SH group first, while nothing else of the thread's state is live -- the kernel sits at the 168-register
+  // step of three workgroups per CU; sh_bwd below still finds the coefficients in LDS, the update went to global memory)
+  if constexpr (kRest > 0 && kAdam) {
+    {  // the direction exactly as gs::sh_bwd / optimizer_sh_factored_kernel form it (and the colour gradient: rows_in[.].xyz)
+      const float4 ga = rows_in[4 * (live ? j : jw)];
+      float ux, uy, uz, len;
+      gs::view_dir(g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, ux, uy, uz, len);
+      float *d = s_dir + (wave_first + lane) * 7;
+      d[0] = ux; d[1] = uy; d[2] = uz; d[3] = ga.x; d[4] = ga.y; d[5] = ga.z; d[6] = __int_as_float(i);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // Twelve lanes own one row (the layout of the scattered row loads above): lane `piece` of a group its floats
+    // 4 piece .. 4 piece + 3, i.e. 16-byte pieces of parameter and moment rows, five rows per wave instruction, whatever
+    // gaps culling has left between the rows; a lane evaluates the basis once per row.  The moment loads of kAhead
+    // trips are requested before the first of them is used.
+    float *sh_p = const_cast<float *>(g.sh);
+    const float *dirs = s_dir + wave_first * 7;
+    constexpr int kPieces = (kRest + 3) / 4, kPer = 64 / kPieces, kIter = (64 + kPer - 1) / kPer, kAhead = 4;
+    const int grp = lane / kPieces, piece = lane - grp * kPieces;
+    const bool in_grp = grp < kPer;
+    constexpr int kLast = kRest - 4 * (kPieces - 1);  // floats of a row's last piece (1..4)
+    const int nval = piece == kPieces - 1 ? kLast : 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < kIter; it0 += kAhead) {
+      float4 mq[kAhead], vq[kAhead];
+      size_t at[kAhead];
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int r = (it0 + u) * kPer + grp;
+        mq[u] = vq[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        at[u] = 0;
+        if (it0 + u < kIter && in_grp && r < rows) {
+          at[u] = (size_t)__float_as_int(dirs[r * 7 + 6]) * kRest + 4 * piece;
+          if (nval == 4) {
+            mq[u] = __builtin_bit_cast(float4, *reinterpret_cast<const gs::f4u *>(ad.m_sh + at[u]));
+            vq[u] = __builtin_bit_cast(float4, *reinterpret_cast<const gs::f4u *>(ad.v_sh + at[u]));
+          } else {
+            mq[u].x = ad.m_sh[at[u]]; vq[u].x = ad.v_sh[at[u]];
+            if (nval > 1) { mq[u].y = ad.m_sh[at[u] + 1]; vq[u].y = ad.v_sh[at[u] + 1]; }
+            if (nval > 2) { mq[u].z = ad.m_sh[at[u] + 2]; vq[u].z = ad.v_sh[at[u] + 2]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int r = (it0 + u) * kPer + grp;
+        if (it0 + u < kIter && in_grp && r < rows) {
+          const float *d = dirs + r * 7;
+          float Y[n];
+          gs::sh_basis<L>(d[0], d[1], d[2], Y);
+          const float *prow = wsh + r * kRest + 4 * piece;
+          float pv[4] = {prow[0], nval > 1 ? prow[1] : 0.0f, nval > 2 ? prow[2] : 0.0f, nval > 3 ? prow[3] : 0.0f};
+          float mv[4] = {mq[u].x, mq[u].y, mq[u].z, mq[u].w}, vv[4] = {vq[u].x, vq[u].y, vq[u].z, vq[u].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t < nval) {
+              const int c = 4 * piece + t, k = c / 3, ch = c - 3 * k;
+              float yv = 0.0f;
+#pragma unroll
+              for (int q = 0; q < n - 1; ++q) yv = k == q ? Y[q + 1] : yv;
+              const float grad = d[3 + ch] * yv;
+              gs::adam_values(pv[t], mv[t], vv[t], grad, ad.lr_sh, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+            }
+          }
+          if (nval == 4) {
+            *reinterpret_cast<gs::f4u *>(sh_p + at[u]) = gs::f4u{pv[0], pv[1], pv[2], pv[3]};
+            *reinterpret_cast<gs::f4u *>(ad.m_sh + at[u]) = gs::f4u{mv[0], mv[1], mv[2], mv[3]};
+            *reinterpret_cast<gs::f4u *>(ad.v_sh + at[u]) = gs::f4u{vv[0], vv[1], vv[2], vv[3]};
+          } else {
+            for (int t = 0; t < nval; ++t) { sh_p[at[u] + t] = pv[t]; ad.m_sh[at[u] + t] = mv[t]; ad.v_sh[at[u] + t] = vv[t]; }
+          }
+        }
+      }
+    }
+  }
   float gx = 0.0f, gy = 0.0f, gz = 0.0f, b0g[3] = {0.0f, 0.0f, 0.0f};
   const gs::Mat34 vw = gs::load_view(view);
   const gs::Mat44 pr = gs::load_proj(proj);
@@ -1077,17 +1177,39 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   const float g_con[3] = {b.x, b.y, b.z};
   const float g_u = b.w, g_v = c.x;
   {
-    float *row = wsh + lane * kRest;  // read as coefficients, overwritten with their gradients
-    gs::sh_bwd<L>(row, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, g_rgb, row, b0g, gx,
-                  gy, gz);
+    float *row = wsh + lane * kRest;  // read as coefficients, overwritten with their gradients (kAdam: left as they are)
+    gs::sh_bwd<L, !kAdam>(row, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, g_rgb, row, b0g,
+                          gx, gy, gz);
   }
-  if constexpr (kRest > 0) {
+  if constexpr (kRest > 0 && !kAdam) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (o.sh) gs::rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
   }
   if (!live) return;
   gx = 0.0f + gx; gy = 0.0f + gy; gz = 0.0f + gz;
+  // kAdam: one three-vector group of this lane's gaussian: parameter and moments at the GLOBAL row i
+  auto step3 = [&](const float *pc, float *m, float *v, const float *gr, float lr) {
+    float *p = const_cast<float *>(pc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float pv = p[3 * i + k], mv = m[3 * i + k], vv = v[3 * i + k];
+      gs::adam_values(pv, mv, vv, gr[k], lr, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+      p[3 * i + k] = pv; m[3 * i + k] = mv; v[3 * i + k] = vv;
+    }
+  };
+  if constexpr (kAdam) {
+    // what is final already -- band 0 (nothing below reads it again), the opacity, the densification statistics
+    // (cuda/trainer.cu:1136-1157, optimizer_step_kernel's expressions) -- leaves now, not across the covariance chain
+    step3(g.rgb, ad.m_rgb, ad.v_rgb, b0g, ad.lr_rgb);
+    {
+      float pv = g.opacity[i], mv = ad.m_op[i], vv = ad.v_op[i];
+      gs::adam_values(pv, mv, vv, g_op, ad.lr_op, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+      const_cast<float *>(g.opacity)[i] = pv; ad.m_op[i] = mv; ad.v_op[i] = vv;
+    }
+    if (ad.uv_accum) ad.uv_accum[i] += sqrtf(g_u * g_u + g_v * g_v);
+    if (ad.accum_dur) ad.accum_dur[i] += 1;
+  }
   // conic -> (J, Sigma).  Sigma, J and the conic are RECOMPUTED from what this kernel reads anyway (quaternion, scale,
   // camera-space position) with the forward's functions and the forward's tan(fov): bit for bit the values
   // preprocess_kernel stored, without reading 60 bytes per gaussian back (the kernel is HBM bound).
@@ -1123,6 +1245,23 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(gsplat_gaussians
   float wx, wy, wz;
   gs::camera_space_bwd(vw, cxg, cyg, czg, wx, wy, wz);
   gx += wx; gy += wy; gz += wz;
+  if constexpr (kAdam) {
+    // the groups whose gradients the covariance chain produced: position, scale, rotation
+    const float gxyz[3] = {gx, gy, gz};
+    step3(g.xyz, ad.m_xyz, ad.v_xyz, gxyz, ad.lr_xyz);
+    step3(g.scale, ad.m_sc, ad.v_sc, dSc, ad.lr_sc);
+    {
+      float4 pq = reinterpret_cast<const float4 *>(g.quaternion)[i];
+      float4 mq = reinterpret_cast<const float4 *>(ad.m_q)[i], vq = reinterpret_cast<const float4 *>(ad.v_q)[i];
+      gs::adam_values(pq.x, mq.x, vq.x, dQ[0], ad.lr_q, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+      gs::adam_values(pq.y, mq.y, vq.y, dQ[1], ad.lr_q, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+      gs::adam_values(pq.z, mq.z, vq.z, dQ[2], ad.lr_q, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+      gs::adam_values(pq.w, mq.w, vq.w, dQ[3], ad.lr_q, ad.b1, ad.b2, ad.eps, ad.bias1, ad.bias2);
+      reinterpret_cast<float4 *>(const_cast<float *>(g.quaternion))[i] = pq;
+      reinterpret_cast<float4 *>(ad.m_q)[i] = mq; reinterpret_cast<float4 *>(ad.v_q)[i] = vq;
+    }
+    if (!o.xyz) return;  // (gradient arrays: only when the caller asked for them)
+  }
   // stores
   if (o.common) {  // the exchange's row, in global order (the same twelve values pack_split_kernel gathers)
     gs::f4u *row = reinterpret_cast<gs::f4u *>(o.common + (size_t)i * 12);
@@ -2099,7 +2238,7 @@ int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, cons
 
 static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                    const gsplat_gradients *out, float *common, float *uv_norm, int first_gaussian,
-                                   int end_gaussian, void *stream);
+                                   int end_gaussian, void *stream, const AdamFused *adam = nullptr);
 
 int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                     const gsplat_gradients *out, int first_gaussian, int end_gaussian, void *stream) {
@@ -2115,9 +2254,29 @@ int gsplat_backward_gaussians_split(gsplat_context *c, const gsplat_gaussians *g
   return backward_gaussians_impl(c, g, cam, l_max, nullptr, common, uv_norm, first_gaussian, end_gaussian, stream);
 }
 
+int gsplat_backward_gaussians_adam(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
+                                   const gsplat_adam_fused *opt, const gsplat_gradients *out, void *stream) {
+  GS_REQUIRE(opt != nullptr && g != nullptr, "null argument struct");
+  const int n_groups = l_max > 0 ? 6 : 5;
+  for (int k = 0; k < 6; ++k) {
+    if (k == 2 && l_max == 0) continue;  // no coefficients beyond band 0
+    GS_REQUIRE_DEV(opt->exp_avg[k]); GS_REQUIRE_DEV(opt->exp_avg_sq[k]);
+  }
+  (void)n_groups;
+  GS_REQUIRE(((uintptr_t)opt->exp_avg[5] & 15) == 0 && ((uintptr_t)opt->exp_avg_sq[5] & 15) == 0,
+             "the quaternion moments must be 16-byte aligned");
+  if (opt->uv_grad_accum) GS_REQUIRE_DEV(opt->uv_grad_accum);
+  if (opt->grad_accum_dur) GS_REQUIRE_DEV(opt->grad_accum_dur);
+  const AdamFused ad = {opt->exp_avg[0], opt->exp_avg_sq[0], opt->exp_avg[1], opt->exp_avg_sq[1], opt->exp_avg[2], opt->exp_avg_sq[2],
+                        opt->exp_avg[3], opt->exp_avg_sq[3], opt->exp_avg[4], opt->exp_avg_sq[4], opt->exp_avg[5], opt->exp_avg_sq[5],
+                        opt->lr[0], opt->lr[1], opt->lr[2], opt->lr[3], opt->lr[4], opt->lr[5],
+                        opt->b1, opt->b2, opt->eps, opt->bias1, opt->bias2, opt->uv_grad_accum, opt->grad_accum_dur};
+  return backward_gaussians_impl(c, g, cam, l_max, out, nullptr, nullptr, 0, g->num_gaussians, stream, &ad);
+}
+
 static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                    const gsplat_gradients *out, float *common, float *uv_norm, int first_gaussian,
-                                   int end_gaussian, void *stream) {
+                                   int end_gaussian, void *stream, const AdamFused *adam) {
   GS_REQUIRE(c && g && cam, "null argument struct");
   GS_REQUIRE(0 <= first_gaussian && first_gaussian <= end_gaussian && end_gaussian <= g->num_gaussians, "bad gaussian range");
   GS_REQUIRE(c->have_forward && c->rows_ready, "gsplat_backward_render has not run for this forward pass");
@@ -2125,7 +2284,7 @@ static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g,
              "backward arguments do not match the recorded forward pass");
   static const gsplat_gradients kNoArrays = {};
   if (!out) out = &kNoArrays;  // split form: the twelve common columns go to `common`, nothing else is stored
-  if (!common) {
+  if (!common && !(adam && out == &kNoArrays)) {  // (the Adam form stores gradient arrays only when it is given some)
     GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
     GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
     GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
@@ -2150,12 +2309,22 @@ static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g,
   const int ranged = whole ? 0 : 1;
   const dim3 grid(gs::div_up(span, kBlock)), block(kBlock);
   c->mark(7, false, st);
+  static const AdamFused kNoAdam = {};
 #define GS_BWD(LL)                                                                                                     \
-  preprocess_bwd_kernel<LL><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),                     \
+  do {                                                                                                                 \
+    if (adam)                                                                                                          \
+      preprocess_bwd_kernel<LL, true><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),           \
                                                     c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
                                                     tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
                                                     cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
-                                                    ranged, first_gaussian, end_gaussian)
+                                                    ranged, first_gaussian, end_gaussian, *adam);                      \
+    else                                                                                                               \
+      preprocess_bwd_kernel<LL, false><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),          \
+                                                    c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
+                                                    tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
+                                                    cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
+                                                    ranged, first_gaussian, end_gaussian, kNoAdam);                    \
+  } while (0)
   switch (l_max) {
     case 0: GS_BWD(0); break;
     case 1: GS_BWD(1); break;

@@ -330,13 +330,11 @@ struct GroupTable {
 
 __device__ __forceinline__ void adam_update(float *param, float *m, float *v, float g, float lr, float b1, float b2,
                                             float eps, float bias1, float bias2) {
-  if (g != g) g = 0.0f;
-  const float mi = b1 * *m + (1.0f - b1) * g;
-  const float vi = b2 * *v + (1.0f - b2) * g * g;
-  const float m_hat = mi / bias1, v_hat = vi / bias2;
-  *param += -lr * m_hat / (sqrtf(v_hat) + eps);
-  *m = mi;
-  *v = vi;
+  float pv = *param, mv = *m, vv = *v;
+  gs::adam_values(pv, mv, vv, g, lr, b1, b2, eps, bias1, bias2);  // (gs_math.h: shared with the backward that applies Adam itself)
+  *param = pv;
+  *m = mv;
+  *v = vv;
 }
 
 // kPacked = false: grads are compacted [M,stride] arrays and c2g maps compacted -> global rows.

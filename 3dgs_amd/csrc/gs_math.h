@@ -515,7 +515,9 @@ __device__ __forceinline__ void sigma_bwd(const RotScale &rs, const float *g /*6
 
 // ---- S2 (reference: compute_sh_gradients_kernel, cuda/spherical_harmonics_backward.cu:28-166)
 // Writes sh_grad (n-1)*3 and band0_grad 3 (overwrite), returns the xyz increment.
-template <int L>
+// kStoreGrad = false (r06, the backward that applies Adam itself): the coefficient gradients are not stored -- their
+// consumer rebuilds gr[c] * Y[k + 1] where it needs them -- and `sh` stays as it was.
+template <int L, bool kStoreGrad = true>
 // sh_grad may be the same row as sh (coefficient k is read before its gradient is written).
 __device__ __forceinline__ void sh_bwd(const float *sh, const float *__restrict__ band0, float px,
                                        float py, float pz, float cx, float cy, float cz, const float *gr,
@@ -540,7 +542,7 @@ __device__ __forceinline__ void sh_bwd(const float *sh, const float *__restrict_
   for (int k = 0; k < n - 1; ++k) {
     const float yv = Y[k + 1];
     const float Ri = sh[3 * k], Gi = sh[3 * k + 1], Bi = sh[3 * k + 2];
-    sh_grad[3 * k] = gr[0] * yv; sh_grad[3 * k + 1] = gr[1] * yv; sh_grad[3 * k + 2] = gr[2] * yv;
+    if constexpr (kStoreGrad) { sh_grad[3 * k] = gr[0] * yv; sh_grad[3 * k + 1] = gr[1] * yv; sh_grad[3 * k + 2] = gr[2] * yv; }
     const float ddx = dY[k + 1][0], ddy = dY[k + 1][1], ddz = dY[k + 1][2];
     dRx += ddx * Ri; dGx += ddx * Gi; dBx += ddx * Bi;
     dRy += ddy * Ri; dGy += ddy * Gi; dBy += ddy * Bi;
@@ -553,6 +555,19 @@ __device__ __forceinline__ void sh_bwd(const float *sh, const float *__restrict_
   ox = (tx - dot * ux) / len;
   oy = (ty - dot * uy) / len;
   oz = (tz - dot * uz) / len;
+}
+
+// ---- f2: one element of the reference's adam_kernel (cuda/optimizer.cu:6-29): NaN gradients count as 0, bias-corrected
+// moments, the update in the reference's order of operations.  On values, so that callers decide where they live.
+__device__ __forceinline__ void adam_values(float &p, float &m, float &v, float g, float lr, float b1, float b2, float eps,
+                                            float bias1, float bias2) {
+  if (g != g) g = 0.0f;
+  const float mi = b1 * m + (1.0f - b1) * g;
+  const float vi = b2 * v + (1.0f - b2) * g * g;
+  const float m_hat = mi / bias1, v_hat = vi / bias2;
+  p += -lr * m_hat / (sqrtf(v_hat) + eps);
+  m = mi;
+  v = vi;
 }
 
 }  // namespace gs

@@ -97,6 +97,22 @@ class AdamOptimizer:
             self.uv_grad_accum.data_ptr() if uv is not None else None,
             self.grad_accum_dur.data_ptr() if uv is not None else None, _stream()))
 
+    def fused_state(self, it, with_stats=True):
+        """The optimizer's state at iteration `it` as the struct RasterContext.backward_pass_adam hands to the per-gaussian
+        backward, which then applies this very step itself (single-GPU training: same parameters, moments and statistics
+        as backward_pass + step, bit for bit, without the gradients' round trip through memory)."""
+        b1c, b2c = self.bias_corrections(it)
+        lrs = self.learning_rates(it)
+        a = _lib.AdamFused()
+        for k, g in enumerate(GROUPS):
+            if g in self.exp_avg:
+                a.exp_avg[k], a.exp_avg_sq[k] = self.exp_avg[g].data_ptr(), self.exp_avg_sq[g].data_ptr()
+            a.lr[k] = lrs[g]
+        a.b1, a.b2, a.eps, a.bias1, a.bias2 = B1, B2, EPS, b1c, b2c
+        a.uv_grad_accum = self.uv_grad_accum.data_ptr() if with_stats else None
+        a.grad_accum_dur = self.grad_accum_dur.data_ptr() if with_stats else None
+        return a
+
     def step_packed(self, it, packed, uv_norm_sum=None):
         """All-reduced packed rows [N, width] (sum over the views of the step).  uv_norm_sum [N]: the all-reduced
         per-view |grad_uv| (ViewShardedStep(with_uv_norm=True)); when given, the densification statistics are updated

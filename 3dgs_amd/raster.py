@@ -256,6 +256,22 @@ class RasterContext:
                                              float(bg_color), int(l_max), ctypes.byref(gs), st))
         return grads
 
+    def backward_pass_adam(self, params, cam, grad_image, bg_color, l_max, adam, grads=None):
+        """backward_pass with the optimizer step inside (single-GPU training): the compositing backward, then ONE
+        per-gaussian kernel that differentiates every visible gaussian and applies the masked Adam step to its rows of the
+        parameters (`params`, in place), the moments and the densification statistics (gsplat_backward_gaussians_adam).
+        adam: an _lib.AdamFused (AdamOptimizer.fused_state); grads: optional gradient arrays to fill as well."""
+        self.backward_render(grad_image, bg_color)
+        self.backward_gaussians_adam(params, cam, l_max, adam, grads)
+
+    def backward_gaussians_adam(self, params, cam, l_max, adam, grads=None):
+        """Second half of backward_pass_adam: the per-gaussian chain with the optimizer step inside."""
+        g, c = self._structs(params, cam, l_max)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        gs = ctypes.byref(self._grad_struct(grads)) if grads is not None else None
+        check(self._lib.gsplat_backward_gaussians_adam(self._h, ctypes.byref(g), ctypes.byref(c), int(l_max),
+                                                       ctypes.byref(adam), gs, st))
+
     def backward_render(self, grad_image, bg_color, rgb_global=None, common=None, uv_norm=None):
         """First half of backward_pass: compositing backward; optionally this view's g_rgb in global order [N,3].
         common [N,12] (and uv_norm [N]): the split exchange's rows -- the rows of the gaussians this view culled are

@@ -61,6 +61,11 @@ class Trainer:
         self.comm = comm if comm is not None else TorchComm()
         self.world, self.rank = self.comm.world, self.comm.rank
         self.exchange = exchange
+        # r06, one rank: GSPLAT_FUSED_ADAM=1 lets the per-gaussian backward apply the optimizer step itself
+        # (gsplat_backward_gaussians_adam: bit-identical parameters, moments and statistics, no gradient arrays).  Off by
+        # default: the one fat kernel takes as long as the three it replaces (352 against 356 us at 1e6 gaussians,
+        # profiles/r06_fused_adam.txt) and the iteration is 2 % slower by the wall clock.
+        self.fused_adam = __import__("os").environ.get("GSPLAT_FUSED_ADAM", "0") == "1"
         self._sharded = None  # (key, ViewShardedStep) for the current gaussian count / SH degree
         self._grad_image = {}  # (H, W) -> dL/dimage buffer, allocated once per image size
         self._grads = None     # (capacity, l_max, dict): per-view gradient arrays, reused across iterations
@@ -145,9 +150,13 @@ class Trainer:
         grad_image = self._grad_image_for(H, W, gt_image.device)
         # the loss value is a blocking read-back: only fetched when the caller logs it
         loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image, blocking=want_loss)
-        grads = self._gradients_for(ctx, fwd["num_culled"])
-        ctx.backward_pass(p, cam, grad_image, bg, self.l_max, grads)
-        self.opt.step(it, fwd, grads, campos=cam["campos"])
+        if self.fused_adam:
+            # r06: the per-gaussian backward applies the optimizer step itself (no gradient arrays at all)
+            ctx.backward_pass_adam(p, cam, grad_image, bg, self.l_max, self.opt.fused_state(it))
+        else:
+            grads = self._gradients_for(ctx, fwd["num_culled"])
+            ctx.backward_pass(p, cam, grad_image, bg, self.l_max, grads)
+            self.opt.step(it, fwd, grads, campos=cam["campos"])
         self.iter += 1
         return loss
 

@@ -819,7 +819,7 @@ def run_rank(args, comm, device_index):
 
     # ---- the whole training iteration (SURVEY 8f rows f1 + f2 around the path): rasterize -> fused L1+SSIM loss ->
     # backward with the uv intermediates -> masked in-place Adam; outside the timed region, last (it moves the parameters)
-    train_ms = None
+    train_ms = train_ms_fused = None
     if do_bwd and os.environ.get("GSPLAT_BENCH_TRAIN_STEP", "1") != "0":
         ops = importlib.import_module("3dgs_amd.ops")
         opt_mod = importlib.import_module("3dgs_amd.optimizer")
@@ -831,21 +831,29 @@ def run_rank(args, comm, device_index):
         tgrads = step.ctx.alloc_gradients(N, L, intermediates=("uv",), factored_sh=True)
         loss_grad = torch.empty(H, W, 3, device=dev)
 
-        def train_step(it):
+        def train_step(it, fused):
             f = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)
             ops.fused_loss(f["image"], target, H, W, 0.2, loss_grad, blocking=False)
-            step.ctx.backward_pass(dp_train, dc, loss_grad, 0.0, L, tgrads)
-            opt.step(it, f, tgrads, campos=dc["campos"])
+            if fused:  # r06 (opt-in): the per-gaussian backward applies the optimizer step itself
+                step.ctx.backward_pass_adam(dp_train, dc, loss_grad, 0.0, L, opt.fused_state(it))
+            else:      # what Trainer runs on one GPU: backward, then the two optimizer kernels on the stored gradients
+                step.ctx.backward_pass(dp_train, dc, loss_grad, 0.0, L, tgrads)
+                opt.step(it, f, tgrads, campos=dc["campos"])
 
-        for it in range(10):
-            train_step(it)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
         reps_tr = max(5, min(args.steps, 50))
-        for it in range(reps_tr):
-            train_step(10 + it)
-        torch.cuda.synchronize()
-        train_ms = (time.perf_counter() - t1) / reps_tr * 1e3
+        train_variants = {}
+        it0 = 0
+        for fused in (False, True):
+            for it in range(10):
+                train_step(it0 + it, fused)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for it in range(reps_tr):
+                train_step(it0 + 10 + it, fused)
+            torch.cuda.synchronize()
+            train_variants[fused] = (time.perf_counter() - t1) / reps_tr * 1e3
+            it0 += 10 + reps_tr
+        train_ms, train_ms_fused = train_variants[False], train_variants[True]
         del dp_train, opt, tgrads, loss_grad, target
 
     # ---- three views in turn on one context (extra key): the forward queues its tail -- placement, per-tile sorts,
@@ -1000,6 +1008,9 @@ def run_rank(args, comm, device_index):
         | {f"{p}_at_8_ranks": gdist.exchange_model(8, N, L, p) for p in ("full", "factored", "split", "split_direct")},
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
         "train_step_ms_with_loss_and_adam": train_ms,
+        # r06: the same iteration with the optimizer step INSIDE the per-gaussian backward (gsplat_backward_gaussians_adam,
+        # Trainer under GSPLAT_FUSED_ADAM=1): bit-identical results, one kernel instead of three -- and no faster
+        "train_step_ms_adam_inside_the_backward": train_ms_fused,
         "ms_per_step_stats": step_stats,
         "ms_per_step_full_forward_outputs": ms_other_mode if lean_headline else ms,
         "ms_per_step_lean_forward": ms if lean_headline else ms_other_mode,

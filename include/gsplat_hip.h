@@ -52,7 +52,7 @@ extern "C" {
 const char *gsplat_last_error(void);
 /* Library ABI version (bumped when a signature changes); bindings compare it with the GSPLAT_ABI_VERSION they were
  * written against, so a stale prebuilt library fails at load time, not with a wrong argument list. */
-#define GSPLAT_ABI_VERSION 7
+#define GSPLAT_ABI_VERSION 8
 int gsplat_abi_version(void);
 /* What the loaded binary was built from: sha256 (first 16 hex digits) over the kernel sources (3dgs_amd/csrc: Makefile,
  * *.h, *.hip) at link time, and the extra compiler flags of a diagnostic build ("" for the product build).  A loader
@@ -385,6 +385,18 @@ typedef struct gsplat_gradients {      /* GaussianGradients (leaf part), compact
   float *grad_conic, *grad_uv, *grad_J, *grad_sigma, *grad_xyz_c, *grad_precompute_rgb;
 } gsplat_gradients;
 
+/* r06: the optimizer state the per-gaussian backward needs to apply the masked Adam step itself
+ * (gsplat_backward_gaussians_adam).  Groups in this order: 0 xyz, 1 rgb (band 0), 2 sh, 3 opacity, 4 scale, 5 quaternion;
+ * moments in GLOBAL order next to the parameters, laid out like them (quaternion moments 16-byte aligned); group 2 is
+ * ignored when l_max == 0. */
+typedef struct gsplat_adam_fused {
+  float *exp_avg[6], *exp_avg_sq[6];
+  float lr[6];                       /* per group (cuda/trainer.cu:1049-1071) */
+  float b1, b2, eps, bias1, bias2;   /* include/gsplat_cuda/optimizer.cuh:9-11; bias_k = 1 - b_k^(iteration + 1) */
+  float *uv_grad_accum;              /* [N] += |grad_uv| of the visible gaussians; may be NULL */
+  int *grad_accum_dur;               /* [N] += 1 for the visible gaussians; may be NULL */
+} gsplat_adam_fused;
+
 int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width, int max_height);
 int gsplat_context_destroy(gsplat_context *ctx);
 /* bytes of device memory currently held by the context */
@@ -399,6 +411,19 @@ int gsplat_rasterize_image(gsplat_context *ctx, const gsplat_gaussians *gaussian
 int gsplat_backward_pass(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *camera,
                          const float *grad_image, float bg_color, int l_max, const gsplat_gradients *out,
                          void *stream);
+/* r06 -- single-GPU training: gsplat_backward_gaussians and the optimizer step of TrainerImpl::optimizer_step
+ * (cuda/trainer.cu:1027-1158) in ONE pass over the visible gaussians.  The kernel differentiates a gaussian and applies
+ * adam_kernel's update (cuda/optimizer.cu:6-29: NaN gradient -> 0, bias-corrected moments) to its rows of all six
+ * parameter groups IN PLACE -- through the pointers of `gaussians`, which this entry point writes -- and of their moments,
+ * the SH group from the factored gradient (gsplat_optimizer_step_sh_factored's product), and adds |grad_uv| / 1 to the
+ * densification statistics.  Call it where gsplat_backward_gaussians would be called (after gsplat_backward_render).
+ * Parameters, moments and statistics come out bit-identical to gsplat_backward_gaussians (grad_sh NULL) +
+ * gsplat_optimizer_step_sh_factored + gsplat_optimizer_step; what is saved is the gradients' round trip through HBM and
+ * the second and third read of parameters the backward has just read (~370 of ~2030 bytes per visible gaussian at
+ * l_max 3).  `out` may be NULL; when given, its arrays are filled as gsplat_backward_gaussians fills them (except grad_sh,
+ * which this form never stores). */
+int gsplat_backward_gaussians_adam(gsplat_context *ctx, const gsplat_gaussians *gaussians, const gsplat_camera *cam,
+                                   int l_max, const gsplat_adam_fused *opt, const gsplat_gradients *out, void *stream);
 
 /* The same backward in two calls, for hosts that overlap a gradient exchange with it (3dgs_amd/dist.py):
  * gsplat_backward_render runs the compositing backward (render_image_backward) and, if rgb_global != NULL, leaves this

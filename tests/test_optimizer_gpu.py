@@ -152,6 +152,62 @@ def test_factored_sh_step_equals_the_stored_gradient_step(gpu, scene, name):
         ob.step(13, fwd, g_fact)  # no camera position: the direction cannot be rebuilt
 
 
+@pytest.mark.parametrize("name", ["small", "small_l1", "small_l0", "mid_l2"])
+def test_backward_with_adam_inside_equals_backward_then_optimizer(gpu, scene, name):
+    """r06: gsplat_backward_gaussians_adam -- the per-gaussian backward that applies the masked Adam step itself -- must
+    leave parameters, both moments of all six groups and the densification statistics BIT-identical to the backward that
+    stores its gradients followed by gsplat_optimizer_step_sh_factored + gsplat_optimizer_step (the same gradient values,
+    gs::adam_values in both), must not touch a culled row, and fills the gradient arrays it is given exactly as the plain
+    backward does.  Both twins differentiate the SAME compositing rows (one gsplat_backward_render: its float atomics
+    reorder between launches).  Two steps: the second sees the moved parameters."""
+    torch, raster, opt_mod = gpu, pkg("raster"), pkg("optimizer")
+    N, W, H, L = {"small": (5000, 256, 144, 3), "small_l1": (3000, 160, 96, 1), "small_l0": (3000, 160, 96, 0),
+                  "mid_l2": (40000, 320, 192, 2)}[name]
+    params = scene.make_gaussians(N, W, H, L)
+    params["xyz"][::3, 2] *= -1
+    cam = scene.make_camera(W, H, 1)
+    c = scene.CONFIG
+    ctx = raster.RasterContext(N, W, H)
+    dp_a, dc = raster.device_params(params), raster.device_camera(cam)
+    dp_b = {k: v.clone() for k, v in dp_a.items()}
+    gi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
+    oa, ob = opt_mod.AdamOptimizer(dp_a, L, scene_extent=2.5), opt_mod.AdamOptimizer(dp_b, L, scene_extent=2.5)
+    rng = np.random.default_rng(5)
+    for g in oa.names:
+        m0 = torch.from_numpy((rng.standard_normal(tuple(oa.exp_avg[g].shape)) * 1e-4).astype(np.float32)).cuda()
+        v0 = torch.from_numpy((rng.random(tuple(oa.exp_avg_sq[g].shape)) * 1e-8).astype(np.float32)).cuda()
+        oa.exp_avg[g].copy_(m0); ob.exp_avg[g].copy_(m0)
+        oa.exp_avg_sq[g].copy_(v0); ob.exp_avg_sq[g].copy_(v0)
+    before = {k: v.clone() for k, v in dp_b.items()}
+    for it in (20, 21):
+        fwd = ctx.rasterize_image(dp_a, dc, c, c["bg"], L)  # (both twins hold the same parameters)
+        M = fwd["num_culled"]
+        assert 0 < M < N
+        ctx.backward_render(gi, c["bg"])
+        g_a = ctx.alloc_gradients(M, L, intermediates=("uv",), factored_sh=True)
+        g_b = ctx.alloc_gradients(M, L, intermediates=("uv",), factored_sh=True)
+        for t in g_b.values():
+            if t is not None:
+                t.fill_(float("nan"))
+        ctx.backward_gaussians(dp_a, dc, L, g_a)
+        oa.step(it, fwd, g_a, campos=cam["campos"])
+        # twin B: one kernel; on the second step without gradient arrays at all (what the trainer does)
+        ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it), g_b if it == 20 else None)
+        torch.cuda.synchronize()
+        if it == 20:
+            for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "uv", "precompute_rgb"):
+                if g_a.get(k) is not None:  # (no precompute_rgb array at degree 0)
+                    assert torch.equal(g_a[k], g_b[k]), k
+        for g in oa.names:
+            assert torch.equal(dp_a[g], dp_b[g]), (it, g)
+            assert torch.equal(oa.exp_avg[g], ob.exp_avg[g]) and torch.equal(oa.exp_avg_sq[g], ob.exp_avg_sq[g]), (it, g)
+        assert torch.equal(oa.uv_grad_accum, ob.uv_grad_accum) and torch.equal(oa.grad_accum_dur, ob.grad_accum_dur), it
+    culled = torch.from_numpy(~_np(fwd["mask"]).astype(bool)).cuda()
+    assert int(ob.grad_accum_dur.max()) == 2 and int(ob.grad_accum_dur[culled].max()) <= 1
+    for g in oa.names:
+        assert not torch.equal(dp_b[g], before[g]), g
+
+
 def test_training_iterations_reduce_the_loss(gpu, scene):
     """rasterize -> fused_loss -> backward -> optimizer step, 30 iterations on one view toward a target rendered
     from the unperturbed scene: the L1+SSIM loss must drop and PSNR must rise (reference loop: trainer.cu:417-516)."""
