@@ -562,8 +562,13 @@ __global__ __launch_bounds__(kWaves * 64) void tile_depth_sort_kernel(unsigned l
 // per-tile depth order: one wave per tile in registers; the few lists above kWaveSortMax entries are listed in
 // `long_tiles` (long_tiles[0] must be 0 on entry) and finished by workgroups of the second kernel
 // `longest`: the longest list when the caller knows it (the fused forward reads it with the counts), else < 0
+// keys_ok: every depth key is a positive, finite, normal float (the caller's near threshold is positive: cull_gaussians keeps
+// z >= near_thresh only), so the wave kernel hands over nothing but lists beyond kWaveSortMax entries -- and when `longest`
+// says that there is none, the hand-over kernel is not launched at all (r06: 4.5 us per forward of launch and drain for a
+// kernel whose every workgroup left at once -- the headline scene's lists end at ~600 entries).
 static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, int num_tiles, size_t S, int *long_tiles,
-                               int *sorted_out, hipStream_t st, long long longest = -1, const SortFork *fork = nullptr) {
+                               int *sorted_out, hipStream_t st, long long longest = -1, const SortFork *fork = nullptr,
+                               bool keys_ok = false) {
   // tiles the wave kernel may hand over: the long lists and any list with a key that has no double form
   const int max_long = (int)std::min<size_t>((size_t)num_tiles, S);
   // The lists above 2, 4 and 8 runs of kWaveSortMax entries: 256-, 512- and 1024-thread workgroups (4 / 8 / 16 register-
@@ -617,7 +622,7 @@ static int sort_tiles_by_depth(unsigned long long *payload, const int *ranges, i
   }
   tile_depth_sort_wave_kernel<<<div_up(num_tiles, 4), 256, 0, st>>>(payload, ranges, num_tiles, sorted_out, long_tiles);
   GS_LAUNCH_CHECK();
-  if (max_long > 0) {
+  if (max_long > 0 && !(keys_ok && longest >= 0 && longest <= (long long)kWaveSortMax)) {
     // workgroups beyond the list's length leave at once; ten (16 KB of LDS) resp. five (32 KB) fit on a CU
 #if GS_SORT_HALF_RUNS
     tile_depth_sort_kernel<4, kWaveSortMax / 2><<<std::min(max_long, 8 * 256), 256, 0, st>>>(payload, ranges, num_tiles,
@@ -1038,14 +1043,15 @@ int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *r
                              const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
-                             unsigned long long ticket, hipStream_t st, const SortFork *fork, bool compact_walk) {
+                             unsigned long long ticket, hipStream_t st, const SortFork *fork, bool compact_walk,
+                             bool keys_ok) {
   const int T = ntx * nty;
   const RecordSource rec = {pub, ticket, m_total, pair_counters};
   bin_scatter_kernel<<<kBinBlocks, kBinThreads, (size_t)T * sizeof(int), st>>>(uv, xyz_c, radius, hitmask, rank, N, ntx,
                                                                              nty, table, ranges, (long long)S, payload,
                                                                              rec, compact_walk);
   GS_LAUNCH_CHECK();
-  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest, fork);
+  return sort_tiles_by_depth(payload, ranges, T, S, long_tiles, sorted_out, st, longest, fork, keys_ok);
 }
 
 // The emit step on its own: the fused forward launches it with the buffers' capacity BEFORE it waits for the

@@ -36,7 +36,8 @@ int binning_scatter_and_sort(const float *uv, const float *xyz_c, const float *r
                              const int *table, int *ranges, size_t S, unsigned long long *payload,
                              int *long_tiles, int *sorted_out, long long longest, const int *m_total,
                              const unsigned long long *pair_counters, unsigned long long *pub,
-                             unsigned long long ticket, hipStream_t st, const SortFork *fork, bool compact_walk);
+                             unsigned long long ticket, hipStream_t st, const SortFork *fork, bool compact_walk,
+                             bool keys_ok);
 int emit_sort_ranges(const float *uv, const float *xyz_c, const float *radius, int ntx, int nty, int N,
                      const unsigned char *mask, const int *rank, const int *offsets, size_t S, unsigned int *tkeys_a,
                      unsigned int *tkeys_b, unsigned long long *pay_a, unsigned long long *pay_b, int *sorted_out,
@@ -1921,8 +1922,11 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
   // to queue follows the previous forward's longest list; afterwards the record is checked, and a forward whose
   // instances outgrew the buffers or whose longest list needed a kernel that was not queued is redone from the
   // placement on (results are unaffected: every launch overwrites).
-  auto list_class = [](long long longest) {  // which of the workgroup sort kernels a list of that length needs
-    return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : 1;
+  // (r06: class 0 -- no list beyond the wave kernel's 1024 entries and every depth key an ordinary positive float: the
+  // hand-over kernel is not queued at all, gs_binning.hip sort_tiles_by_depth)
+  const bool keys_ok = cfg->near_thresh >= 1e-30f;
+  auto list_class = [keys_ok](long long longest) {  // which of the workgroup sort kernels a list of that length needs
+    return longest > 8 * 1024 ? 4 : longest > 4 * 1024 ? 3 : longest > 2 * 1024 ? 2 : (longest > 1024 || !keys_ok) ? 1 : 0;
   };
   bool segmented_this_forward = false;
   auto queue_tail = [&](size_t cap, long long longest_hint, bool publish) -> int {  // the placement publishes the record
@@ -1938,7 +1942,8 @@ int gsplat_rasterize_image(gsplat_context *c, const gsplat_gaussians *g, const g
                                          c->hitmask.as<unsigned long long>(), c->rank.as<int>(), N, ntx, nty,
                                          c->bin_table.as<int>(), c->ranges.as<int>(), cap, c->pay_a.as<unsigned long long>(),
                                          c->keys_a.as<int>(), c->sorted.as<int>(), longest_hint, c->rank.as<int>() + N,
-                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st, &c->fork, compact);
+                                         c->pair_counters(), publish ? c->d_pub : nullptr, ticket, st, &c->fork, compact,
+                                         keys_ok);
     if (r) return r;
     c->mark(2, true, st);
     c->mark(4, false, st);

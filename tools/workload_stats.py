@@ -20,6 +20,8 @@ dp = raster.device_params(params); dc = raster.device_camera(scene.make_camera(W
 dgi = torch.as_tensor(scene.make_grad_image(W, H)).cuda()
 ctx = raster.RasterContext(N, W, H)
 ctx.set_lean_forward(os.environ.get('GSPLAT_STATS_FULL') != '1')  # GSPLAT_STATS_FULL=1: every ForwardPassData array stored
+if os.environ.get('GSPLAT_STATS_ROUTE'):  # 1: counting sort + per-tile sorts, 2: rocPRIM radix sorts (A/B of the binning route)
+    ctx.set_binning_route(int(os.environ['GSPLAT_STATS_ROUTE']))
 grads = ctx.alloc_gradients(N, L)
 for _ in range(5):
     fwd = ctx.rasterize_image(dp, dc, cfg, cfg["bg"], L)
