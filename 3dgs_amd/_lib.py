@@ -116,7 +116,8 @@ class Gradients(ctypes.Structure):  # gsplat_gradients
 class AdamFused(ctypes.Structure):  # gsplat_adam_fused
     _fields_ = [("exp_avg", ctypes.c_void_p * 6), ("exp_avg_sq", ctypes.c_void_p * 6), ("lr", ctypes.c_float * 6),
                 ("b1", ctypes.c_float), ("b2", ctypes.c_float), ("eps", ctypes.c_float), ("bias1", ctypes.c_float),
-                ("bias2", ctypes.c_float), ("uv_grad_accum", ctypes.c_void_p), ("grad_accum_dur", ctypes.c_void_p)]
+                ("bias2", ctypes.c_float), ("uv_grad_accum", ctypes.c_void_p), ("grad_accum_dur", ctypes.c_void_p),
+                ("mode", ctypes.c_int)]
 
 
 class AdamGroup(ctypes.Structure):  # gsplat_adam_group

@@ -1010,7 +1010,10 @@ struct AdamFused {
 // thread e owns element e of the span, rebuilds gradient = g_rgb[channel] * Y_k(direction) as
 // optimizer_sh_factored_kernel does and streams sh / exp_avg / exp_avg_sq through the update: consecutive lanes,
 // consecutive addresses.
-template <int L, bool kAdam = false>
+// kAdam 2: all six groups here.  kAdam 1: band 0, opacity, scale, rotation and the statistics here; the SH group
+// (gsplat_optimizer_step_sh_factored, which needs the positions the backward saw) and the position group
+// (gsplat_optimizer_step on grad_xyz) stay with the optimizer kernels behind this one.
+template <int L, int kAdam = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
                                                                 const float *__restrict__ proj, int M,
                                                                 const int *__restrict__ c2g,
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   // gradient rows on the way out.  Each wave stages only its own rows (no workgroup barrier).
   __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 ? kBlock * kRest : 4];
   // kAdam: per row the unit direction and the colour gradient (what the SH gradients are made of) and the global row
-  __shared__ float s_dir[kAdam && kRest > 0 ? kBlock * 7 : 1];
+  __shared__ float s_dir[kAdam == 2 && kRest > 0 ? kBlock * 7 : 1];
   const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
   const int jw = j_first + blockIdx.x * kBlock + wave_first;  // first compacted slot of this wave
   if (jw >= M) return;
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   }
   // (kAdam: the SH group first, while nothing else of the thread's state is live -- the kernel sits at the 168-register
   // step of three workgroups per CU; sh_bwd below still finds the coefficients in LDS, the update went to global memory)
-  if constexpr (kRest > 0 && kAdam) {
+  if constexpr (kRest > 0 && kAdam == 2) {
     {  // the direction exactly as gs::sh_bwd / optimizer_sh_factored_kernel form it (and the colour gradient: rows_in[.].xyz)
       const float4 ga = rows_in[4 * (live ? j : jw)];
       float ux, uy, uz, len;
@@ -1179,10 +1182,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   const float g_u = b.w, g_v = c.x;
   {
     float *row = wsh + lane * kRest;  // read as coefficients, overwritten with their gradients (kAdam: left as they are)
-    gs::sh_bwd<L, !kAdam>(row, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, g_rgb, row, b0g,
+    gs::sh_bwd<L, kAdam == 0>(row, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, g_rgb, row, b0g,
                           gx, gy, gz);
   }
-  if constexpr (kRest > 0 && !kAdam) {
+  if constexpr (kRest > 0 && kAdam == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (o.sh) gs::rows_from_lds<kRest>(o.sh + (size_t)jw * kRest, wsh, rows, lane);
@@ -1199,7 +1202,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
       p[3 * i + k] = pv; m[3 * i + k] = mv; v[3 * i + k] = vv;
     }
   };
-  if constexpr (kAdam) {
+  if constexpr (kAdam != 0) {
     // what is final already -- band 0 (nothing below reads it again), the opacity, the densification statistics
     // (cuda/trainer.cu:1136-1157, optimizer_step_kernel's expressions) -- leaves now, not across the covariance chain
     step3(g.rgb, ad.m_rgb, ad.v_rgb, b0g, ad.lr_rgb);
@@ -1246,10 +1249,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   float wx, wy, wz;
   gs::camera_space_bwd(vw, cxg, cyg, czg, wx, wy, wz);
   gx += wx; gy += wy; gz += wz;
-  if constexpr (kAdam) {
-    // the groups whose gradients the covariance chain produced: position, scale, rotation
-    const float gxyz[3] = {gx, gy, gz};
-    step3(g.xyz, ad.m_xyz, ad.v_xyz, gxyz, ad.lr_xyz);
+  if constexpr (kAdam != 0) {
+    // the groups whose gradients the covariance chain produced: position (kAdam 2), scale, rotation
+    if constexpr (kAdam == 2) {
+      const float gxyz[3] = {gx, gy, gz};
+      step3(g.xyz, ad.m_xyz, ad.v_xyz, gxyz, ad.lr_xyz);
+    }
     step3(g.scale, ad.m_sc, ad.v_sc, dSc, ad.lr_sc);
     {
       float4 pq = reinterpret_cast<const float4 *>(g.quaternion)[i];
@@ -1264,7 +1269,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
     if (!o.xyz) return;  // (gradient arrays: only when the caller asked for them)
   }
   // stores
-  if (o.common) {  // the exchange's row, in global order (the same twelve values pack_split_kernel gathers)
+  if constexpr (kAdam == 1) {
+    // what the optimizer kernels behind this one need: the position gradient and the colour gradient the SH gradients
+    // are made of; the other arrays only where the caller gave them
+    o.xyz[3 * j] = gx; o.xyz[3 * j + 1] = gy; o.xyz[3 * j + 2] = gz;
+    if (o.opacity) o.opacity[j] = g_op;
+    if (o.scale) { o.scale[3 * j] = dSc[0]; o.scale[3 * j + 1] = dSc[1]; o.scale[3 * j + 2] = dSc[2]; }
+    if (o.quaternion) reinterpret_cast<float4 *>(o.quaternion)[j] = make_float4(dQ[0], dQ[1], dQ[2], dQ[3]);
+  } else if (o.common) {  // the exchange's row, in global order (the same twelve values pack_split_kernel gathers)
     gs::f4u *row = reinterpret_cast<gs::f4u *>(o.common + (size_t)i * 12);
     row[0] = gs::f4u{gx, gy, gz, g_op};
     row[1] = gs::f4u{dSc[0], dSc[1], dSc[2], dQ[0]};
@@ -2243,7 +2255,7 @@ int gsplat_backward_gaussians(gsplat_context *c, const gsplat_gaussians *g, cons
 
 static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                    const gsplat_gradients *out, float *common, float *uv_norm, int first_gaussian,
-                                   int end_gaussian, void *stream, const AdamFused *adam = nullptr);
+                                   int end_gaussian, void *stream, const AdamFused *adam = nullptr, int adam_mode = 2);
 
 int gsplat_backward_gaussians_range(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                     const gsplat_gradients *out, int first_gaussian, int end_gaussian, void *stream) {
@@ -2276,12 +2288,18 @@ int gsplat_backward_gaussians_adam(gsplat_context *c, const gsplat_gaussians *g,
                         opt->exp_avg[3], opt->exp_avg_sq[3], opt->exp_avg[4], opt->exp_avg_sq[4], opt->exp_avg[5], opt->exp_avg_sq[5],
                         opt->lr[0], opt->lr[1], opt->lr[2], opt->lr[3], opt->lr[4], opt->lr[5],
                         opt->b1, opt->b2, opt->eps, opt->bias1, opt->bias2, opt->uv_grad_accum, opt->grad_accum_dur};
-  return backward_gaussians_impl(c, g, cam, l_max, out, nullptr, nullptr, 0, g->num_gaussians, stream, &ad);
+  GS_REQUIRE(opt->mode == 0 || opt->mode == 1, "mode: 0 all six groups in the kernel, 1 SH and position left to the optimizer kernels");
+  if (opt->mode == 1) {
+    GS_REQUIRE(out != nullptr, "mode 1 hands grad_xyz and grad_precompute_rgb to the optimizer kernels: `out` is needed");
+    GS_REQUIRE_DEV(out->grad_xyz);
+    if (l_max > 0) GS_REQUIRE_DEV(out->grad_precompute_rgb);
+  }
+  return backward_gaussians_impl(c, g, cam, l_max, out, nullptr, nullptr, 0, g->num_gaussians, stream, &ad, opt->mode == 1 ? 1 : 2);
 }
 
 static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
                                    const gsplat_gradients *out, float *common, float *uv_norm, int first_gaussian,
-                                   int end_gaussian, void *stream, const AdamFused *adam) {
+                                   int end_gaussian, void *stream, const AdamFused *adam, int adam_mode) {
   GS_REQUIRE(c && g && cam, "null argument struct");
   GS_REQUIRE(0 <= first_gaussian && first_gaussian <= end_gaussian && end_gaussian <= g->num_gaussians, "bad gaussian range");
   GS_REQUIRE(c->have_forward && c->rows_ready, "gsplat_backward_render has not run for this forward pass");
@@ -2289,7 +2307,7 @@ static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g,
              "backward arguments do not match the recorded forward pass");
   static const gsplat_gradients kNoArrays = {};
   if (!out) out = &kNoArrays;  // split form: the twelve common columns go to `common`, nothing else is stored
-  if (!common && !(adam && out == &kNoArrays)) {  // (the Adam form stores gradient arrays only when it is given some)
+  if (!common && !(adam && (out == &kNoArrays || adam_mode == 1))) {  // (the Adam forms store only the arrays they are given)
     GS_REQUIRE_DEV(out->grad_xyz); GS_REQUIRE_DEV(out->grad_rgb); GS_REQUIRE_DEV(out->grad_opacity);
     GS_REQUIRE_DEV(out->grad_scale); GS_REQUIRE_DEV(out->grad_quaternion);
     GS_REQUIRE(((uintptr_t)out->grad_quaternion & 15) == 0, "grad_quaternion must be 16-byte aligned");
@@ -2317,14 +2335,20 @@ static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g,
   static const AdamFused kNoAdam = {};
 #define GS_BWD(LL)                                                                                                     \
   do {                                                                                                                 \
-    if (adam)                                                                                                          \
-      preprocess_bwd_kernel<LL, true><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),           \
+    if (adam && adam_mode == 1)                                                                                        \
+      preprocess_bwd_kernel<LL, 1><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),              \
+                                                    c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
+                                                    tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
+                                                    cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
+                                                    ranged, first_gaussian, end_gaussian, *adam);                      \
+    else if (adam)                                                                                                     \
+      preprocess_bwd_kernel<LL, 2><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),           \
                                                     c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
                                                     tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
                                                     cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
                                                     ranged, first_gaussian, end_gaussian, *adam);                      \
     else                                                                                                               \
-      preprocess_bwd_kernel<LL, false><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),          \
+      preprocess_bwd_kernel<LL, 0><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),          \
                                                     c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
                                                     tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
                                                     cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \

@@ -97,7 +97,22 @@ class AdamOptimizer:
             self.uv_grad_accum.data_ptr() if uv is not None else None,
             self.grad_accum_dur.data_ptr() if uv is not None else None, _stream()))
 
-    def fused_state(self, it, with_stats=True):
+    def step_after_partial_backward(self, it, fwd, grads, campos):
+        """What is left of `step` behind RasterContext.backward_pass_adam(..., fused_state(it, mode=1)): the SH group from
+        the factored gradient (it takes its directions from the positions, so it goes first), then the position group."""
+        b1c, b2c = self.bias_corrections(it)
+        c2g = fwd["compact_to_global"].data_ptr() if fwd["num_culled"] else None
+        if "sh" in self.names:
+            check(_lib.load().gsplat_optimizer_step_sh_factored(
+                c2g, int(fwd["num_culled"]), int(self.l_max), self.params["sh"].data_ptr(), self.exp_avg["sh"].data_ptr(),
+                self.exp_avg_sq["sh"].data_ptr(), self.learning_rates(it)["sh"], B1, B2, EPS, b1c, b2c,
+                self.params["xyz"].data_ptr(), float(campos[0]), float(campos[1]), float(campos[2]),
+                grads["precompute_rgb"].data_ptr(), _stream()))
+        arr = self._groups(it, grads, ["xyz"])
+        check(_lib.load().gsplat_optimizer_step(c2g, int(fwd["num_culled"]), arr, 1, B1, B2, EPS, b1c, b2c, None, None, None,
+                                                _stream()))
+
+    def fused_state(self, it, with_stats=True, mode=0):
         """The optimizer's state at iteration `it` as the struct RasterContext.backward_pass_adam hands to the per-gaussian
         backward, which then applies this very step itself (single-GPU training: same parameters, moments and statistics
         as backward_pass + step, bit for bit, without the gradients' round trip through memory)."""
@@ -111,6 +126,7 @@ class AdamOptimizer:
         a.b1, a.b2, a.eps, a.bias1, a.bias2 = B1, B2, EPS, b1c, b2c
         a.uv_grad_accum = self.uv_grad_accum.data_ptr() if with_stats else None
         a.grad_accum_dur = self.grad_accum_dur.data_ptr() if with_stats else None
+        a.mode = int(mode)
         return a
 
     def step_packed(self, it, packed, uv_norm_sum=None):

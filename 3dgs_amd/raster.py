@@ -240,9 +240,9 @@ class RasterContext:
     @staticmethod
     def _grad_struct(grads):
         gs = _lib.Gradients()
-        gs.grad_xyz, gs.grad_rgb, gs.grad_sh = _ptr(grads["xyz"]), _ptr(grads["rgb"]), _ptr(grads.get("sh"))
-        gs.grad_opacity, gs.grad_scale = _ptr(grads["opacity"]), _ptr(grads["scale"])
-        gs.grad_quaternion = _ptr(grads["quaternion"])
+        gs.grad_xyz, gs.grad_rgb, gs.grad_sh = _ptr(grads["xyz"]), _ptr(grads.get("rgb")), _ptr(grads.get("sh"))
+        gs.grad_opacity, gs.grad_scale = _ptr(grads.get("opacity")), _ptr(grads.get("scale"))
+        gs.grad_quaternion = _ptr(grads.get("quaternion"))
         for k in ("conic", "uv", "J", "sigma", "xyz_c", "precompute_rgb"):
             setattr(gs, "grad_" + k, _ptr(grads.get(k)))
         return gs

@@ -65,7 +65,10 @@ class Trainer:
         # (gsplat_backward_gaussians_adam: bit-identical parameters, moments and statistics, no gradient arrays).  Off by
         # default: the one fat kernel takes as long as the three it replaces (352 against 356 us at 1e6 gaussians,
         # profiles/r06_fused_adam.txt) and the iteration is 2 % slower by the wall clock.
-        self.fused_adam = __import__("os").environ.get("GSPLAT_FUSED_ADAM", "0") == "1"
+        #   GSPLAT_FUSED_ADAM=2: all six groups inside the backward (the measurement above);
+        #   GSPLAT_FUSED_ADAM=1: band 0, opacity, scale, rotation and the statistics inside the backward, the SH and the
+        #   position group behind it (the SH group takes its directions from positions that must not have moved yet)
+        self.fused_adam = int(__import__("os").environ.get("GSPLAT_FUSED_ADAM", "0") or 0)
         self._sharded = None  # (key, ViewShardedStep) for the current gaussian count / SH degree
         self._grad_image = {}  # (H, W) -> dL/dimage buffer, allocated once per image size
         self._grads = None     # (capacity, l_max, dict): per-view gradient arrays, reused across iterations
@@ -128,6 +131,14 @@ class Trainer:
             self._grads = (n, self.l_max, ctx.alloc_gradients(n, self.l_max, intermediates=("uv",), factored_sh=True))
         return {k: (v[:m] if v is not None else None) for k, v in self._grads[2].items()}
 
+    def _partial_gradients_for(self, ctx, m):
+        """The two arrays the optimizer kernels behind a partial backward_pass_adam read: grad_xyz, grad_precompute_rgb."""
+        n = self.num_gaussians
+        if getattr(self, "_grads2", None) is None or self._grads2[0] < n:
+            dev = self.params["xyz"].device
+            self._grads2 = (n, dict(xyz=torch.empty(n, 3, device=dev), precompute_rgb=torch.empty(n, 3, device=dev)))
+        return {k: v[:m] for k, v in self._grads2[1].items()}
+
     def train_step(self, cam, gt_image, want_loss=True):
         if self.world > 1:
             return self._train_step_sharded(cam, gt_image, want_loss)
@@ -150,9 +161,13 @@ class Trainer:
         grad_image = self._grad_image_for(H, W, gt_image.device)
         # the loss value is a blocking read-back: only fetched when the caller logs it
         loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image, blocking=want_loss)
-        if self.fused_adam:
+        if self.fused_adam == 2:
             # r06: the per-gaussian backward applies the optimizer step itself (no gradient arrays at all)
             ctx.backward_pass_adam(p, cam, grad_image, bg, self.l_max, self.opt.fused_state(it))
+        elif self.fused_adam == 1:
+            g2 = self._partial_gradients_for(ctx, fwd["num_culled"])
+            ctx.backward_pass_adam(p, cam, grad_image, bg, self.l_max, self.opt.fused_state(it, mode=1), g2)
+            self.opt.step_after_partial_backward(it, fwd, g2, cam["campos"])
         else:
             grads = self._gradients_for(ctx, fwd["num_culled"])
             ctx.backward_pass(p, cam, grad_image, bg, self.l_max, grads)

@@ -395,6 +395,11 @@ typedef struct gsplat_adam_fused {
   float b1, b2, eps, bias1, bias2;   /* include/gsplat_cuda/optimizer.cuh:9-11; bias_k = 1 - b_k^(iteration + 1) */
   float *uv_grad_accum;              /* [N] += |grad_uv| of the visible gaussians; may be NULL */
   int *grad_accum_dur;               /* [N] += 1 for the visible gaussians; may be NULL */
+  int mode;                          /* 0: all six groups in the kernel.  1: band 0, opacity, scale, quaternion and the
+                                      * statistics in the kernel; it stores grad_xyz and grad_precompute_rgb (`out` must hold
+                                      * them) and the caller runs gsplat_optimizer_step_sh_factored and then
+                                      * gsplat_optimizer_step on the xyz group alone -- the positions must not move before
+                                      * the SH group has taken its directions from them */
 } gsplat_adam_fused;
 
 int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width, int max_height);

@@ -152,8 +152,9 @@ def test_factored_sh_step_equals_the_stored_gradient_step(gpu, scene, name):
         ob.step(13, fwd, g_fact)  # no camera position: the direction cannot be rebuilt
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("name", ["small", "small_l1", "small_l0", "mid_l2"])
-def test_backward_with_adam_inside_equals_backward_then_optimizer(gpu, scene, name):
+def test_backward_with_adam_inside_equals_backward_then_optimizer(gpu, scene, name, mode):
     """r06: gsplat_backward_gaussians_adam -- the per-gaussian backward that applies the masked Adam step itself -- must
     leave parameters, both moments of all six groups and the densification statistics BIT-identical to the backward that
     stores its gradients followed by gsplat_optimizer_step_sh_factored + gsplat_optimizer_step (the same gradient values,
@@ -191,8 +192,12 @@ def test_backward_with_adam_inside_equals_backward_then_optimizer(gpu, scene, na
                 t.fill_(float("nan"))
         ctx.backward_gaussians(dp_a, dc, L, g_a)
         oa.step(it, fwd, g_a, campos=cam["campos"])
-        # twin B: one kernel; on the second step without gradient arrays at all (what the trainer does)
-        ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it), g_b if it == 20 else None)
+        if mode == 0:  # twin B: one kernel; on the second step without gradient arrays at all (what the trainer does)
+            ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it), g_b if it == 20 else None)
+        else:  # mode 1: four groups + statistics in the kernel, then the SH and the position group behind it
+            g_part = g_b if it == 20 else dict(xyz=g_b["xyz"], precompute_rgb=g_b.get("precompute_rgb"))
+            ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it, mode=1), g_part)
+            ob.step_after_partial_backward(it, fwd, g_part, cam["campos"])
         torch.cuda.synchronize()
         if it == 20:
             for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "uv", "precompute_rgb"):
