@@ -437,6 +437,7 @@ def config2_workload(torch, scene, raster, dev, reps=100):
     out.update({"M": M, "S": S, "S_eff": S_eff, "num_pairs": fwd["num_pairs"],
                 "tile_list_mean": round(float(lens.float().mean().item()), 1), "tile_list_max": int(lens.max().item()),
                 "ms_per_render": 1e3 / out["render_fps_training_context"],
+                "ms_per_step": 1e3 / out["render_fps_training_context"],  # (forward only: a step of this workload is a render)
                 "stage_ms": {k: round(v[0], 4) for k, v in st.items()},
                 "roofline": compositing_rooflines(S_eff, W * H, st["render_forward"][0], None, None)})
     ctx.close()
