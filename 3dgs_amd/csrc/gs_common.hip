@@ -151,7 +151,7 @@ namespace {
 // because every caller sat on the NULL stream (the reference host owns a second stream: cuda/trainer.cu:1257-1259).
 struct PoolBlock { size_t cls; int device; hipStream_t freed_on; };
 const hipStream_t kQuiet = reinterpret_cast<hipStream_t>(~(uintptr_t)0);
-hipEvent_t g_pool_event = nullptr;  // scratch event of pool_order_behind (used under the pool mutex)
+hipEvent_t g_pool_event[64] = {};  // scratch event of pool_order_behind, one per device (used under the pool mutex)
 unsigned long long g_pool_cross_stream = 0;  // reuses that needed the ordering (gsplat_pool_cross_stream_reuses)
 std::mutex g_pool_mutex;
 std::unordered_map<void *, PoolBlock> g_pool_live, g_pool_idle_info;
@@ -224,12 +224,14 @@ namespace {
 int pool_order_behind(hipStream_t giver, hipStream_t taker) {
   if (giver == kQuiet || giver == taker) return GSPLAT_OK;
   ++g_pool_cross_stream;
-  if (!g_pool_event && hipEventCreateWithFlags(&g_pool_event, hipEventDisableTiming) != hipSuccess) {
+  int dev = -1;  // (an event belongs to the device it was created on: blocks are only ever reused on their own device)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev >= 0 && !g_pool_event[dev] && hipEventCreateWithFlags(&g_pool_event[dev], hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
-    g_pool_event = nullptr;
+    g_pool_event[dev] = nullptr;
   }
-  if (g_pool_event && hipEventRecord(g_pool_event, giver) == hipSuccess &&
-      hipStreamWaitEvent(taker, g_pool_event, 0) == hipSuccess)
+  if (dev >= 0 && g_pool_event[dev] && hipEventRecord(g_pool_event[dev], giver) == hipSuccess &&
+      hipStreamWaitEvent(taker, g_pool_event[dev], 0) == hipSuccess)
     return GSPLAT_OK;
   (void)hipGetLastError();
   if (hipDeviceSynchronize() != hipSuccess) {
