@@ -582,6 +582,25 @@ def test_few_long_tile_lists_in_a_sparse_scene(gpu, scene, orc):
     assert lens.max() > 4096 and ((lens > 1024) & (lens <= 2048)).any() and ((lens > 2048) & (lens <= 4096)).any()
     assert lens.mean() < 768
     _check_forward(fwd, ref)
+    # r06: a context whose previous forward had no list beyond the wave kernel's 1024 entries does not queue the hand-over
+    # sort kernel at all; a forward whose longest list then lands just above (1025..2048: the hand-over class alone) must
+    # notice from its count record and redo its tail -- the lists exact as ever
+    plain = scene.make_gaussians(N, W, H, L)
+    plain["opacity"][:] = -4.0
+    mild = {k: np.array(v, copy=True) for k, v in plain.items()}
+    lo, hi, (cu, cv) = 9600, 11100, (200.0, 100.0)
+    mild["xyz"][lo:hi], mild["scale"][lo:hi] = params["xyz"][lo:hi], params["scale"][lo:hi]
+    ref2 = orc.rasterize(mild, cam, c["near_thresh"], c["mh_dist"], c["cull_mask_padding"], 0.5, L, threads=8)
+    lens2 = np.diff(ref2["ranges"])
+    assert 1024 < lens2.max() <= 2048
+    other = raster.RasterContext(N, W, H)
+    short = other.rasterize_image(raster.device_params(plain), raster.device_camera(cam), c, 0.5, L)
+    assert np.diff(_np(short["ranges"])).max() * 3 // 2 + 64 <= 1024  # (the tail is queued for 1.5x the last longest + 64)
+    before = other.counters()["tail_redone"]
+    _check_forward(other.rasterize_image(raster.device_params(mild), raster.device_camera(cam), c, 0.5, L), ref2)
+    assert other.counters()["tail_redone"] == before + 1
+    _check_forward(other.rasterize_image(raster.device_params(mild), raster.device_camera(cam), c, 0.5, L), ref2)
+    assert other.counters()["tail_redone"] == before + 1  # (the hint now covers the list: nothing is redone)
 
 
 def test_very_long_tile_lists(gpu, scene, orc):
