@@ -140,7 +140,8 @@ struct RowCounts { int c0, c1, c2, c3; };
 // record arrays (slot * 16), so the loop needs no shift; counts are wave-uniform.
 template <int kStride>
 __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigned short *lists, int count, int wave,
-                                                     int lane, int lim0, int lim1, int lim2, int lim3, int round) {
+                                                     int lane, int lim0, int lim1, int lim2, int lim3, int round,
+                                                     int slot0 = 0) {  // slot0: the record arrays' slot of `s_r2[0]` (r06: two sets)
   RowCounts rc = {0, 0, 0, 0};
   const int b0 = wave_first_bit(wave);
   for (int sb = 0; sb < count; sb += 64) {
@@ -151,10 +152,10 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
     const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
     if ((m0 | m1 | m2 | m3) == 0ull) continue;
 #define GS_MBCNT(m) __builtin_amdgcn_mbcnt_hi((unsigned int)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)(m), 0u))
-    if (h0) lists[0 * kStride + rc.c0 + GS_MBCNT(m0)] = (unsigned short)(slot << 4);
-    if (h1) lists[1 * kStride + rc.c1 + GS_MBCNT(m1)] = (unsigned short)(slot << 4);
-    if (h2) lists[2 * kStride + rc.c2 + GS_MBCNT(m2)] = (unsigned short)(slot << 4);
-    if (h3) lists[3 * kStride + rc.c3 + GS_MBCNT(m3)] = (unsigned short)(slot << 4);
+    if (h0) lists[0 * kStride + rc.c0 + GS_MBCNT(m0)] = (unsigned short)((slot0 + slot) << 4);
+    if (h1) lists[1 * kStride + rc.c1 + GS_MBCNT(m1)] = (unsigned short)((slot0 + slot) << 4);
+    if (h2) lists[2 * kStride + rc.c2 + GS_MBCNT(m2)] = (unsigned short)((slot0 + slot) << 4);
+    if (h3) lists[3 * kStride + rc.c3 + GS_MBCNT(m3)] = (unsigned short)((slot0 + slot) << 4);
 #undef GS_MBCNT
     rc.c0 += __popcll(m0); rc.c1 += __popcll(m1); rc.c2 += __popcll(m2); rc.c3 += __popcll(m3);
   }
@@ -162,7 +163,7 @@ __device__ __forceinline__ RowCounts build_row_lists(const float4 *s_r2, unsigne
   // record is all zeros (opacity 0 -> alpha 0): a row past the end of its list then needs no "am I active" test.
   const int longest = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
   const int padded = (longest + round - 1) / round * round;
-  const unsigned short sentinel = (unsigned short)(kStride << 4);
+  const unsigned short sentinel = (unsigned short)((slot0 + kStride) << 4);
   for (int k = lane; k < padded; k += 64) {
     if (k >= rc.c0) lists[0 * kStride + k] = sentinel;
     if (k >= rc.c1) lists[1 * kStride + k] = sentinel;
@@ -1063,6 +1064,355 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
 }
 
+// ---- r06 experiment: the backward with TWO half-batches in flight ("ping-pong").  A batch of the
+// kernel above costs four barriers: (0) flush step 2 done -> staging, (1) staging done -> lists + trips, (2) trips done ->
+// flush step 1, (3) step 1 done -> step 2; the stamps put 20 % of the wave cycles at those barriers and 24 % in staging
+// and flush, during which the trip loop -- the part that bounds the kernel -- does not run in this workgroup.  Here the
+// list is walked in halves of 62 slots with two sets of record arrays and accumulators: while all four waves run the
+// trips of half p on set X = p & 1, ONE wave (p & 3: the duty rotates) first deals with set 1 - X -- it takes half p-1's
+// nine sums per gaussian into registers (one lane per slot), clears them, parks the records of half p+1 (which it
+// requested a phase earlier) in their place, converts the sums and sends the nine atomics straight from its registers (no
+// second step, no parking of the values in LDS) -- and then joins the trips.  The next duty wave requests the records of
+// half p+2 (list entries at the top of the phase, records once its row lists are built: no wait for a dependent round
+// trip in front of the trips).  ONE barrier per half = two per 124 slots instead of four, and nothing between them that
+// the other three waves wait for.  Fused path only (packed records, gradient rows); same arithmetic in the same order as
+// the kernel above per (pixel, gaussian) -- the sums of a gaussian are still merged by LDS atomics in arrival order.
+#ifndef GS_BWD_PINGPONG
+#define GS_BWD_PINGPONG 0  // launch_render_bwd's default for the fused path; GSPLAT_BWD_PINGPONG=0|1 overrides at run time
+#endif
+#ifndef GS_PP_DUTY_PRIO
+#define GS_PP_DUTY_PRIO 2
+#endif
+constexpr int kHalf = 62;
+static_assert(kSegEntries % kHalf == 0, "a segment is a whole number of half-batches");
+static_assert(GS_ROWSUM_QUAD == 2 && GS_BWD_ALPHA_ASM == 1 && GS_BWD_CAP_AS_FORWARD == 1, "the ping-pong kernel exists in the default loop form only");
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_bwd_pp_kernel(
+    const float4 *__restrict__ recs, const int *__restrict__ sorted, const int *__restrict__ ranges, const int *__restrict__ n_px,
+    const float *__restrict__ T_px, const float *__restrict__ grad_image, int width, int height, int ntx, int num_tiles, float bg,
+    float *__restrict__ rows_out, const unsigned short *__restrict__ masks_in, const int *__restrict__ order, TileSegments seg) {
+  constexpr int kS = kHalf + 1;  // slots of one set: 62 + the all-zero sentinel
+  constexpr int kAcc = 10;       // doubles per slot (nine used), as above
+  __shared__ float4 s_r0[2 * kS], s_r1[2 * kS], s_r2[2 * kS];
+  __shared__ double s_acc[2 * kS * kAcc];
+  __shared__ int s_id[2 * kHalf];
+  __shared__ __attribute__((aligned(16))) unsigned short s_list[16 * kHalf];  // [wave][row][62]
+  __shared__ int s_top;
+  int tile, seg_a = 0, seg_end = -1, chk_slot = -1;
+  if (seg.chk && (int)blockIdx.x < seg.extra_cap) {
+    const int e = (int)blockIdx.x;
+    if (e >= *seg.extra_count) return;
+    const int2 ex = seg.extra[e];
+    tile = ex.x;
+    seg_a = ex.y * kSegEntries;
+    seg_end = seg_a + kSegEntries;
+    chk_slot = segment_slot(ranges[tile], ex.y + 1);
+  } else {
+    tile = ordered_tile(order, seg.chk ? (int)blockIdx.x - seg.extra_cap : (int)blockIdx.x, num_tiles);
+    if (tile >= num_tiles) return;
+    if (seg.chk && seg.granted[tile] > 0) { seg_end = kSegEntries; chk_slot = segment_slot(ranges[tile], 1); }
+  }
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, j = lane & 15;
+#if GS_STAMP
+  const unsigned long long st_t0 = GS_NOW(), st_rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_last = st_t0, st_bar = 0, st_stage = 0, st_lists = 0, st_loop = 0, st_flush = 0, st_trips = 0, st_batches = 0;
+  auto st_write = [&]() {
+    if (lane == 0) {
+      unsigned long long *o = gs_stamp_buf + ((size_t)blockIdx.x * 4 + wave) * GS_STAMP_WORDS;
+      o[0] = (unsigned long long)tile; o[1] = st_rt0; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = GS_NOW() - st_t0;
+      o[4] = st_bar; o[5] = st_stage; o[6] = st_lists; o[7] = st_loop; o[8] = st_flush; o[9] = st_trips; o[10] = st_batches;
+      unsigned int xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[11] = xcc; o[12] = 0; o[13] = 0; o[14] = 0; o[15] = (unsigned long long)wave;
+    }
+  };
+#endif
+  const int tile_x = tile % ntx, tile_y = tile / ntx;
+  const int px = tile_x * 16 + (wave & 1) * 8 + (row & 1) * 4 + (j & 3);
+  const int py = tile_y * 16 + (wave >> 1) * 8 + (row >> 1) * 4 + (j >> 2);
+  const bool inside = px < width && py < height;
+  const float fpx = (float)px, fpy = (float)py;
+  const int start = ranges[tile] + seg_a;
+
+  int n = 0;
+  float Tf = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+  if (inside) {
+    const int pid = py * width + px;
+    n = n_px[pid];
+    Tf = T_px[pid];
+    g0 = grad_image[3 * pid]; g1 = grad_image[3 * pid + 1]; g2 = grad_image[3 * pid + 2];
+  }
+  float T = Tf, s = bg * g0 + bg * g1 + bg * g2;  // (see render_bwd_kernel: the carried dot product, the background behind all)
+  if (seg_end >= 0) {
+    if (n > seg_end) {
+      const int pid = py * width + px;
+      const float4 ck = seg.chk[(size_t)chk_slot * 256 + tid];
+      T = ck.x;
+      const float inv = __builtin_amdgcn_rcpf(ck.x);
+      s = (g0 * (seg.image[3 * pid] - ck.y) + g1 * (seg.image[3 * pid + 1] - ck.z) + g2 * (seg.image[3 * pid + 2] - ck.w)) * inv;
+      n = seg_end - seg_a;
+    } else {
+      n = max(n - seg_a, 0);
+    }
+  }
+  const int row_top_v = row_max_int(n);
+  const int rt0 = __builtin_amdgcn_readlane(row_top_v, 0), rt1 = __builtin_amdgcn_readlane(row_top_v, 16);
+  const int rt2 = __builtin_amdgcn_readlane(row_top_v, 32), rt3 = __builtin_amdgcn_readlane(row_top_v, 48);
+  const int wave_top = max(max(rt0, rt1), max(rt2, rt3));
+  if (tid < 2) {  // the two sets' sentinel records
+    s_r0[tid * kS + kHalf] = s_r2[tid * kS + kHalf] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s_r1[tid * kS + kHalf] = sentinel_r1();
+  }
+  if (tid == 0) s_top = 0;
+  for (int k = tid; k < 2 * kS * kAcc; k += 256) s_acc[k] = 0.0;
+  __syncthreads();
+  if (lane == 0) atomicMax(&s_top, wave_top);
+  __syncthreads();
+  const int top = s_top;
+#if GS_STAMP
+  GS_LAP(st_stage);
+  if (top <= 0) { st_write(); return; }
+#endif
+  if (top <= 0) return;
+  const int red_idx = row_moments9r_index(lane);
+  const bool red_lane = red_idx >= 0;
+  const float alpha_cap = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_amdgcn_exp2f(kLog2AlphaMax))));
+  const unsigned int acc0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)reinterpret_cast<char *>(s_acc);
+
+  const int P = (top + kHalf - 1) / kHalf;  // half p covers the entries [(P-1-p) 62, ...): back to front
+  // what a duty wave holds for the half it will bring in: slot `lane`'s list entry and block mask (requested a phase
+  // earlier).  The 48-byte records themselves never pass through registers: twelve more values per lane, live across a
+  // trip loop, are more than the kernel's 64 registers hold, and a spilled load result is first WAITED for -- they go from
+  // HBM straight into the set's record arrays (global_load_lds_dwordx4: lane l's 16 bytes land in slot l) while the
+  // duty wave runs its own trips, and are put into the loop's form in place at the end of the phase (finish_records).
+  int pre_g = 0;
+  unsigned int pre_mask = 0;
+  // `lo`: the lane index behind an opaque per-phase copy (see render_bwd_kernel: addresses and constants derived from the
+  // plain index are loop invariants, get hoisted above the phase loop and spilled -- and a reload from scratch in the duty
+  // wave waits for its atomics)
+  auto request_entry = [&](int p, int lo) {
+    const int b = (P - 1 - p) * kHalf;
+    if (lo < min(kHalf, top - b)) {
+      pre_mask = (unsigned int)masks_in[start + b + lo];
+      pre_g = sorted[start + b + lo];
+    }
+  };
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  auto request_records = [&](int p, int lo) {  // half p's records -> set p & 1, asynchronously
+    const int b = (P - 1 - p) * kHalf, x = p & 1;
+    if (lo < min(kHalf, top - b)) {
+      // (as asm: through the builtin the compiler knows a write to LDS is pending and waits for it -- vmcnt(0) -- in front of
+      // this wave's next LDS access of any kind, i.e. at once; the wait that counts is finish_records' own)
+      const float4 *src = recs + 3 * (size_t)pre_g;
+      const unsigned int d0 = (unsigned int)(size_t)(lptr_t)(s_r0 + x * kS), d1 = (unsigned int)(size_t)(lptr_t)(s_r1 + x * kS);
+      const unsigned int d2 = (unsigned int)(size_t)(lptr_t)(s_r2 + x * kS);
+      unsigned int keep;
+      asm volatile("s_mov_b32 %0, m0\n\t"
+                   "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                   "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                   "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src + 0), "v"(src + 1), "v"(src + 2), "s"(d0), "s"(d1), "s"(d2)
+                   : "memory");
+      s_id[x * kHalf + lo] = pre_g;
+    }
+  };
+  auto finish_records = [&](int p, int lo) {  // once they have landed: the loop's form (stage_record) and the block mask
+    const int b = (P - 1 - p) * kHalf, x = p & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lo < min(kHalf, top - b)) {
+      SplatRec r;
+      r.r0 = s_r0[x * kS + lo]; r.r1 = s_r1[x * kS + lo]; r.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      stage_record(r);
+      s_r0[x * kS + lo] = r.r0; s_r1[x * kS + lo] = r.r1;
+      s_r2[x * kS + lo].w = __uint_as_float(pre_mask);
+    }
+  };
+  // one lane per slot: half q's nine sums -> nine gradient values -> nine atomics; in between the set is handed on
+  // (sums cleared, the next half's records parked: `then`)
+  auto flush_half = [&](int q, int lo, auto then) {
+    const int b = (P - 1 - q) * kHalf, x = q & 1, cnt = min(kHalf, top - b);
+    const bool mine = lo < cnt;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
+    int g = 0;
+    if (mine) {
+      a = s_r0[x * kS + lo]; bb = s_r1[x * kS + lo];
+      g = s_id[x * kHalf + lo];
+    }
+    // (same wave, LDS in order: the reads above return before the records are overwritten; the sums are read only after
+    // the requested records have left their registers -- both at once do not fit the kernel's 64)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    then();
+    if (mine) {
+      const double *acc = &s_acc[(x * kS + lo) * kAcc];
+      const double a0 = acc[0], a1 = acc[1], a2 = acc[2], S1 = acc[3], Sx = acc[4], Sy = acc[5], Sxx = acc[6], Sxy = acc[7], Syy = acc[8];
+      int txo = tile_x, tyo = tile_y, wo = width, ho = height;  // (opaque: see `lo`)
+      asm volatile("" : "+s"(txo), "+s"(tyo), "+s"(wo), "+s"(ho));
+      const float opa = bb.z;
+      const double X = (double)(a.x - ((float)(txo * 16) + 7.5f)), Y = (double)(a.y - ((float)(tyo * 16) + 7.5f));
+      const float sx = (float)(X * S1 - Sx), sy = (float)(Y * S1 - Sy);
+      const float sxx = (float)(X * (X * S1 - 2.0 * Sx) + Sxx);
+      const float sxy = (float)(X * (Y * S1 - Sy) - Y * Sx + Sxy);
+      const float syy = (float)(Y * (Y * S1 - 2.0 * Sy) + Syy);
+      const float ca = a.z * kConicDiag, cb = a.w * kConicOff, cc = bb.x * kConicDiag;
+      const bool any_gp = (S1 != 0.0) | (Sx != 0.0) | (Sy != 0.0) | (Sxx != 0.0) | (Sxy != 0.0) | (Syy != 0.0);
+      const float keep = (opa == 1.0f || !any_gp) ? 0.0f : 1.0f;  // cuda/render_backward.cu:170 (see the kernel above)
+      // the nine values (and the gaussian) wait in the slot's own -- now dead -- accumulators for the transposed pass below
+      float *res = reinterpret_cast<float *>(&s_acc[(x * kS + lo) * kAcc]);
+      res[0] = keep * (float)a0;
+      res[1] = keep * (float)a1;
+      res[2] = keep * (float)a2;
+      res[3] = keep * ((float)S1 * (1.0f - opa));
+      res[4] = keep * (-0.5f * sxx);
+      res[5] = keep * -sxy;
+      res[6] = keep * (-0.5f * syy);
+      res[7] = keep * (-(ca * sx + cb * sy) * (0.5f * (float)wo));
+      res[8] = keep * (-(cc * sy + cb * sx) * (0.5f * (float)ho));
+      res[9] = __int_as_float(g);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 16 lanes per gaussian: each wave instruction adds into four whole 64-byte gradient rows (one lane per VALUE of one
+    // gaussian sends nine times as many requests to the L2's atomic units: 1.04 ms instead of 0.28, measured)
+    const int k = lo & 15;
+#pragma unroll 4
+    for (int r = 0; r < (kHalf + 3) / 4; ++r) {
+      const int slot = 4 * r + (lo >> 4);
+      if (slot < cnt && k < 9) {
+        const float *res = reinterpret_cast<const float *>(&s_acc[(x * kS + slot) * kAcc]);
+        const float val = res[k];
+        const int gg = __float_as_int(res[9]);
+        if (val != 0.0f) atomicAdd(rows_out + (size_t)gg * 16 + k, val);  // zero: nothing to add -- NaN still goes out
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+      double *acc = &s_acc[(x * kS + lo) * kAcc];
+#pragma unroll
+      for (int kk = 0; kk < kAcc; ++kk) acc[kk] = 0.0;
+    }
+  };
+
+  // (every value loaded so far is taken here: a wait for them placed by the compiler inside the trip loop would also wait for
+  // the duty wave's atomics and requests, which are younger)
+  asm volatile("" : "+v"(T), "+v"(s), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(n));
+  // before the first phase: wave 3 brings half 0 in by itself (the one exposed round trip), wave 0 asks for half 1's entries
+  if (wave == 3) { request_entry(0, lane); request_records(0, lane); finish_records(0, lane); }
+  if (wave == 0 && P > 1) request_entry(1, lane);
+  for (int p = 0; p < P; ++p) {
+    const int base = (P - 1 - p) * kHalf, count = min(kHalf, top - base), x = p & 1;
+#if GS_STAMP
+    ++st_batches;
+    GS_LAP(st_flush);
+#endif
+    __syncthreads();
+    GS_LAP(st_bar);
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int lo = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (wv == (p & 3)) {  // this phase's duty wave: the other set
+#if GS_PP_DUTY_PRIO
+      __builtin_amdgcn_s_setprio(GS_PP_DUTY_PRIO);  // (its workgroup's three other waves will wait for this one)
+#endif
+      if (p > 0) flush_half(p - 1, lo, [&]() { if (p + 1 < P) request_records(p + 1, lo); });
+      else if (p + 1 < P) request_records(p + 1, lo);
+#if GS_PP_DUTY_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    GS_LAP(st_stage);
+    const bool asks = wv == ((p + 1) & 3) && p + 2 < P;
+    if (asks) request_entry(p + 2, lo);
+    const bool active = base < wave_top;
+    unsigned int list_lds = 0;
+    int trips = 0;
+    if (active) {
+      unsigned short *lists = s_list + wv * 4 * kHalf;
+      list_lds = (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned short *)(lists + (lo >> 4) * kHalf);
+      const RowCounts rc = build_row_lists<kHalf>(s_r2 + x * kS, lists, count, wv, lo, rt0 - base, rt1 - base, rt2 - base, rt3 - base, 1, x * kS);
+      trips = max(max(rc.c0, rc.c1), max(rc.c2, rc.c3));
+    }
+#if GS_STAMP
+    st_trips += trips;
+    GS_LAP(st_lists);
+#endif
+    if (active) {
+      // (a list entry is the slot's byte offset in the record arrays, the set's first slot included: constant bases)
+      const int n_rel = (n - base + x * kS) * 16;
+      const char *r0x = reinterpret_cast<const char *>(s_r0), *r1x = reinterpret_cast<const char *>(s_r1);
+      const char *r2x = reinterpret_cast<const char *>(s_r2);
+      const unsigned int acc_lane = acc0 + (unsigned int)(red_idx * 8);
+      float g0b = g0, g1b = g1, g2b = g2;
+      asm volatile("" : "+v"(g0b), "+v"(g1b), "+v"(g2b));
+      const RowsWeights rw = make_rows_weights(t & 63, (float)(((t >> 6) & 1) * 8 + ((t >> 4) & 1) * 4 + (t & 3)) - 7.5f,
+                                               (float)((t >> 7) * 8 + ((t >> 5) & 1) * 4 + ((t >> 2) & 3)) - 7.5f, g0b, g1b, g2b);
+      auto run_trips = [&](auto check_n) {
+        constexpr bool kCheckN = decltype(check_n)::value;
+        for (int i = trips - 1; i >= 0; --i) {
+          int off;
+          asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(off) : "v"(list_lds + 2 * i) : "memory");
+          const float4 a = *reinterpret_cast<const float4 *>(r0x + off), b = *reinterpret_cast<const float4 *>(r1x + off);
+          const float4 c = *reinterpret_cast<const float4 *>(r2x + off);
+          asm volatile("" ::"v"(c.w));
+          const float dx = a.x - fpx, dy = a.y - fpy;
+          float og, t0;
+          {
+            float tq, uq;
+            asm("v_mul_f32 %[t], %[a2], %[dx]\n\t"
+                "v_mul_f32 %[u], %[c2], %[dy]\n\t"
+                "v_fmac_f32 %[t], %[b2], %[dy]\n\t"
+                "v_fma_f32 %[t], %[t], %[dx], %[lopa]\n\t"
+                "v_fmac_f32 %[t], %[u], %[dy]\n\t"
+                "v_min_f32 %[t], %[t], %[lopa]\n\t"
+                "v_exp_f32 %[og], %[t]\n\t"
+                "v_fma_f32 %[t0], %[cx], %[g0], -%[s]"
+                : [og] "=&v"(og), [t0] "=&v"(t0), [t] "=&v"(tq), [u] "=&v"(uq)
+                : [a2] "v"(a.z), [b2] "v"(a.w), [c2] "v"(b.x), [lopa] "v"(b.y), [dx] "v"(dx), [dy] "v"(dy), [cx] "v"(c.x),
+                  [g0] "v"(g0), [s] "v"(s));
+          }
+          const bool valid = kCheckN ? (!(og < kAlphaMin) && (off < n_rel)) : !(og < kAlphaMin);
+          if (__ballot(valid) == 0ull) continue;
+          og = valid ? og : 0.0f;
+          float alpha;
+          asm("v_min_f32 %0, %2, %1" : "=v"(alpha) : "v"(og), "s"(alpha_cap));
+          const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+          T *= inv;
+          const float aT = alpha * T;
+          const float tt = __builtin_fmaf(c.z, g2, __builtin_fmaf(c.y, g1, t0));
+          const float ga = tt * T;
+          s = __builtin_fmaf(alpha, tt, s);
+          const float gp = og * ga;
+          unsigned int acc_addr;
+          const float red = row_moments9r(aT, gp, rw, (unsigned int)off, acc_lane, acc_addr);
+          if (red_lane)
+            __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double *>(acc_addr),
+                                   (double)red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+#if GS_BWD_PRIO
+      __builtin_amdgcn_s_setprio(GS_BWD_PRIO);
+#endif
+      if (__any(n_rel < (count + x * kS) * 16)) run_trips(std::true_type{});
+      else run_trips(std::false_type{});
+#if GS_BWD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    GS_LAP(st_loop);
+    if (wv == (p & 3) && p + 1 < P) finish_records(p + 1, lo);
+    GS_LAP(st_stage);
+  }
+  __syncthreads();
+  GS_LAP(st_bar);
+  if (wave == (P & 3)) flush_half(P - 1, lane, []() {});
+#if GS_STAMP
+  GS_LAP(st_flush);
+  st_write();
+#endif
+}
+
 // Deals every XCD's run of tiles heaviest first (r04).  The hardware starts workgroups in block order, so with the plain
 // map the launch ends on whatever tiles sit at the end of the runs, and its last round lasts as long as the heaviest of
 // them; heaviest first, the last round is made of the lightest tiles of the image.  `work[t]`: list length (forward) or
@@ -1411,7 +1761,15 @@ int launch_render_bwd(const float4 *recs, const RawSplats *raw, const int *sorte
   const dim3 grid(tile_grid(num_tiles) + (seg.chk ? seg.extra_cap : 0)), block(256);
   RawSplats none = {nullptr, nullptr, nullptr, nullptr};
   GradOut out = {rows, g_rgb, g_opacity, g_uv, g_conic};
-  if (recs && rows && ev_start && ev_stop) {
+  const char *pp_env = getenv("GSPLAT_BWD_PINGPONG");  // (read per launch: the tests switch it inside one process)
+  const int pingpong = pp_env ? atoi(pp_env) : GS_BWD_PINGPONG;
+  if (recs && rows && pingpong) {  // r06 experiment: two half-batches in flight (render_bwd_pp_kernel)
+    if (ev_start && ev_stop)
+      hipExtLaunchKernelGGL(render_bwd_pp_kernel, grid, block, 0, st, ev_start, ev_stop, 0, recs, sorted, ranges, n_px, T_px,
+                            grad_image, width, height, ntx, num_tiles, bg, rows, masks_in, order, seg);
+    else
+      render_bwd_pp_kernel<<<grid, block, 0, st>>>(recs, sorted, ranges, n_px, T_px, grad_image, width, height, ntx, num_tiles, bg, rows, masks_in, order, seg);
+  } else if (recs && rows && ev_start && ev_stop) {
     // timed launch (the context's per-stage timing): the events take the begin and end timestamps of THIS dispatch from
     // its completion signal.  Two hipEventRecord calls around the launch are barrier packets of their own and kept the
     // GPU idle for ~11 us before and ~6 us after the kernel in every step they were on.
