@@ -125,6 +125,7 @@ struct gsplat_context {
   hipEvent_t ev_pre_fork = nullptr, ev_pre_join = nullptr;
   gs::DeviceBuffer chunk_first;  // [chunks of the index space]: slice-local rank of each chunk's first index (mode 2)
   gs::DeviceBuffer kept;     // slice-local lists of the kept gaussians (project_cull -> preprocess' compacted walk)
+  gs::DeviceBuffer dir_grad;  // [M,3]: sh_adam_dir_kernel -> preprocess_bwd_kernel<L, 3> (gsplat_adam_fused.mode 2)
   gs::SortFork fork;         // side streams for the per-tile sorts of long lists (created when a forward first needs them)
   // the forward's record (gs_common.h: publish_record): pinned host memory the GPU writes and the host polls
   volatile unsigned long long *h_pub = nullptr;
@@ -175,7 +176,7 @@ struct gsplat_context {
     const gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                      &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                      &sorted, &temp, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order,
-                                     &seg_first, &seg_extra, &seg_chk, &fseg_first, &fseg_blocks, &fseg_gran, &fseg_part, &fseg_stop};
+                                     &seg_first, &seg_extra, &seg_chk, &fseg_first, &fseg_blocks, &fseg_gran, &fseg_part, &fseg_stop, &dir_grad};
     size_t b = 0;
     for (auto *p : all) b += p->bytes;
     return b;
@@ -186,7 +187,7 @@ struct gsplat_context {
     gs::DeviceBuffer *all[] = {&mask, &counters, &rank, &xyz_c_all, &uv_all, &c2g, &xyz_c, &uv, &sigma, &conic, &J,
                                &rgb, &radius, &recs, &counts, &offsets, &grad_rows, &hitmask, &keys_a, &keys_b, &pay_a, &pay_b,
                                &sorted, &temp, &bin_table, &ranges, &image, &T_px, &n_px, &blockmasks, &kept, &tile_tops, &tile_order,
-                               &seg_first, &seg_extra, &seg_chk, &fseg_first, &fseg_blocks, &fseg_gran, &fseg_part, &fseg_stop};
+                               &seg_first, &seg_extra, &seg_chk, &fseg_first, &fseg_blocks, &fseg_gran, &fseg_part, &fseg_stop, &dir_grad};
     for (auto *p : all) p->release();
     fseg_gran_zeroed = nullptr;
     fork.destroy();
@@ -996,6 +997,7 @@ struct AdamFused {
   float b1, b2, eps, bias1, bias2;
   float *uv_accum;
   int *accum_dur;
+  float *dir;  // kAdam 3: [M,3] d loss / d position through the view direction of the colour (sh_adam_dir_kernel -> here)
 };
 
 // ---- backward of everything per gaussian, one thread per compacted slot
@@ -1012,9 +1014,15 @@ struct AdamFused {
 // consecutive addresses.
 // kAdam 2: all six groups here.  kAdam 1: band 0, opacity, scale, rotation and the statistics here; the SH group
 // (gsplat_optimizer_step_sh_factored, which needs the positions the backward saw) and the position group
-// (gsplat_optimizer_step on grad_xyz) stay with the optimizer kernels behind this one.
+// (gsplat_optimizer_step on grad_xyz) stay with the optimizer kernels behind this one.  kAdam 3: the five small groups
+// here and NOTHING of the SH rows -- sh_adam_dir_kernel (below) has run in front of this kernel: it read the coefficient
+// rows once, for their Adam step AND for sh_bwd's sums over them, and left the position gradient through the view
+// direction in ad.dir; no LDS, and without sh_bwd's basis tables far fewer registers.
+#ifndef GS_BWD3_WAVES
+#define GS_BWD3_WAVES 3  // waves per SIMD the kAdam 3 form is compiled for (r06 A/B)
+#endif
 template <int L, int kAdam = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kAdam == 3 ? GS_BWD3_WAVES : 3, 8))) void preprocess_bwd_kernel(gsplat_gaussians g, const float *__restrict__ view,
                                                                 const float *__restrict__ proj, int M,
                                                                 const int *__restrict__ c2g,
                                                                 const float *__restrict__ xyz_c_sel,
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   // The SH rows (kRest floats per gaussian, 180 B at degree 3) go through LDS: a lane reading ITS row touches 64
   // different cache lines per wave instruction; the wave's 64 rows as one linear span touch 8.  Same for the
   // gradient rows on the way out.  Each wave stages only its own rows (no workgroup barrier).
-  __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 ? kBlock * kRest : 4];
+  __shared__ __attribute__((aligned(16))) float s_sh[kRest > 0 && kAdam != 3 ? kBlock * kRest : 4];
   // kAdam: per row the unit direction and the colour gradient (what the SH gradients are made of) and the global row
   __shared__ float s_dir[kAdam == 2 && kRest > 0 ? kBlock * 7 : 1];
   const int lane = threadIdx.x & 63, wave_first = threadIdx.x - lane;
@@ -1048,8 +1056,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   const int rows = min(64, M - jw);
   const bool live = j < M;
   const int i = c2g[live ? j : jw];
-  float *wsh = s_sh + wave_first * kRest;
-  if constexpr (kRest > 0) {
+  float *wsh = s_sh + (kAdam != 3 ? wave_first * kRest : 0);
+  if constexpr (kRest > 0 && kAdam != 3) {
     const int i0 = __builtin_amdgcn_readfirstlane(i);
     if (__all(!live || i == i0 + lane)) {  // consecutive gaussians (no culling in between): one linear span
       gs::rows_to_lds<kRest>(g.sh + (size_t)i0 * kRest, wsh, rows, lane);
@@ -1180,7 +1188,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   const float g_op = a.w;
   const float g_con[3] = {b.x, b.y, b.z};
   const float g_u = b.w, g_v = c.x;
-  {
+  if constexpr (kAdam == 3 && kRest > 0) {
+    // gs::sh_bwd's two results from elsewhere: band 0's gradient is its own expression (Y_0 is the constant), the position
+    // gradient through the view direction is what sh_adam_dir_kernel left (the same sums in the same order)
+    b0g[0] = g_rgb[0] * GS_SH_C0; b0g[1] = g_rgb[1] * GS_SH_C0; b0g[2] = g_rgb[2] * GS_SH_C0;
+    gx = ad.dir[3 * (size_t)jr]; gy = ad.dir[3 * (size_t)jr + 1]; gz = ad.dir[3 * (size_t)jr + 2];
+  } else {
     float *row = wsh + lane * kRest;  // read as coefficients, overwritten with their gradients (kAdam: left as they are)
     gs::sh_bwd<L, kAdam == 0>(row, g.rgb + 3 * i, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2], cx, cy, cz, g_rgb, row, b0g,
                           gx, gy, gz);
@@ -1251,7 +1264,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
   gx += wx; gy += wy; gz += wz;
   if constexpr (kAdam != 0) {
     // the groups whose gradients the covariance chain produced: position (kAdam 2), scale, rotation
-    if constexpr (kAdam == 2) {
+    if constexpr (kAdam == 2 || kAdam == 3) {
       const float gxyz[3] = {gx, gy, gz};
       step3(g.xyz, ad.m_xyz, ad.v_xyz, gxyz, ad.lr_xyz);
     }
@@ -1301,6 +1314,89 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 8))) 
     for (int k = 0; k < 6; ++k) o.sigma[6 * j + k] = dS[k];
   }
   if (o.xyz_c) { o.xyz_c[3 * j] = cxg; o.xyz_c[3 * j + 1] = cyg; o.xyz_c[3 * j + 2] = czg; }
+}
+
+// r06 (gsplat_adam_fused.mode 2): the SH group's Adam step and gs::sh_bwd's sums over the coefficient rows in ONE read of
+// the rows.  The unfused iteration reads them twice -- preprocess_bwd_kernel for d colour / d direction, then
+// optimizer_sh_factored_kernel for the update -- and the one fat kernel (kAdam 2) reads them once but at three waves per
+// SIMD.  Here sixteen lanes own one gaussian: lane k its coefficient k + 1 (three channels: 12 bytes of the parameter row
+// and of both moment rows, neighbouring lanes neighbouring pieces, as optimizer_sh_factored_kernel).  Every lane evaluates
+// the basis and its gradient at the row's direction and keeps its own coefficient's entries; the update is
+// optimizer_sh_factored_kernel's (gradient = g_rgb[channel] * Y_k), from the OLD coefficients the lane also forms its
+// nine products dY_k/d(axis) * coefficient[channel], and the nine sums over k run through the row as a chain of DPP adds
+// (row_shr:1, one instruction per step and sum): lane k ends with exactly gs::sh_bwd's left-to-right partial sum
+// ((0 + band-0 term) + k = 1) + ... + k, so the
+// last coefficient's lane holds sh_bwd's sums BIT FOR BIT and finishes its three outputs.  No LDS, ~60 registers.
+template <int L>
+__global__ __launch_bounds__(kBlock) void sh_adam_dir_kernel(int M, const int *__restrict__ c2g, float *__restrict__ sh,
+                                                             float *__restrict__ m, float *__restrict__ v, float lr,
+                                                             float b1, float b2, float eps, float bias1, float bias2,
+                                                             const float *__restrict__ xyz,
+                                                             const float *__restrict__ band0, float cx, float cy, float cz,
+                                                             const float4 *__restrict__ rows_in, float *__restrict__ dir_out) {
+  constexpr int n = (L + 1) * (L + 1), kCoef = n - 1;
+  static_assert(L >= 1 && kCoef <= 15, "one 16-lane row per gaussian");
+  const unsigned int t = blockIdx.x * (unsigned int)kBlock + threadIdx.x;
+  const unsigned int r = t >> 4;
+  const int k = (int)(t & 15u);
+  if (r >= (unsigned int)M) return;  // (a whole DPP row leaves together)
+  const long long row = c2g[r];
+  const float4 ga = rows_in[4 * (size_t)r];  // d loss / d colour of this view: rows[.][0..2]
+  const float gr[3] = {ga.x, ga.y, ga.z};
+  float ux, uy, uz, len;
+  gs::view_dir(xyz[3 * row], xyz[3 * row + 1], xyz[3 * row + 2], cx, cy, cz, ux, uy, uz, len);
+  float Y[n], dY[n][3];
+  gs::sh_basis<L>(ux, uy, uz, Y);
+  gs::sh_basis_grad<L>(ux, uy, uz, dY);
+  float yv = 0.0f, dd[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < kCoef; ++q) {
+    yv = k == q ? Y[q + 1] : yv;
+    dd[0] = k == q ? dY[q + 1][0] : dd[0]; dd[1] = k == q ? dY[q + 1][1] : dd[1]; dd[2] = k == q ? dY[q + 1][2] : dd[2];
+  }
+  const bool act = k < kCoef;
+  const long long o = (row * kCoef + k) * 3;
+  float p[3] = {0.0f, 0.0f, 0.0f};
+  if (act) {
+    float mm[3], vv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p[c] = sh[o + c]; mm[c] = m[o + c]; vv[c] = v[o + c]; }
+    float pn[3] = {p[0], p[1], p[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gs::adam_values(pn[c], mm[c], vv[c], gr[c] * yv, lr, b1, b2, eps, bias1, bias2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sh[o + c] = pn[c]; m[o + c] = mm[c]; v[o + c] = vv[c]; }
+  }
+  // acc[axis][channel]: gs::sh_bwd's dRx dGx dBx | dRy .. | dRz ..  x = what a lane adds: its product, in lane 0 sh_bwd's
+  // start (0 + band-0 term) + product.  One DPP add per step and sum: lane l takes lane l - 1's partial sum + x; lane 0 gets a
+  // zero shifted in and re-forms 0 + x = its start (never -0: a sum that began with + 0 is not), so there is no select.
+  float x[3][3], acc[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float leaf = dd[a] * p[c];
+      float first = 0.0f;
+      first += dY[0][a] * band0[3 * row + c];
+      first += leaf;
+      x[a][c] = acc[a][c] = k == 0 ? first : leaf;
+    }
+#pragma unroll
+  for (int step = 1; step < kCoef; ++step)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        acc[a][c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[a][c]), 0x111 /* row_shr:1 */, 0xF, 0xF, true)) + x[a][c];
+  if (k == kCoef - 1) {  // gs::sh_bwd's last lines
+    const float tx = gr[0] * acc[0][0] + gr[1] * acc[0][1] + gr[2] * acc[0][2];
+    const float ty = gr[0] * acc[1][0] + gr[1] * acc[1][1] + gr[2] * acc[1][2];
+    const float tz = gr[0] * acc[2][0] + gr[1] * acc[2][1] + gr[2] * acc[2][2];
+    const float dot = tx * ux + ty * uy + tz * uz;
+    dir_out[3 * (size_t)r] = (tx - dot * ux) / len;
+    dir_out[3 * (size_t)r + 1] = (ty - dot * uy) / len;
+    dir_out[3 * (size_t)r + 2] = (tz - dot * uz) / len;
+  }
 }
 
 // ---- global-order gradient rows for the view-sharded all-reduce
@@ -2284,17 +2380,43 @@ int gsplat_backward_gaussians_adam(gsplat_context *c, const gsplat_gaussians *g,
              "the quaternion moments must be 16-byte aligned");
   if (opt->uv_grad_accum) GS_REQUIRE_DEV(opt->uv_grad_accum);
   if (opt->grad_accum_dur) GS_REQUIRE_DEV(opt->grad_accum_dur);
-  const AdamFused ad = {opt->exp_avg[0], opt->exp_avg_sq[0], opt->exp_avg[1], opt->exp_avg_sq[1], opt->exp_avg[2], opt->exp_avg_sq[2],
-                        opt->exp_avg[3], opt->exp_avg_sq[3], opt->exp_avg[4], opt->exp_avg_sq[4], opt->exp_avg[5], opt->exp_avg_sq[5],
-                        opt->lr[0], opt->lr[1], opt->lr[2], opt->lr[3], opt->lr[4], opt->lr[5],
-                        opt->b1, opt->b2, opt->eps, opt->bias1, opt->bias2, opt->uv_grad_accum, opt->grad_accum_dur};
-  GS_REQUIRE(opt->mode == 0 || opt->mode == 1, "mode: 0 all six groups in the kernel, 1 SH and position left to the optimizer kernels");
+  AdamFused ad = {opt->exp_avg[0], opt->exp_avg_sq[0], opt->exp_avg[1], opt->exp_avg_sq[1], opt->exp_avg[2], opt->exp_avg_sq[2],
+                  opt->exp_avg[3], opt->exp_avg_sq[3], opt->exp_avg[4], opt->exp_avg_sq[4], opt->exp_avg[5], opt->exp_avg_sq[5],
+                  opt->lr[0], opt->lr[1], opt->lr[2], opt->lr[3], opt->lr[4], opt->lr[5],
+                  opt->b1, opt->b2, opt->eps, opt->bias1, opt->bias2, opt->uv_grad_accum, opt->grad_accum_dur, nullptr};
+  GS_REQUIRE(opt->mode >= 0 && opt->mode <= 2,
+             "mode: 0 all six groups in one kernel, 1 SH and position left to the optimizer kernels, 2 the SH group in a kernel of its own in front");
   if (opt->mode == 1) {
     GS_REQUIRE(out != nullptr, "mode 1 hands grad_xyz and grad_precompute_rgb to the optimizer kernels: `out` is needed");
     GS_REQUIRE_DEV(out->grad_xyz);
     if (l_max > 0) GS_REQUIRE_DEV(out->grad_precompute_rgb);
   }
-  return backward_gaussians_impl(c, g, cam, l_max, out, nullptr, nullptr, 0, g->num_gaussians, stream, &ad, opt->mode == 1 ? 1 : 2);
+  if (opt->mode == 2 && l_max > 0 && c && c->have_forward && c->M > 0) {
+    // the SH rows are read ONCE, by sh_adam_dir_kernel: their Adam step and sh_bwd's sums over them; the per-gaussian
+    // backward behind it (kAdam 3) takes the position gradient through the view direction from c->dir_grad
+    GS_REQUIRE(c->rows_ready, "gsplat_backward_render has not run for this forward pass");
+    GS_REQUIRE(l_max == c->l_max && g->num_gaussians == c->N, "backward arguments do not match the recorded forward pass");
+    GS_REQUIRE(cam != nullptr, "null argument struct");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = c->dir_grad.reserve((size_t)c->M * 3 * sizeof(float), st);
+    if (rc) return rc;
+    ad.dir = c->dir_grad.as<float>();
+    const unsigned int blocks = (unsigned int)(((long long)c->M * 16 + kBlock - 1) / kBlock);
+    float *sh_p = const_cast<float *>(g->sh);
+#define GS_SHA(LL)                                                                                                     \
+  sh_adam_dir_kernel<LL><<<blocks, kBlock, 0, st>>>(c->M, c->c2g.as<int>(), sh_p, ad.m_sh, ad.v_sh, ad.lr_sh, ad.b1, ad.b2,  \
+                                                   ad.eps, ad.bias1, ad.bias2, g->xyz, g->rgb, cam->campos[0], cam->campos[1], \
+                                                   cam->campos[2], c->grad_rows.as<float4>(), ad.dir)
+    switch (l_max) {
+      case 1: GS_SHA(1); break;
+      case 2: GS_SHA(2); break;
+      default: GS_SHA(3); break;
+    }
+#undef GS_SHA
+    GS_LAUNCH_CHECK();
+  }
+  return backward_gaussians_impl(c, g, cam, l_max, out, nullptr, nullptr, 0, g->num_gaussians, stream, &ad,
+                                 opt->mode == 1 ? 1 : opt->mode == 2 ? 3 : 2);
 }
 
 static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g, const gsplat_camera *cam, int l_max,
@@ -2332,11 +2454,17 @@ static int backward_gaussians_impl(gsplat_context *c, const gsplat_gaussians *g,
   const int ranged = whole ? 0 : 1;
   const dim3 grid(gs::div_up(span, kBlock)), block(kBlock);
   c->mark(7, false, st);
-  static const AdamFused kNoAdam = {};
+  static const AdamFused kNoAdam = {};  // (value-initialised: every pointer null)
 #define GS_BWD(LL)                                                                                                     \
   do {                                                                                                                 \
     if (adam && adam_mode == 1)                                                                                        \
       preprocess_bwd_kernel<LL, 1><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),              \
+                                                    c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
+                                                    tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
+                                                    cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \
+                                                    ranged, first_gaussian, end_gaussian, *adam);                      \
+    else if (adam && adam_mode == 3)                                                                                   \
+      preprocess_bwd_kernel<LL, 3><<<grid, block, 0, st>>>(*g, cam->view, cam->proj, M, c->c2g.as<int>(),              \
                                                     c->xyz_c.as<float>(), c->grad_rows.as<float4>(), fx, fy, tan_fovx, \
                                                     tan_fovy, fwd_tan_fovx, fwd_tan_fovy, c->mh_dist,                  \
                                                     cam->campos[0], cam->campos[1], cam->campos[2], W, H, bo,          \

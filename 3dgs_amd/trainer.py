@@ -61,14 +61,19 @@ class Trainer:
         self.comm = comm if comm is not None else TorchComm()
         self.world, self.rank = self.comm.world, self.comm.rank
         self.exchange = exchange
-        # r06, one rank: GSPLAT_FUSED_ADAM=1 lets the per-gaussian backward apply the optimizer step itself
-        # (gsplat_backward_gaussians_adam: bit-identical parameters, moments and statistics, no gradient arrays).  Off by
-        # default: the one fat kernel takes as long as the three it replaces (352 against 356 us at 1e6 gaussians,
-        # profiles/r06_fused_adam.txt) and the iteration is 2 % slower by the wall clock.
-        #   GSPLAT_FUSED_ADAM=2: all six groups inside the backward (the measurement above);
-        #   GSPLAT_FUSED_ADAM=1: band 0, opacity, scale, rotation and the statistics inside the backward, the SH and the
-        #   position group behind it (the SH group takes its directions from positions that must not have moved yet)
-        self.fused_adam = int(__import__("os").environ.get("GSPLAT_FUSED_ADAM", "0") or 0)
+        # r06, one rank: where the optimizer step runs (GSPLAT_FUSED_ADAM; every form leaves parameters, moments and
+        # statistics bit-identical -- tests/test_optimizer_gpu.py; kernel times at 1e6 gaussians, SH 3, from one trace:
+        # profiles/r06_two_kernel_adam.txt):
+        #   1 (default): band 0, opacity, scale, rotation and the statistics inside the per-gaussian backward, then
+        #     gsplat_optimizer_step_sh_factored (which takes its directions from positions that must not have moved yet) and
+        #     gsplat_optimizer_step on the position group alone: 122 + 183 + 24 us against 72 + 176 + 94 -- 20 us of an
+        #     iteration's 1100, and only the position and colour gradients are stored;
+        #   3: two kernels -- sh_adam_dir_kernel in front reads the SH rows once (the SH group's step and the sums over the
+        #     rows that the position gradient needs), then the backward with the five small groups' steps and no SH rows:
+        #     219 + 113 us, 10 us of the 1100, no gradient arrays at all;
+        #   2: all six groups inside the backward (one fat kernel at three waves per SIMD: 356 us, 2 % slower);
+        #   0: the backward stores its gradients, the two optimizer kernels read them (r01-r05).
+        self.fused_adam = int(__import__("os").environ.get("GSPLAT_FUSED_ADAM", "1") or 0)
         self._sharded = None  # (key, ViewShardedStep) for the current gaussian count / SH degree
         self._grad_image = {}  # (H, W) -> dL/dimage buffer, allocated once per image size
         self._grads = None     # (capacity, l_max, dict): per-view gradient arrays, reused across iterations
@@ -161,7 +166,11 @@ class Trainer:
         grad_image = self._grad_image_for(H, W, gt_image.device)
         # the loss value is a blocking read-back: only fetched when the caller logs it
         loss = ops.fused_loss(fwd["image"], gt_image, H, W, float(c["ssim_frac"]), grad_image, blocking=want_loss)
-        if self.fused_adam == 2:
+        if self.fused_adam == 3:
+            # r06: the SH group's step in a kernel that reads the coefficient rows once (update + the sums the position
+            # gradient needs), then the per-gaussian backward with the five small groups' steps inside: no gradient arrays
+            ctx.backward_pass_adam(p, cam, grad_image, bg, self.l_max, self.opt.fused_state(it, mode=2))
+        elif self.fused_adam == 2:
             # r06: the per-gaussian backward applies the optimizer step itself (no gradient arrays at all)
             ctx.backward_pass_adam(p, cam, grad_image, bg, self.l_max, self.opt.fused_state(it))
         elif self.fused_adam == 1:

@@ -820,7 +820,7 @@ def run_rank(args, comm, device_index):
 
     # ---- the whole training iteration (SURVEY 8f rows f1 + f2 around the path): rasterize -> fused L1+SSIM loss ->
     # backward with the uv intermediates -> masked in-place Adam; outside the timed region, last (it moves the parameters)
-    train_ms = train_ms_partial = train_ms_fused = None
+    train_ms = train_ms_partial = train_ms_fused = train_ms_two = None
     if do_bwd and os.environ.get("GSPLAT_BENCH_TRAIN_STEP", "1") != "0":
         ops = importlib.import_module("3dgs_amd.ops")
         opt_mod = importlib.import_module("3dgs_amd.optimizer")
@@ -835,7 +835,10 @@ def run_rank(args, comm, device_index):
         def train_step(it, fused):
             f = step.ctx.rasterize_image(dp_train, dc, cfg, 0.0, L)
             ops.fused_loss(f["image"], target, H, W, 0.2, loss_grad, blocking=False)
-            if fused == 2:  # r06 (opt-in): the per-gaussian backward applies the optimizer step itself
+            if fused == 3:  # r06: the SH group's step in a kernel of its own in front (one read of the coefficient rows),
+                # then the per-gaussian backward with the five small groups' steps inside
+                step.ctx.backward_pass_adam(dp_train, dc, loss_grad, 0.0, L, opt.fused_state(it, mode=2))
+            elif fused == 2:  # r06 (opt-in): the per-gaussian backward applies the optimizer step itself
                 step.ctx.backward_pass_adam(dp_train, dc, loss_grad, 0.0, L, opt.fused_state(it))
             elif fused == 1:  # r06: four groups + the statistics inside the backward, SH and position groups behind it
                 step.ctx.backward_pass_adam(dp_train, dc, loss_grad, 0.0, L, opt.fused_state(it, mode=1), pgrads)
@@ -848,7 +851,7 @@ def run_rank(args, comm, device_index):
         train_variants = {}
         it0 = 0
         pgrads = dict(xyz=tgrads["xyz"], precompute_rgb=tgrads["precompute_rgb"])
-        for fused in (0, 1, 2):
+        for fused in (0, 1, 2, 3):
             for it in range(10):
                 train_step(it0 + it, fused)
             torch.cuda.synchronize()
@@ -859,6 +862,7 @@ def run_rank(args, comm, device_index):
             train_variants[fused] = (time.perf_counter() - t1) / reps_tr * 1e3
             it0 += 10 + reps_tr
         train_ms, train_ms_partial, train_ms_fused = train_variants[0], train_variants[1], train_variants[2]
+        train_ms_two = train_variants[3]
         del dp_train, opt, tgrads, loss_grad, target
 
     # ---- three views in turn on one context (extra key): the forward queues its tail -- placement, per-tile sorts,
@@ -1018,6 +1022,9 @@ def run_rank(args, comm, device_index):
         "train_step_ms_adam_inside_the_backward": train_ms_fused,
         # ... and with band 0 / opacity / scale / rotation + the statistics inside the backward, SH and position behind it
         "train_step_ms_small_groups_inside_the_backward": train_ms_partial,
+        # ... and as two kernels: the SH group's step in front (coefficient rows read once: update + the sums the position
+        # gradient needs), then the backward with the five small groups' steps inside (gsplat_adam_fused.mode 2)
+        "train_step_ms_sh_step_in_front_of_the_backward": train_ms_two,
         "ms_per_step_stats": step_stats,
         "ms_per_step_full_forward_outputs": ms_other_mode if lean_headline else ms,
         "ms_per_step_lean_forward": ms if lean_headline else ms_other_mode,

@@ -399,7 +399,11 @@ typedef struct gsplat_adam_fused {
                                       * statistics in the kernel; it stores grad_xyz and grad_precompute_rgb (`out` must hold
                                       * them) and the caller runs gsplat_optimizer_step_sh_factored and then
                                       * gsplat_optimizer_step on the xyz group alone -- the positions must not move before
-                                      * the SH group has taken its directions from them */
+                                      * the SH group has taken its directions from them.  2: all six groups, in TWO kernels:
+                                      * the SH group's step in a kernel of its own in front, which reads the coefficient rows
+                                      * once -- for the update and for the sums over them that the position gradient needs
+                                      * (handed on in a [M,3] array of the context) -- then the per-gaussian backward with the
+                                      * five small groups, which no longer reads the SH rows at all.  Same bits as modes 0, 1 */
 } gsplat_adam_fused;
 
 int gsplat_context_create(gsplat_context **out, int max_gaussians, int max_width, int max_height);

@@ -152,7 +152,7 @@ def test_factored_sh_step_equals_the_stored_gradient_step(gpu, scene, name):
         ob.step(13, fwd, g_fact)  # no camera position: the direction cannot be rebuilt
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("name", ["small", "small_l1", "small_l0", "mid_l2"])
 def test_backward_with_adam_inside_equals_backward_then_optimizer(gpu, scene, name, mode):
     """r06: gsplat_backward_gaussians_adam -- the per-gaussian backward that applies the masked Adam step itself -- must
@@ -192,8 +192,10 @@ def test_backward_with_adam_inside_equals_backward_then_optimizer(gpu, scene, na
                 t.fill_(float("nan"))
         ctx.backward_gaussians(dp_a, dc, L, g_a)
         oa.step(it, fwd, g_a, campos=cam["campos"])
-        if mode == 0:  # twin B: one kernel; on the second step without gradient arrays at all (what the trainer does)
-            ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it), g_b if it == 20 else None)
+        if mode in (0, 2):  # twin B: one kernel (0), or the SH group's kernel in front of the backward with the small
+            # groups' steps (2: sh_adam_dir_kernel reads the coefficient rows once and hands the position gradient through
+            # the view direction on); on the second step without gradient arrays at all (what the trainer does)
+            ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it, mode=mode), g_b if it == 20 else None)
         else:  # mode 1: four groups + statistics in the kernel, then the SH and the position group behind it
             g_part = g_b if it == 20 else dict(xyz=g_b["xyz"], precompute_rgb=g_b.get("precompute_rgb"))
             ctx.backward_gaussians_adam(dp_b, dc, L, ob.fused_state(it, mode=1), g_part)

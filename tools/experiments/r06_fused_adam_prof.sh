@@ -8,6 +8,6 @@ python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
     n=r['Name']
-    if any(k in n for k in ('preprocess_bwd','optimizer_','loss_','render_bwd')):
+    if any(k in n for k in ('preprocess_bwd','optimizer_','loss_','render_bwd','sh_adam_dir')):
         print(f"{n[:110]:110s} calls {r['Calls']:>4s} avg_us {float(r['AverageNs'])/1e3:8.1f}")
 PY
