@@ -1016,9 +1016,13 @@ def run_rank(args, comm, device_index):
                                                              chunks=step.chunks)} if world > 1 else {})
         | {f"{p}_at_8_ranks": gdist.exchange_model(8, N, L, p) for p in ("full", "factored", "split", "split_direct")},
         "render_fps_forward_only": fps, "render_fps_render_only_context": fps_render_only,
-        "train_step_ms_with_loss_and_adam": train_ms,
-        # r06: the same iteration with the optimizer step INSIDE the per-gaussian backward (gsplat_backward_gaussians_adam,
-        # Trainer under GSPLAT_FUSED_ADAM=1): bit-identical results, one kernel instead of three -- and no faster
+        # (the Trainer's choreography: since r06 the small groups' steps inside the per-gaussian backward, the SH and the
+        # position group behind it -- the same number as train_step_ms_small_groups_inside_the_backward below)
+        "train_step_ms_with_loss_and_adam": train_ms_partial,
+        # backward -> stored gradients -> the two optimizer kernels (the Trainer's choreography of r01-r05)
+        "train_step_ms_optimizer_kernels_behind_the_backward": train_ms,
+        # r06: the same iteration with the WHOLE optimizer step inside the per-gaussian backward (gsplat_backward_gaussians_adam
+        # mode 0, Trainer under GSPLAT_FUSED_ADAM=2): bit-identical results, one kernel instead of three -- and no faster
         "train_step_ms_adam_inside_the_backward": train_ms_fused,
         # ... and with band 0 / opacity / scale / rotation + the statistics inside the backward, SH and position behind it
         "train_step_ms_small_groups_inside_the_backward": train_ms_partial,
